@@ -1,0 +1,177 @@
+"""ctypes binding of libbzhip.so (include/bzhip.h).  No CPU fallback: if the library or a
+gfx950 device is missing, calls raise."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbzhip.so")
+
+u8p = ctypes.POINTER(ctypes.c_uint8)
+u16p = ctypes.POINTER(ctypes.c_uint16)
+u32p = ctypes.POINTER(ctypes.c_uint32)
+u64p = ctypes.POINTER(ctypes.c_uint64)
+szp = ctypes.POINTER(ctypes.c_size_t)
+
+
+class BzhError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        super().__init__(f"bzhip status {status}: {detail}")
+
+
+class Block(ctypes.Structure):
+    _fields_ = [("in_off", ctypes.c_uint64), ("in_len", ctypes.c_uint64), ("rle_len", ctypes.c_uint32),
+                ("crc", ctypes.c_uint32)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_double) for k in
+                ("ms_plan", "ms_rle1", "ms_bwt", "ms_mtf", "ms_huff", "ms_pack", "ms_total", "ms_bwt_sort")] + \
+               [(k, ctypes.c_uint64) for k in
+                ("bwt_sort_launches", "bwt_sort_elems", "raw_bytes", "rle_bytes", "mtf_syms", "out_bits",
+                 "bwt_rounds", "bwt_active_sum")] + \
+               [("blocks", ctypes.c_uint32), ("pad", ctypes.c_uint32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "pad"}
+
+
+# name -> (restype, argtypes); also the list the symbol-export test checks against include/bzhip.h
+SIGNATURES = {
+    "bzh_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "bzh_destroy": (None, [ctypes.c_void_p]),
+    "bzh_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "bzh_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "bzh_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "bzh_set_profiling": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "bzh_get_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Stats)]),
+    "bzh_encode": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_size_t, u8p, ctypes.c_size_t, szp, szp]),
+    "bzh_encode_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                         ctypes.c_size_t, szp, szp]),
+    "bzh_plan_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, szp]),
+    "bzh_plan_blocks": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Block), ctypes.c_size_t]),
+    "bzh_encode_range_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p,
+                                               ctypes.c_size_t, u64p]),
+    "bzh_assemble_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), u64p, ctypes.c_size_t,
+                                           u32p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, szp]),
+    "bzh_rle1_split": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_size_t, ctypes.POINTER(Block), ctypes.c_size_t,
+                                      szp, u8p, ctypes.c_size_t]),
+    "bzh_crc32": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_size_t, u32p]),
+    "bzh_bwt_batch": (ctypes.c_int, [ctypes.c_void_p, u8p, u64p, u32p, ctypes.c_size_t, u8p, u32p, u8p]),
+    "bzh_bwt": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_size_t, u8p, u32p, u8p]),
+    "bzh_mtf": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_size_t, u8p, u16p, szp, u32p, u32p]),
+    "bzh_huffman": (ctypes.c_int, [ctypes.c_void_p, u16p, ctypes.c_size_t, ctypes.c_uint32, u32p, u8p,
+                                   ctypes.c_size_t, u64p, u8p, u32p]),
+}
+
+
+def build(force=False):
+    """Compile libbzhip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "bzhip.h"))
+    newest = max(os.path.getmtime(s) for s in srcs)
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
+        subprocess.check_call(["make", "-C", src_dir, "-s", "-j4"])
+    return LIB_PATH
+
+
+_lib = None
+MISSING = []
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BzhError(-3, f"{LIB_PATH} is missing: build it with banzai_amd._native.build() "
+                               "(there is no CPU fallback)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(L, name)
+            except AttributeError:
+                MISSING.append(name)  # the export test requires this list to stay empty
+                continue
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def ptr(a, t=u8p):
+    return a.ctypes.data_as(t)
+
+
+class Context:
+    """One context per GPU (bzh_create / bzh_destroy)."""
+
+    def __init__(self, device=0, level=9, max_batch=0):
+        self._h = ctypes.c_void_p()
+        self.level = level
+        st = lib().bzh_create(ctypes.byref(self._h), device, level, max_batch)
+        if st != 0:
+            self._h = None
+            raise BzhError(st, lib().bzh_strerror(st).decode())
+
+    def close(self):
+        if self._h:
+            lib().bzh_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def check(self, st):
+        if st != 0:
+            raise BzhError(st, lib().bzh_strerror(st).decode() + ": " + lib().bzh_last_error(self._h).decode())
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_stream(self, stream_ptr):
+        self.check(lib().bzh_set_stream(self._h, ctypes.c_void_p(stream_ptr)))
+
+    def set_profiling(self, on=True):
+        self.check(lib().bzh_set_profiling(self._h, 1 if on else 0))
+
+    def stats(self):
+        s = Stats()
+        self.check(lib().bzh_get_stats(self._h, ctypes.byref(s)))
+        return s.as_dict()
+
+    # ---- stage seams (host numpy in / out) ----
+    def bwt(self, data):
+        a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        n = a.size
+        src = np.ascontiguousarray(a) if n else np.zeros(1, np.uint8)
+        out = np.zeros(max(n, 1), dtype=np.uint8)
+        p = ctypes.c_uint32(0)
+        hb = np.zeros(256, dtype=np.uint8)
+        self.check(lib().bzh_bwt(self._h, ptr(src), n, ptr(out), ctypes.byref(p), ptr(hb)))
+        return out[:n].tobytes(), int(p.value), hb
+
+    def bwt_batch(self, blocks):
+        lens = np.array([len(b) for b in blocks], dtype=np.uint32)
+        offs = np.zeros(len(blocks), dtype=np.uint64)
+        offs[1:] = np.cumsum(lens[:-1], dtype=np.uint64)
+        cat = np.frombuffer(b"".join(bytes(b) for b in blocks), dtype=np.uint8).copy()
+        out = np.zeros_like(cat)
+        ptrs = np.zeros(len(blocks), dtype=np.uint32)
+        hb = np.zeros(len(blocks) * 256, dtype=np.uint8)
+        self.check(lib().bzh_bwt_batch(self._h, ptr(cat), ptr(offs, u64p), ptr(lens, u32p), len(blocks), ptr(out),
+                                       ptr(ptrs, u32p), ptr(hb)))
+        res = []
+        for k in range(len(blocks)):
+            o = int(offs[k])
+            res.append((out[o:o + int(lens[k])].tobytes(), int(ptrs[k]), hb[k * 256:(k + 1) * 256].copy()))
+        return res

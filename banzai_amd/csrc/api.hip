@@ -1,0 +1,251 @@
+// api.hip -- the C ABI of libbzhip.so (include/bzhip.h): context, workspace, whole-path drivers
+// and the host-pointer stage seams used by the parity tests.
+//
+// Whole path = the loop of banzai::encode (reference lib/lib.rs:84-132) turned inside out:
+//   plan    : RLE1 run scan + every block cut + block CRCs            (rle1.hip)
+//   batches : RLE1 emit -> BWT -> MTF/RLE2 -> Huffman tables + bit lengths (all blocks at once)
+//   pack    : block headers + payload bits written straight at their final bit offset
+//   assemble: "BZh9", stream CRC fold, footer
+#include <stdarg.h>
+#include <algorithm>
+
+#include "common.h"
+
+void bzh_set_error(bzh_ctx *ctx, const char *fmt, ...)
+{
+    if (!ctx) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+    va_end(ap);
+}
+
+hipEvent_t bzh_event(bzh_ctx *ctx)
+{
+    if (ctx->evnext == ctx->evpool.size()) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        ctx->evpool.push_back(e);
+    }
+    return ctx->evpool[ctx->evnext++];
+}
+
+extern "C" const char *bzh_strerror(int status)
+{
+    switch (status) {
+    case BZH_OK: return "ok";
+    case BZH_E_ARG: return "invalid argument";
+    case BZH_E_NOMEM: return "out of memory";
+    case BZH_E_HIP: return "HIP runtime error or no usable gfx950 device";
+    case BZH_E_CAP: return "output buffer too small";
+    case BZH_E_STATE: return "call sequence error";
+    default: return "unknown status";
+    }
+}
+
+extern "C" const char *bzh_last_error(const bzh_ctx *ctx) { return ctx ? ctx->err : "no context"; }
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+template <typename T>
+static void carve(uint8_t *&p, T *&dst, size_t count)
+{
+    dst = reinterpret_cast<T *>(p);
+    p += align_up(count * sizeof(T), 256);
+}
+
+// Lays the batch arrays out in the arena; with base == nullptr only measures.
+static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
+{
+    bt.B = B;
+    bt.M = M;
+    bt.S = (uint32_t)align_up((size_t)M + 1, SORT_TILE);
+    bt.TPB = bt.S / SORT_TILE;
+    const size_t S = bt.S, NB = B;
+    const size_t MT = (S + MTF_TILE - 1) / MTF_TILE;
+    const size_t PT = (S + 64 + PACK_TILE - 1) / PACK_TILE;
+    uint8_t *p = base;
+    carve(p, bt.rle, NB * S);
+    carve(p, bt.n, NB);
+    carve(p, bt.bwt, NB * S);
+    carve(p, bt.ptr, NB);
+    carve(p, bt.hasbyte, NB * 256);
+    carve(p, bt.rank, NB * S);
+    carve(p, bt.sa, NB * S);
+    carve(p, bt.listA, NB * S);
+    carve(p, bt.listB, NB * S);
+    carve(p, bt.hist, NB * 256 * bt.TPB);
+    carve(p, bt.flg, NB * S);
+    carve(p, bt.tagg, NB * bt.TPB);
+    carve(p, bt.nactA, NB);
+    carve(p, bt.nactB, NB);
+    carve(p, bt.mtfpos, NB * S);
+    carve(p, bt.tilelist, NB * MT * 256);
+    carve(p, bt.tinfo, NB * MT * 4);
+    carve(p, bt.syms, NB * (S + 64));
+    carve(p, bt.m, NB);
+    carve(p, bt.freqs, NB * 258);
+    carve(p, bt.nsyms, NB);
+    carve(p, bt.tfreq, NB * 3 * 258);
+    carve(p, bt.lens, NB * 3 * 258);
+    carve(p, bt.ntab, NB);
+    carve(p, bt.codes, NB * 258);
+    carve(p, bt.hdr, NB * HDR_BYTES);
+    carve(p, bt.hdrbits, NB);
+    carve(p, bt.bits, NB);
+    carve(p, bt.bitoff, NB + 1);
+    carve(p, bt.symbits, NB * PT);
+    carve(p, bt.desc, NB);
+    return (size_t)(p - base);
+}
+
+extern "C" int bzh_create(bzh_ctx **out, int device, int level, int max_batch)
+{
+    if (!out || level < 1 || level > 9 || max_batch < 0) return BZH_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return BZH_E_HIP;
+    if (hipSetDevice(device) != hipSuccess) return BZH_E_HIP;
+    bzh_ctx *ctx = new (std::nothrow) bzh_ctx();
+    if (!ctx) return BZH_E_NOMEM;
+    ctx->device = device;
+    ctx->level = level;
+    ctx->M = 100000u * (uint32_t)level - 1u; // lib/rle.rs:121
+    ctx->max_batch = max_batch ? (uint32_t)max_batch : 128u;
+    Batch probe{};
+    ctx->arena_size = layout_batch(probe, nullptr, ctx->max_batch, ctx->M);
+    if (probe.TPB > 1024) {
+        delete ctx;
+        return BZH_E_ARG;
+    }
+    if (hipMalloc((void **)&ctx->arena, ctx->arena_size) != hipSuccess) {
+        delete ctx;
+        return BZH_E_NOMEM;
+    }
+    layout_batch(ctx->bt, ctx->arena, ctx->max_batch, ctx->M);
+    ctx->S = ctx->bt.S;
+    if (hipHostMalloc((void **)&ctx->h_pinned, sizeof(uint32_t) * (ctx->max_batch * 8 + 64)) != hipSuccess) {
+        hipFree(ctx->arena);
+        delete ctx;
+        return BZH_E_NOMEM;
+    }
+    *out = ctx;
+    return BZH_OK;
+}
+
+extern "C" void bzh_destroy(bzh_ctx *ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipDeviceSynchronize();
+    for (hipEvent_t e : ctx->evpool) hipEventDestroy(e);
+    if (ctx->arena) hipFree(ctx->arena);
+    if (ctx->plan_ws) hipFree(ctx->plan_ws);
+    if (ctx->d_stage_in) hipFree(ctx->d_stage_in);
+    if (ctx->d_stage_out) hipFree(ctx->d_stage_out);
+    if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+    delete ctx;
+}
+
+extern "C" int bzh_set_stream(bzh_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return BZH_E_ARG;
+    ctx->stream = (hipStream_t)hip_stream;
+    return BZH_OK;
+}
+
+extern "C" int bzh_set_profiling(bzh_ctx *ctx, int enabled)
+{
+    if (!ctx) return BZH_E_ARG;
+    ctx->profiling = enabled ? 1 : 0;
+    return BZH_OK;
+}
+
+extern "C" int bzh_get_stats(const bzh_ctx *ctx, bzh_stats *out)
+{
+    if (!ctx || !out) return BZH_E_ARG;
+    *out = ctx->stats;
+    return BZH_OK;
+}
+
+static void stats_begin(bzh_ctx *ctx)
+{
+    memset(&ctx->stats, 0, sizeof ctx->stats);
+    ctx->evnext = 0;
+    ctx->sort_spans.clear();
+}
+
+static void stats_collect_sort(bzh_ctx *ctx)
+{
+    double ms = 0;
+    for (auto &sp : ctx->sort_spans) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, sp.first, sp.second) == hipSuccess) ms += t;
+    }
+    ctx->stats.ms_bwt_sort = ms;
+}
+
+static int ensure_stage(bzh_ctx *ctx, uint8_t *&buf, size_t &cur, size_t need)
+{
+    if (need <= cur) return BZH_OK;
+    if (buf) hipFree(buf);
+    buf = nullptr;
+    cur = 0;
+    size_t want = align_up(need + need / 8 + 4096, 4096);
+    if (hipMalloc((void **)&buf, want) != hipSuccess) {
+        bzh_set_error(ctx, "hipMalloc(%zu) failed", want);
+        return BZH_E_NOMEM;
+    }
+    cur = want;
+    return BZH_OK;
+}
+
+// ---- stage seam: BWT ---------------------------------------------------------------------------------
+extern "C" int bzh_bwt_batch(bzh_ctx *ctx, const uint8_t *in, const uint64_t *offs, const uint32_t *lens,
+                             size_t nblk, uint8_t *bwt_out, uint32_t *ptr, uint8_t *has_byte)
+{
+    if (!ctx || !in || !offs || !lens || !bwt_out || !ptr || !has_byte) return BZH_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    stats_begin(ctx);
+    Batch &bt = ctx->bt;
+    for (size_t k0 = 0; k0 < nblk; k0 += ctx->max_batch) {
+        uint32_t B = (uint32_t)std::min<size_t>(ctx->max_batch, nblk - k0);
+        uint32_t nmax = 0;
+        for (uint32_t b = 0; b < B; b++) {
+            uint32_t n = lens[k0 + b];
+            if (n == 0 || n > ctx->M) {
+                bzh_set_error(ctx, "block %zu length %u outside 1..%u", k0 + b, n, ctx->M);
+                return BZH_E_ARG;
+            }
+            nmax = std::max(nmax, n);
+            HIP_TRY(ctx, hipMemcpyAsync(bt.rle + (size_t)b * bt.S, in + offs[k0 + b], n, hipMemcpyHostToDevice,
+                                        ctx->stream));
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(bt.n, lens + k0, B * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        BZH_TRY(bwt_run(ctx, B, nmax));
+        for (uint32_t b = 0; b < B; b++)
+            HIP_TRY(ctx, hipMemcpyAsync(bwt_out + offs[k0 + b], bt.bwt + (size_t)b * bt.S, lens[k0 + b],
+                                        hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ptr + k0, bt.ptr, B * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(has_byte + k0 * 256, bt.hasbyte, (size_t)B * 256, hipMemcpyDeviceToHost,
+                                    ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (ctx->profiling) stats_collect_sort(ctx);
+    return BZH_OK;
+}
+
+extern "C" int bzh_bwt(bzh_ctx *ctx, const uint8_t *in, size_t n, uint8_t *bwt_out, uint32_t *ptr,
+                       uint8_t *has_byte)
+{
+    if (!ctx || !ptr || !has_byte) return BZH_E_ARG;
+    if (n == 0) { // lib/bwt.rs:535-541
+        memset(has_byte, 0, 256);
+        *ptr = UINT32_MAX;
+        return BZH_OK;
+    }
+    if (n > ctx->M) return BZH_E_ARG;
+    uint64_t off = 0;
+    uint32_t len = (uint32_t)n;
+    return bzh_bwt_batch(ctx, in, &off, &len, 1, bwt_out, ptr, has_byte);
+}

@@ -1,0 +1,203 @@
+// common.h -- shared declarations of libbzhip.so (MI355X / gfx950 only).
+// Context, workspace arena, error plumbing and the wavefront-64 scan primitives every stage uses.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/bzhip.h"
+
+#define BZH_WAVE 64
+
+// ---- error plumbing -----------------------------------------------------------------------
+struct bzh_ctx;
+void bzh_set_error(bzh_ctx *ctx, const char *fmt, ...);
+
+#define HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            bzh_set_error((ctx), "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+            return BZH_E_HIP;                                                                      \
+        }                                                                                          \
+    } while (0)
+
+#define BZH_TRY(expr)                                                                              \
+    do {                                                                                           \
+        int s_ = (expr);                                                                           \
+        if (s_ != BZH_OK) return s_;                                                               \
+    } while (0)
+
+// ---- geometry -----------------------------------------------------------------------------
+// Every per-block device array uses one stride S (bytes/elements per bzip2 block), a multiple
+// of the sort tile so tiles never straddle blocks.
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_ITEMS = 16;
+constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS; // 4096 elements per workgroup
+constexpr uint32_t RANK_RESOLVED = 0x80000000u;      // suffix is alone in its group
+
+struct BlockDesc { // device-side description of one planned block (mirrors bzh_block + restart info)
+    uint64_t in_off;
+    uint64_t in_len;
+    uint32_t rle_len;
+    uint32_t crc;
+};
+
+// Device arrays of one batch of B blocks.  Passed to kernels by value.
+struct Batch {
+    uint32_t B;       // blocks in this batch
+    uint32_t S;       // stride (elements) between blocks in per-block arrays
+    uint32_t TPB;     // sort tiles per block stride (S / SORT_TILE)
+    uint32_t M;       // max RLE1 bytes per block (100000*level-1)
+    uint8_t *rle;     // [B][S]  RLE1 output = BWT input
+    uint32_t *n;      // [B]     RLE1 length per block
+    uint8_t *bwt;     // [B][S]
+    uint32_t *ptr;    // [B]
+    uint8_t *hasbyte; // [B][256]
+    // suffix sorting
+    uint32_t *rank; // [B][S]
+    uint32_t *sa;   // [B][S]
+    uint2 *listA;   // [B][S] (key, suffix)
+    uint2 *listB;   // [B][S]
+    uint32_t *hist; // [B][256*TPB]
+    uint8_t *flg;   // [B][S]
+    int2 *tagg;     // [B][TPB] tile aggregates (last group start, last boundary)
+    uint32_t *nactA; // [B]
+    uint32_t *nactB; // [B]
+    // MTF / RLE2
+    uint8_t *mtfpos;   // [B][S]   MTF position of every BWT byte
+    uint8_t *tilelist; // [B][MT][256] recency list at each MTF tile entry
+    uint32_t *tinfo;   // [B][MT][4] per-tile zero-run bookkeeping
+    uint16_t *syms;    // [B][S+64]
+    uint32_t *m;       // [B]   symbol count incl. EOB
+    uint32_t *freqs;   // [B][258]
+    uint32_t *nsyms;   // [B]
+    // Huffman
+    uint32_t *tfreq;   // [B][3][258]
+    uint8_t *lens;     // [B][3][258]
+    uint32_t *ntab;    // [B]
+    uint32_t *codes;   // [B][258]  (len << 24 | word) for table 0
+    uint8_t *hdr;      // [B][HDR_BYTES] per-block header bits (block header .. coding tables)
+    uint32_t *hdrbits; // [B]
+    uint64_t *bits;    // [B]   total bits of the block
+    uint64_t *bitoff;  // [B+1] exclusive scan of bits
+    uint32_t *symbits; // [B][PT] per pack tile bit counts
+    BlockDesc *desc;   // [B]
+};
+
+constexpr uint32_t MTF_TILE = 2048;  // BWT bytes walked by one wavefront
+constexpr uint32_t HDR_BYTES = 1024; // block header + symbol map + selectors excluded + 3 tables < 8192 bits
+constexpr uint32_t PACK_TILE = 4096; // MTF symbols packed by one workgroup
+
+struct Timer {
+    hipEvent_t a = nullptr, b = nullptr;
+};
+
+struct bzh_ctx {
+    int device = 0;
+    int level = 9;
+    uint32_t M = 0;
+    uint32_t S = 0;
+    uint32_t max_batch = 0;
+    hipStream_t stream = nullptr;
+    int profiling = 0;
+    char err[512] = {0};
+    // arena
+    uint8_t *arena = nullptr;
+    size_t arena_size = 0;
+    Batch bt{};
+    // plan
+    const uint8_t *plan_in = nullptr; // device
+    size_t plan_n = 0;
+    std::vector<bzh_block> plan_blocks;
+    std::vector<uint32_t> plan_restart; // per block: offset inside the first run where it (re)starts
+    void *plan_ws = nullptr;            // device scratch of the plan (run tables)
+    size_t plan_ws_size = 0;
+    // staging
+    uint8_t *d_stage_in = nullptr;
+    size_t stage_in_size = 0;
+    uint8_t *d_stage_out = nullptr;
+    size_t stage_out_size = 0;
+    uint32_t *h_pinned = nullptr; // small pinned readback area
+    bzh_stats stats{};
+    std::vector<hipEvent_t> evpool;
+    size_t evnext = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> sort_spans;
+};
+
+// ---- wavefront-64 primitives ----------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int wave_incl_max(int v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (lane >= d) v = max(v, t);
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// Workgroup exclusive add-scan of one value per thread.  `lds` needs (threads/64)+1 words.
+// Returns the exclusive prefix; *total receives the workgroup sum.
+__device__ __forceinline__ uint32_t block_excl_add(uint32_t v, uint32_t *lds, uint32_t *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    uint32_t inc = wave_incl_add(v, lane);
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t w = lane < nw ? lds[lane] : 0;
+        uint32_t wi = wave_incl_add(w, lane);
+        if (lane < nw) lds[lane] = wi - w;
+        if (lane == nw - 1) lds[nw] = wi;
+    }
+    __syncthreads();
+    uint32_t res = inc - v + lds[wave];
+    *total = lds[nw];
+    __syncthreads();
+    return res;
+}
+
+// Workgroup inclusive max-scan of one int per thread. `lds` needs (threads/64) ints.
+__device__ __forceinline__ int block_incl_max(int v, int *lds)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    int inc = wave_incl_max(v, lane);
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    int carry = INT32_MIN;
+    for (int w = 0; w < wave; w++) carry = max(carry, lds[w]);
+    (void)nw;
+    int res = max(inc, carry);
+    __syncthreads();
+    return res;
+}
+
+// ---- stage entry points (host side, defined in the stage files) ---------------------------------
+int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax);                 // bwt.hip
+int mtf_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax);                 // mtf.hip
+int huff_prepare(bzh_ctx *ctx, uint32_t B, uint32_t mmax);            // huffman.hip: tables, header bits, bit totals
+int huff_pack(bzh_ctx *ctx, uint32_t B, uint32_t mmax, uint8_t *d_out, uint64_t bit_base); // huffman.hip
+int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n);           // rle1.hip
+int rle1_emit(bzh_ctx *ctx, size_t b0, uint32_t B);                   // rle1.hip: fill bt.rle / bt.n / bt.desc
+int crc_device(bzh_ctx *ctx, const uint8_t *d_in, size_t n, uint32_t *crc_out); // rle1.hip
+
+hipEvent_t bzh_event(bzh_ctx *ctx);

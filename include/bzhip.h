@@ -1,0 +1,134 @@
+/*
+ * bzhip.h -- C ABI of libbzhip.so: an MI355X (gfx950) bzip2 block encoder that emits the
+ * same bits as jgbyrne/banzai v0.3.1.
+ *
+ * The reference has no FFI; its boundary is the crate's public functions and the private
+ * per-stage functions.  Each entry point below names the reference
+ * interface it replaces.  Conventions: plain pointers and sizes, caller-owned buffers, int
+ * status (0 = ok, negative = bzh_status), nothing unwinds across the ABI.  A context is bound
+ * to ONE GPU (one process per GPU) and is single-threaded; distinct contexts may run
+ * concurrently.  Pointers named d_* are DEVICE pointers (HBM); all others are host pointers.
+ * There is no CPU fallback: every entry point that computes fails with BZH_E_HIP when no
+ * gfx950 device is usable.
+ */
+#ifndef BZHIP_H
+#define BZHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(BZH_BUILD)
+#define BZH_API __attribute__((visibility("default")))
+#else
+#define BZH_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bzh_ctx bzh_ctx;
+
+typedef enum {
+    BZH_OK = 0,
+    BZH_E_ARG = -1,   /* bad argument (reference: assert!/panic!, lib/lib.rs:89) */
+    BZH_E_NOMEM = -2, /* host or device allocation failed */
+    BZH_E_HIP = -3,   /* HIP runtime error / no usable device */
+    BZH_E_CAP = -4,   /* output buffer too small; *out_len holds the size needed where stated */
+    BZH_E_STATE = -5  /* call sequence error (e.g. encode_range without a plan) */
+} bzh_status;
+
+/* One bzip2 block of a plan: which raw bytes it consumes and what RLE1 makes of them.
+ * Mirrors `Rle { output, chk, raw, consumed }` (lib/rle.rs:94-99) minus the byte vectors. */
+typedef struct {
+    uint64_t in_off;  /* first raw byte of the block                                   */
+    uint64_t in_len;  /* raw bytes consumed (Rle::consumed)                             */
+    uint32_t rle_len; /* RLE1 output bytes, <= 100000*level-1 (lib/rle.rs:121)          */
+    uint32_t crc;     /* CRC-32/BZIP2 of the raw bytes (Rle::chk, lib/crc32.rs:31-48)   */
+} bzh_block;
+
+/* Per-stage device timings (milliseconds, HIP events on the context's stream) and counters of
+ * the last bzh_encode* / bzh_encode_range_device call; filled when profiling is enabled. */
+typedef struct {
+    double ms_plan, ms_rle1, ms_bwt, ms_mtf, ms_huff, ms_pack, ms_total;
+    double ms_bwt_sort;           /* radix scatter+histogram kernels only (dominant kernel class) */
+    uint64_t bwt_sort_launches;   /* number of radix scatter launches timed in ms_bwt_sort       */
+    uint64_t bwt_sort_elems;      /* elements moved by those launches                           */
+    uint64_t raw_bytes, rle_bytes, mtf_syms, out_bits;
+    uint64_t bwt_rounds;          /* prefix-doubling rounds run (max over blocks)               */
+    uint64_t bwt_active_sum;      /* sum over rounds and blocks of unresolved suffixes (A)      */
+    uint32_t blocks, pad;
+} bzh_stats;
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+
+/* Create a context on HIP device `device` for block size `level` (1..9; lib/lib.rs:89).
+ * max_batch = bzip2 blocks processed per kernel batch (0 = default). */
+BZH_API int bzh_create(bzh_ctx **ctx, int device, int level, int max_batch);
+BZH_API void bzh_destroy(bzh_ctx *ctx);
+BZH_API const char *bzh_strerror(int status);
+BZH_API const char *bzh_last_error(const bzh_ctx *ctx); /* detail of the last failure on this ctx   */
+BZH_API int bzh_set_stream(bzh_ctx *ctx, void *hip_stream); /* hipStream_t to launch on (default 0) */
+BZH_API int bzh_set_profiling(bzh_ctx *ctx, int enabled);
+BZH_API int bzh_get_stats(const bzh_ctx *ctx, bzh_stats *out);
+
+/* ---- whole path: replaces banzai::encode(reader, writer, level), lib/lib.rs:84-132 -------- */
+
+/* Host buffers in and out (H2D + encode + D2H).  Produces the complete .bz2 stream for the
+ * slice in[0..n) -- identical to encode() fed by a reader that yields the slice -- and
+ * returns the bytes consumed (== n) in *consumed.  BZH_E_CAP if cap is too small. */
+BZH_API int bzh_encode(bzh_ctx *ctx, const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len,
+               size_t *consumed);
+
+/* Same, input and output resident in HBM (the timed path of bench.py). */
+BZH_API int bzh_encode_device(bzh_ctx *ctx, const void *d_in, size_t n, void *d_out, size_t cap, size_t *out_len,
+                      size_t *consumed);
+
+/* ---- block-sharded path (one rank per GPU) -------------------------- */
+
+/* Split d_in[0..n) into blocks: the sequential part of the loop at lib/lib.rs:101-126, i.e.
+ * every rle_one() cut (lib/rle.rs:102-253) and block CRC, without encoding anything.
+ * The plan stays in the context and references d_in (caller keeps it alive). */
+BZH_API int bzh_plan_device(bzh_ctx *ctx, const void *d_in, size_t n, size_t *nblocks);
+BZH_API int bzh_plan_blocks(const bzh_ctx *ctx, bzh_block *out, size_t max_blocks);
+
+/* Encode blocks [b0, b1) of the plan: per block the header (lib/lib.rs:24-36), symbol map
+ * (:39-64) and Huffman payload (lib/huffman.rs:313-575), bit-concatenated from bit 0 of d_out
+ * (MSB first, lib/out.rs), zero padded to a 4-byte multiple.  No stream header/footer. */
+BZH_API int bzh_encode_range_device(bzh_ctx *ctx, size_t b0, size_t b1, void *d_out, size_t cap, uint64_t *nbits);
+
+/* Stream assembly on one GPU: "BZh"+level (lib/lib.rs:18-22), the nseg bit strings
+ * d_segs[k][0..seg_bits[k]) concatenated in order (funnel shift), footer + stream CRC folded
+ * over block_crcs in block order (lib/lib.rs:66-70, :108), zero pad to a byte (lib/out.rs:22-28). */
+BZH_API int bzh_assemble_device(bzh_ctx *ctx, const void *const *d_segs, const uint64_t *seg_bits, size_t nseg,
+                        const uint32_t *block_crcs, size_t nblocks, void *d_out, size_t cap, size_t *out_len);
+
+/* ---- stage seams (host pointers; computed on the GPU; used by the parity tests) ------------ */
+
+/* rle_one() applied repeatedly (lib/rle.rs:102-253): block table for in[0..n) and, if rle_out
+ * is non-NULL, the RLE1 bytes of every block back to back (rle_cap bytes available). */
+BZH_API int bzh_rle1_split(bzh_ctx *ctx, const uint8_t *in, size_t n, bzh_block *blocks, size_t max_blocks,
+                   size_t *nblocks, uint8_t *rle_out, size_t rle_cap);
+
+/* crc32::checksum (lib/crc32.rs:31-48). */
+BZH_API int bzh_crc32(bzh_ctx *ctx, const uint8_t *in, size_t n, uint32_t *crc);
+
+/* bwt::bwt (lib/bwt.rs:526-756) on nblk independent blocks: block k is
+ * in[offs[k] .. offs[k]+lens[k]); bwt_out uses the same offsets; ptr[k]; has_byte[k*256..]. */
+BZH_API int bzh_bwt_batch(bzh_ctx *ctx, const uint8_t *in, const uint64_t *offs, const uint32_t *lens, size_t nblk,
+                  uint8_t *bwt_out, uint32_t *ptr, uint8_t *has_byte);
+BZH_API int bzh_bwt(bzh_ctx *ctx, const uint8_t *in, size_t n, uint8_t *bwt_out, uint32_t *ptr, uint8_t *has_byte);
+
+/* mtf::mtf_and_rle (lib/mtf.rs:14-121): syms must hold n+1 entries, freqs 258. */
+BZH_API int bzh_mtf(bzh_ctx *ctx, const uint8_t *bwt, size_t n, const uint8_t *has_byte, uint16_t *syms, size_t *m,
+            uint32_t *freqs, uint32_t *num_syms);
+
+/* huffman::encode (lib/huffman.rs:313-575) of one block as a standalone bit string from bit 0;
+ * code_lengths (optional) receives num_tables x 258 final lengths, *num_tables the count. */
+BZH_API int bzh_huffman(bzh_ctx *ctx, const uint16_t *syms, size_t m, uint32_t num_syms, const uint32_t *freqs,
+                uint8_t *bits_out, size_t cap, uint64_t *nbits, uint8_t *code_lengths, uint32_t *num_tables);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BZHIP_H */
