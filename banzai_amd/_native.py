@@ -175,3 +175,27 @@ class Context:
             o = int(offs[k])
             res.append((out[o:o + int(lens[k])].tobytes(), int(ptrs[k]), hb[k * 256:(k + 1) * 256].copy()))
         return res
+
+    def mtf(self, bwt_bytes, has_byte):
+        a = np.frombuffer(bytes(bwt_bytes), dtype=np.uint8).copy()
+        n = a.size
+        hb = np.ascontiguousarray(has_byte, dtype=np.uint8)
+        syms = np.zeros(n + 2, dtype=np.uint16)
+        freqs = np.zeros(258, dtype=np.uint32)
+        m = ctypes.c_size_t(0)
+        ns = ctypes.c_uint32(0)
+        self.check(lib().bzh_mtf(self._h, ptr(a), n, ptr(hb), ptr(syms, u16p), ctypes.byref(m), ptr(freqs, u32p),
+                                 ctypes.byref(ns)))
+        return syms[:m.value].copy(), freqs, int(ns.value)
+
+    def huffman(self, syms, num_syms, freqs):
+        s = np.ascontiguousarray(syms, dtype=np.uint16)
+        f = np.ascontiguousarray(freqs, dtype=np.uint32)
+        cap = s.size * 3 + 8192
+        out = np.zeros(cap, dtype=np.uint8)
+        lens = np.zeros(3 * 258, dtype=np.uint8)
+        nb = ctypes.c_uint64(0)
+        nt = ctypes.c_uint32(0)
+        self.check(lib().bzh_huffman(self._h, ptr(s, u16p), s.size, num_syms, ptr(f, u32p), ptr(out), cap,
+                                     ctypes.byref(nb), ptr(lens), ctypes.byref(nt)))
+        return out[:(nb.value + 7) // 8].tobytes(), int(nb.value), lens.reshape(3, 258)[:nt.value].copy()

@@ -91,7 +91,7 @@ static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
     carve(p, bt.ntab, NB);
     carve(p, bt.codes, NB * 258);
     carve(p, bt.hdr, NB * HDR_BYTES);
-    carve(p, bt.hdrbits, NB);
+    carve(p, bt.hdrbits, NB * 4);
     carve(p, bt.bits, NB);
     carve(p, bt.bitoff, NB + 1);
     carve(p, bt.symbits, NB * PT);
@@ -114,7 +114,7 @@ extern "C" int bzh_create(bzh_ctx **out, int device, int level, int max_batch)
     ctx->max_batch = max_batch ? (uint32_t)max_batch : 128u;
     Batch probe{};
     ctx->arena_size = layout_batch(probe, nullptr, ctx->max_batch, ctx->M);
-    if (probe.TPB > 1024) {
+    if (probe.TPB > 1024 || ctx->max_batch > 1024) {
         delete ctx;
         return BZH_E_ARG;
     }
@@ -248,4 +248,88 @@ extern "C" int bzh_bwt(bzh_ctx *ctx, const uint8_t *in, size_t n, uint8_t *bwt_o
     uint64_t off = 0;
     uint32_t len = (uint32_t)n;
     return bzh_bwt_batch(ctx, in, &off, &len, 1, bwt_out, ptr, has_byte);
+}
+
+// ---- stage seam: MTF + RLE2 ---------------------------------------------------------------------------
+extern "C" int bzh_mtf(bzh_ctx *ctx, const uint8_t *bwt, size_t n, const uint8_t *has_byte, uint16_t *syms,
+                       size_t *m, uint32_t *freqs, uint32_t *num_syms)
+{
+    if (!ctx || !bwt || !has_byte || !syms || !m || !freqs || !num_syms || n == 0 || n > ctx->M) return BZH_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    stats_begin(ctx);
+    Batch &bt = ctx->bt;
+    hipStream_t st = ctx->stream;
+    uint32_t n32 = (uint32_t)n;
+    HIP_TRY(ctx, hipMemcpyAsync(bt.bwt, bwt, n, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(bt.n, &n32, sizeof n32, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(bt.hasbyte, has_byte, 256, hipMemcpyHostToDevice, st));
+    BZH_TRY(mtf_run(ctx, 1, n32));
+    uint32_t m32 = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&m32, bt.m, sizeof m32, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(num_syms, bt.nsyms, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(freqs, bt.freqs, 258 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (m32 == 0 || m32 > n32 + 1) {
+        bzh_set_error(ctx, "mtf produced m=%u for n=%u", m32, n32);
+        return BZH_E_HIP;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(syms, bt.syms, (size_t)m32 * sizeof(uint16_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    *m = m32;
+    return BZH_OK;
+}
+
+// ---- stage seam: Huffman ----------------------------------------------------------------------------------
+// The device path always writes a whole block (header + symbol map + payload).  For the seam the
+// block is built with a fixed dummy header (crc 0, ptr 0, only byte 0 present: 105 + 32 bits) and
+// the host strips those 137 bits, leaving exactly what huffman::encode writes (lib/huffman.rs:464-572).
+extern "C" int bzh_huffman(bzh_ctx *ctx, const uint16_t *syms, size_t m, uint32_t num_syms, const uint32_t *freqs,
+                           uint8_t *bits_out, size_t cap, uint64_t *nbits, uint8_t *code_lengths,
+                           uint32_t *num_tables)
+{
+    if (!ctx || !syms || !freqs || !bits_out || !nbits || m == 0 || m > (size_t)ctx->M + 1 || num_syms < 3 ||
+        num_syms > 258)
+        return BZH_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    stats_begin(ctx);
+    Batch &bt = ctx->bt;
+    hipStream_t st = ctx->stream;
+    const uint32_t m32 = (uint32_t)m;
+    uint8_t hb[256] = {1};
+    BlockDesc d{};
+    uint32_t zero = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(bt.syms, syms, m * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(bt.m, &m32, 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(bt.nsyms, &num_syms, 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(bt.freqs, freqs, 258 * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(bt.hasbyte, hb, 256, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(bt.desc, &d, sizeof d, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(bt.ptr, &zero, 4, hipMemcpyHostToDevice, st));
+    BZH_TRY(huff_prepare(ctx, 1, m32));
+    uint64_t total = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&total, bt.bitoff + 1, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    const size_t bytes = (size_t)((total + 31) / 32 * 4);
+    BZH_TRY(ensure_stage(ctx, ctx->d_stage_out, ctx->stage_out_size, bytes));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_stage_out, 0, bytes, st));
+    BZH_TRY(huff_pack(ctx, 1, m32, ctx->d_stage_out, 0));
+    std::vector<uint8_t> tmp(bytes + 8, 0);
+    HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), ctx->d_stage_out, bytes, hipMemcpyDeviceToHost, st));
+    uint32_t nt = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&nt, bt.ntab, 4, hipMemcpyDeviceToHost, st));
+    if (code_lengths) HIP_TRY(ctx, hipMemcpyAsync(code_lengths, bt.lens, 3 * 258, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (num_tables) *num_tables = nt;
+    const uint64_t skip = 105 + 32;
+    const uint64_t pay = total - skip;
+    *nbits = pay;
+    const size_t need = (size_t)((pay + 7) / 8);
+    if (need > cap) return BZH_E_CAP;
+    for (size_t k = 0; k < need; k++) { // shift left by 137 bits = 17 bytes + 1 bit
+        const size_t src = k + skip / 8;
+        const unsigned sh = skip % 8;
+        bits_out[k] = (uint8_t)((tmp[src] << sh) | (tmp[src + 1] >> (8 - sh)));
+    }
+    if (pay % 8) bits_out[need - 1] &= (uint8_t)(0xFF << (8 - pay % 8));
+    return BZH_OK;
 }

@@ -80,7 +80,7 @@ struct Batch {
     uint32_t *ntab;    // [B]
     uint32_t *codes;   // [B][258]  (len << 24 | word) for table 0
     uint8_t *hdr;      // [B][HDR_BYTES] per-block header bits (block header .. coding tables)
-    uint32_t *hdrbits; // [B]
+    uint32_t *hdrbits; // [B][4] bits of part A, selector count, bits of part B, payload bits
     uint64_t *bits;    // [B]   total bits of the block
     uint64_t *bitoff;  // [B+1] exclusive scan of bits
     uint32_t *symbits; // [B][PT] per pack tile bit counts
@@ -88,7 +88,7 @@ struct Batch {
 };
 
 constexpr uint32_t MTF_TILE = 2048;  // BWT bytes walked by one wavefront
-constexpr uint32_t HDR_BYTES = 1024; // block header + symbol map + selectors excluded + 3 tables < 8192 bits
+constexpr uint32_t HDR_BYTES = 4160; // 64 B block header/symbol map/counts + up to 3 delta-coded tables (< 25.6 kbit)
 constexpr uint32_t PACK_TILE = 4096; // MTF symbols packed by one workgroup
 
 struct Timer {

@@ -1,0 +1,544 @@
+// huffman.hip -- Huffman stage + bit packing for a batch of blocks.
+//
+// Replaces huffman::encode (reference lib/huffman.rs:313-575) and the framing writes of
+// lib/lib.rs:24-64 / lib/out.rs.  The reference's behaviour is reproduced, not
+// libbz2's:
+//   * 2 tables if num_syms <= 199 else 3 (lib/huffman.rs:319-326)
+//   * iteration 0 assigns each 50-symbol segment to the table whose initial range holds the
+//     FEWEST of its symbols (length 15 inside the range, 0 outside; :364-372, :424-438)
+//   * iterations 1-3 zero the length tables, so table 0 wins every segment and its frequency
+//     list grows by the global histogram each time (:402-409, :441-443): final frequencies are
+//     f0_0 + 3F for table 0 and f0_t otherwise, every selector is 0, all symbols use table 0
+//   * code lengths from the reference's own binary heap, operation for operation (:165-298)
+//
+// Kernels: huff_init (ranges), huff_segments (segment classification + per-table histograms),
+// huff_build (exact heap, one wavefront per table, lane 0 drives, heap in LDS), huff_header
+// (block header, symbol map, coding tables as a bit string; canonical codes; bit totals),
+// block_scan, pack_tilebits / pack_tilescan / pack_symbols (prefix-sum placed parallel pack through
+// an LDS word buffer), pack_headers.
+#include "common.h"
+
+constexpr int HUF_SYMS = 258;
+constexpr int HUF_MAXLEN = 17; // lib/huffman.rs:13
+constexpr int SEG = 50;        // lib/huffman.rs:310
+constexpr uint32_t HDR_A = 64; // bytes reserved for the part before the selectors
+
+// ---- initial ranges (lib/huffman.rs:333-376) -----------------------------------------------------------
+__global__ void __launch_bounds__(64) huff_init(Batch bt, uint32_t *ranges)
+{
+    const uint32_t b = blockIdx.x;
+    uint32_t *tf = bt.tfreq + (size_t)b * 3 * HUF_SYMS;
+    for (int k = threadIdx.x; k < 3 * HUF_SYMS; k += 64) tf[k] = 0;
+    if (threadIdx.x != 0) return;
+    const uint32_t nsyms = bt.nsyms[b];
+    const uint32_t *F = bt.freqs + (size_t)b * HUF_SYMS;
+    const uint32_t ntab = nsyms <= 199 ? 2 : 3;
+    bt.ntab[b] = ntab;
+    uint32_t remaining = bt.m[b], left = 0;
+    uint32_t *r = ranges + (size_t)b * 8;
+    for (uint32_t t = 0; t < ntab; t++) {
+        const uint32_t target = remaining / (ntab - t);
+        uint32_t acc = 0, right = left;
+        for (;;) {
+            acc += F[right];
+            if (acc >= target || right + 1 == nsyms) break;
+            right++;
+        }
+        if (right > left && t != 0 && t != ntab - 1 && (t & 1u)) {
+            acc -= F[right];
+            right--;
+        }
+        r[2 * t] = left;
+        r[2 * t + 1] = right;
+        left = right + 1;
+        remaining -= acc;
+    }
+    if (ntab == 2) {
+        r[4] = 1; // empty range
+        r[5] = 0;
+    }
+}
+
+// ---- iteration 0: classify segments, accumulate per-table histograms (lib/huffman.rs:411-454) -------
+__global__ void __launch_bounds__(256) huff_segments(Batch bt, const uint32_t *ranges)
+{
+    const uint32_t b = blockIdx.y;
+    const uint32_t m = bt.m[b];
+    const uint32_t nseg = (m + SEG - 1) / SEG;
+    const uint32_t seg0 = blockIdx.x * 256;
+    if (seg0 >= nseg) return;
+    __shared__ uint32_t h[3][HUF_SYMS];
+    for (int k = threadIdx.x; k < 3 * HUF_SYMS; k += 256) (&h[0][0])[k] = 0;
+    __syncthreads();
+    const uint32_t ntab = bt.ntab[b];
+    const uint32_t *r = ranges + (size_t)b * 8;
+    const uint32_t l0 = r[0], r0 = r[1], l1 = r[2], r1 = r[3], l2 = r[4], r2 = r[5];
+    const uint32_t seg = seg0 + threadIdx.x;
+    if (seg < nseg) {
+        const uint16_t *s = bt.syms + (size_t)b * (bt.S + 64) + (size_t)seg * SEG;
+        const uint32_t len = m - seg * SEG < SEG ? m - seg * SEG : SEG;
+        uint32_t c0 = 0, c1 = 0, c2 = 0;
+        // 50 u16 = 100 bytes, 4-byte aligned: read as 25 words
+        uint32_t w[SEG / 2];
+#pragma unroll
+        for (int k = 0; k < SEG / 2; k++) w[k] = reinterpret_cast<const uint32_t *>(s)[k];
+#pragma unroll
+        for (int k = 0; k < SEG; k++) {
+            const uint32_t v = (w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+            if ((uint32_t)k < len) {
+                c0 += (v >= l0 && v <= r0);
+                c1 += (v >= l1 && v <= r1);
+                c2 += (v >= l2 && v <= r2);
+            }
+        }
+        uint32_t best = 0, cost = c0; // cost_t = 15 * count_t; first strict minimum wins
+        if (c1 < cost) {
+            best = 1;
+            cost = c1;
+        }
+        if (ntab == 3 && c2 < cost) best = 2;
+#pragma unroll
+        for (int k = 0; k < SEG; k++) {
+            const uint32_t v = (w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+            if ((uint32_t)k < len) atomicAdd(&h[best][v], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t *tf = bt.tfreq + (size_t)b * 3 * HUF_SYMS;
+    for (int k = threadIdx.x; k < 3 * HUF_SYMS; k += 256) {
+        uint32_t v = (&h[0][0])[k];
+        if (v) atomicAdd(&tf[k], v);
+    }
+}
+
+// ---- exact heap (lib/huffman.rs:161-298) ---------------------------------------------------------------
+struct HeapMem {
+    uint64_t prio[HUF_SYMS + 2]; // (weight << 8) | depth : lexicographic Priority(usize, u8)
+    uint16_t id[HUF_SYMS + 2];
+    int16_t lch[2 * HUF_SYMS], rch[2 * HUF_SYMS];
+    int16_t depth[2 * HUF_SYMS];
+    uint32_t fr[HUF_SYMS];
+};
+
+__device__ void heap_insert(HeapMem &h, uint32_t &len, uint16_t sym, uint64_t pr) // :196-222
+{
+    const uint32_t init_idx = len + 1;
+    h.id[init_idx] = sym;
+    h.prio[init_idx] = pr;
+    len++;
+    if (init_idx == 1) return;
+    uint32_t this_idx = init_idx;
+    for (;;) {
+        const uint32_t above = this_idx >> 1;
+        const uint64_t ap = h.prio[above];
+        if (pr < ap) {
+            h.prio[this_idx] = ap;
+            h.id[this_idx] = h.id[above];
+            this_idx = above;
+            if (this_idx == 1) break;
+        } else {
+            break;
+        }
+    }
+    if (this_idx != init_idx) {
+        h.id[this_idx] = sym;
+        h.prio[this_idx] = pr;
+    }
+}
+
+__device__ void heap_extract(HeapMem &h, uint32_t &len, uint16_t &osym, uint64_t &oprio) // :225-267
+{
+    const uint16_t lsym = h.id[len];
+    const uint64_t lpr = h.prio[len];
+    len--;
+    if (len == 0) {
+        osym = lsym;
+        oprio = lpr;
+        return;
+    }
+    osym = h.id[1];
+    oprio = h.prio[1];
+    uint32_t this_idx = 1;
+    for (;;) {
+        const uint32_t left = this_idx << 1;
+        if (left > len) break;
+        const uint32_t right = left + 1;
+        uint32_t below = left;
+        uint64_t bp = h.prio[left];
+        if (right <= len) {
+            const uint64_t rp = h.prio[right];
+            if (rp < bp) {
+                below = right;
+                bp = rp;
+            }
+        }
+        if (lpr < bp) break;
+        h.prio[this_idx] = bp;
+        h.id[this_idx] = h.id[below];
+        this_idx = below;
+    }
+    h.id[this_idx] = lsym;
+    h.prio[this_idx] = lpr;
+}
+
+__device__ void build_lengths(HeapMem &h, uint32_t nsyms, uint8_t *out) // :271-298
+{
+    uint32_t scaling = 1;
+    for (;;) {
+        uint32_t nnodes = nsyms + 1, len = 0;
+        for (uint32_t s = 0; s < nsyms; s++) heap_insert(h, len, (uint16_t)(s + 1), ((uint64_t)(h.fr[s] / scaling + 1)) << 8);
+        for (;;) {
+            uint16_t a, c;
+            uint64_t pa, pc;
+            heap_extract(h, len, a, pa);
+            heap_extract(h, len, c, pc);
+            if (nnodes == 2 * nsyms - 1) { // Tree::tie :60-74 -- last tie hangs off the root (id 0)
+                h.lch[0] = (int16_t)a;
+                h.rch[0] = (int16_t)c;
+                break;
+            }
+            const uint32_t parent = nnodes++;
+            h.lch[parent] = (int16_t)a;
+            h.rch[parent] = (int16_t)c;
+            const uint64_t da = pa & 0xFF, dc = pc & 0xFF;
+            const uint64_t pr = (((pa >> 8) + (pc >> 8)) << 8) | ((da > dc ? da : dc) + 1); // :147-158
+            heap_insert(h, len, (uint16_t)parent, pr);
+        }
+        // leaf depths (:78-102): inner node ids grow with creation time, a parent is always newer
+        h.depth[h.lch[0]] = 1;
+        h.depth[h.rch[0]] = 1;
+        for (uint32_t idn = nnodes - 1; idn > nsyms; idn--) {
+            const int16_t d = h.depth[idn];
+            h.depth[h.lch[idn]] = (int16_t)(d + 1);
+            h.depth[h.rch[idn]] = (int16_t)(d + 1);
+        }
+        int maxlen = 0;
+        for (uint32_t s = 0; s < nsyms; s++) maxlen = max(maxlen, (int)h.depth[s + 1]);
+        if (maxlen <= HUF_MAXLEN) {
+            for (uint32_t s = 0; s < nsyms; s++) out[s] = (uint8_t)h.depth[s + 1];
+            return;
+        }
+        scaling <<= 1;
+    }
+}
+
+// One wavefront per table (3 per workgroup); lane 0 walks the heap held in LDS.
+__global__ void __launch_bounds__(192) huff_build(Batch bt)
+{
+    const uint32_t b = blockIdx.x;
+    const uint32_t t = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t ntab = bt.ntab[b], nsyms = bt.nsyms[b];
+    __shared__ HeapMem hm[3];
+    if (t >= ntab) return;
+    const uint32_t *tf = bt.tfreq + ((size_t)b * 3 + t) * HUF_SYMS;
+    const uint32_t *F = bt.freqs + (size_t)b * HUF_SYMS;
+    for (uint32_t s = lane; s < nsyms; s += 64) hm[t].fr[s] = tf[s] + (t == 0 ? 3u * F[s] : 0u);
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    if (lane == 0) build_lengths(hm[t], nsyms, bt.lens + ((size_t)b * 3 + t) * HUF_SYMS);
+}
+
+// ---- header bit string + canonical codes + bit totals ----------------------------------------------------
+struct BitW { // MSB-first byte writer into global memory
+    uint8_t *p;
+    uint32_t acc, nacc, bits;
+    __device__ void put(uint32_t v, uint32_t n)
+    {
+        bits += n;
+        while (n) {
+            const uint32_t take = min(n, 8u - nacc);
+            acc = (acc << take) | ((v >> (n - take)) & ((1u << take) - 1u));
+            nacc += take;
+            n -= take;
+            if (nacc == 8) {
+                *p++ = (uint8_t)acc;
+                acc = 0;
+                nacc = 0;
+            }
+        }
+    }
+    __device__ void flush() // pad with zeros to a whole 32-bit word (pack_headers reads words)
+    {
+        if (nacc) *p++ = (uint8_t)(acc << (8 - nacc));
+        const uint32_t bytes = (bits + 7) >> 3;
+        for (uint32_t k = bytes; k & 3u; k++) *p++ = 0;
+    }
+};
+
+__global__ void __launch_bounds__(64) huff_header(Batch bt)
+{
+    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+    const uint32_t ntab = bt.ntab[b], nsyms = bt.nsyms[b], m = bt.m[b];
+    const uint8_t *lens = bt.lens + (size_t)b * 3 * HUF_SYMS;
+    uint8_t *hdr = bt.hdr + (size_t)b * HDR_BYTES;
+    // payload bits = sum F[s] * len0[s]
+    const uint32_t *F = bt.freqs + (size_t)b * HUF_SYMS;
+    uint32_t pay = 0;
+    for (uint32_t s = lane; s < nsyms; s += 64) pay += F[s] * lens[s];
+    pay = wave_reduce_add(pay);
+
+    if (lane != 0) return;
+    // canonical codes of table 0 (lib/huffman.rs:548-561)
+    uint32_t *codes = bt.codes + (size_t)b * HUF_SYMS;
+    {
+        uint32_t minl = 255, maxl = 0;
+        for (uint32_t s = 0; s < nsyms; s++) {
+            minl = min(minl, (uint32_t)lens[s]);
+            maxl = max(maxl, (uint32_t)lens[s]);
+        }
+        uint32_t word = 0;
+        for (uint32_t l = minl; l <= maxl; l++) {
+            for (uint32_t s = 0; s < nsyms; s++)
+                if (lens[s] == l) codes[s] = (l << 24) | word++;
+            word <<= 1;
+        }
+    }
+    // part A: block header (lib/lib.rs:24-36), symbol map (:39-64), table count, selector count
+    BitW a{hdr, 0, 0, 0};
+    a.put(0x314159, 24);
+    a.put(0x265359, 24);
+    const uint32_t crc = bt.desc[b].crc;
+    a.put(crc >> 16, 16);
+    a.put(crc & 0xFFFF, 16);
+    a.put(0, 1);
+    a.put(bt.ptr[b], 24);
+    {
+        const uint8_t *hb = bt.hasbyte + (size_t)b * 256;
+        uint32_t sector_map = 0, sectors[16], ns = 0;
+        for (uint32_t x = 0; x < 16; x++) {
+            uint32_t sec = 0;
+            for (uint32_t y = 0; y < 16; y++) sec = (sec << 1) | (hb[(x << 4) | y] ? 1u : 0u);
+            sector_map <<= 1;
+            if (sec) {
+                sector_map |= 1;
+                sectors[ns++] = sec;
+            }
+        }
+        a.put(sector_map, 16);
+        for (uint32_t k = 0; k < ns; k++) a.put(sectors[k], 16);
+    }
+    a.put(ntab, 3); // lib/huffman.rs:467
+    const uint32_t nsel = (m + SEG - 1) / SEG;
+    a.put(nsel, 15); // :470-471
+    a.flush();
+    // selectors: nsel single 0 bits (every selector is table 0, :483-505) -- left as zeros in the output
+    // part B: delta-coded tables (:509-545)
+    BitW c{hdr + HDR_A, 0, 0, 0};
+    for (uint32_t t = 0; t < ntab; t++) {
+        const uint8_t *tl = lens + (size_t)t * HUF_SYMS;
+        c.put(tl[0], 5);
+        uint32_t acc = tl[0];
+        for (uint32_t s = 0; s < nsyms; s++) {
+            const uint32_t l = tl[s];
+            while (acc < l) {
+                c.put(2, 2);
+                acc++;
+            }
+            while (acc > l) {
+                c.put(3, 2);
+                acc--;
+            }
+            c.put(0, 1);
+        }
+    }
+    c.flush();
+    uint32_t *hb32 = bt.hdrbits + (size_t)b * 4;
+    hb32[0] = a.bits;
+    hb32[1] = nsel;
+    hb32[2] = c.bits;
+    hb32[3] = pay;
+    bt.bits[b] = (uint64_t)a.bits + nsel + c.bits + pay;
+}
+
+// Exclusive scan of block bit totals; bitoff[B] = sum.  B <= 1024.
+__global__ void __launch_bounds__(1024) block_scan(Batch bt, uint32_t B)
+{
+    __shared__ uint64_t v[1024];
+    const uint32_t t = threadIdx.x;
+    v[t] = t < B ? bt.bits[t] : 0;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint64_t x = t >= d ? v[t - d] : 0;
+        __syncthreads();
+        v[t] += x;
+        __syncthreads();
+    }
+    if (t < B) bt.bitoff[t] = t ? v[t - 1] : 0;
+    if (t == 0) bt.bitoff[B] = v[B - 1];
+}
+
+// ---- symbol packing -----------------------------------------------------------------------------------------
+constexpr int PACK_THREADS = 256;
+constexpr int PACK_ITEMS = 16;
+static_assert(PACK_THREADS * PACK_ITEMS == PACK_TILE, "pack tile");
+
+__global__ void __launch_bounds__(PACK_THREADS) pack_tilebits(Batch bt, uint32_t PT)
+{
+    const uint32_t b = blockIdx.y, tile = blockIdx.x;
+    const uint32_t m = bt.m[b];
+    if (tile * PACK_TILE >= m) return;
+    __shared__ uint32_t cl[HUF_SYMS];
+    const uint32_t *codes = bt.codes + (size_t)b * HUF_SYMS;
+    const uint32_t nsyms = bt.nsyms[b];
+    for (uint32_t k = threadIdx.x; k < nsyms; k += PACK_THREADS) cl[k] = codes[k] >> 24;
+    __syncthreads();
+    const uint16_t *s = bt.syms + (size_t)b * (bt.S + 64);
+    const uint32_t q0 = tile * PACK_TILE + threadIdx.x * PACK_ITEMS;
+    uint32_t bits = 0;
+    if (q0 < m) {
+        const uint4 w0 = *reinterpret_cast<const uint4 *>(s + q0), w1 = *reinterpret_cast<const uint4 *>(s + q0 + 8);
+        const uint32_t w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int k = 0; k < PACK_ITEMS; k++)
+            if (q0 + k < m) bits += cl[(w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu];
+    }
+    __shared__ uint32_t ls[PACK_THREADS / 64 + 2];
+    uint32_t tot;
+    (void)block_excl_add(bits, ls, &tot);
+    if (threadIdx.x == 0) bt.symbits[(size_t)b * PT + tile] = tot;
+}
+
+__global__ void __launch_bounds__(1024) pack_tilescan(Batch bt, uint32_t PT)
+{
+    const uint32_t b = blockIdx.x;
+    const uint32_t m = bt.m[b];
+    const uint32_t ntile = (m + PACK_TILE - 1) / PACK_TILE; // <= 1024
+    uint32_t *sb = bt.symbits + (size_t)b * PT;
+    __shared__ uint32_t ls[20];
+    const uint32_t v = threadIdx.x < ntile ? sb[threadIdx.x] : 0;
+    uint32_t tot;
+    const uint32_t ex = block_excl_add(v, ls, &tot);
+    if (threadIdx.x < ntile) sb[threadIdx.x] = ex;
+}
+
+__device__ __forceinline__ void or_be32(uint32_t *out, uint64_t word_idx, uint32_t v)
+{
+    if (v) atomicOr(out + word_idx, __builtin_bswap32(v));
+}
+
+__global__ void __launch_bounds__(PACK_THREADS) pack_symbols(Batch bt, uint32_t PT, uint32_t *out, uint64_t bit_base)
+{
+    const uint32_t b = blockIdx.y, tile = blockIdx.x;
+    const uint32_t m = bt.m[b];
+    if (tile * PACK_TILE >= m) return;
+    __shared__ uint32_t cw[HUF_SYMS];
+    __shared__ uint32_t buf[PACK_TILE * HUF_MAXLEN / 32 + 4];
+    const uint32_t *codes = bt.codes + (size_t)b * HUF_SYMS;
+    const uint32_t nsyms = bt.nsyms[b];
+    for (uint32_t k = threadIdx.x; k < nsyms; k += PACK_THREADS) cw[k] = codes[k];
+    for (uint32_t k = threadIdx.x; k < PACK_TILE * HUF_MAXLEN / 32 + 4; k += PACK_THREADS) buf[k] = 0;
+    __syncthreads();
+    const uint16_t *s = bt.syms + (size_t)b * (bt.S + 64);
+    const uint32_t q0 = tile * PACK_TILE + threadIdx.x * PACK_ITEMS;
+    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t bits = 0;
+    if (q0 < m) {
+        const uint4 w0 = *reinterpret_cast<const uint4 *>(s + q0), w1 = *reinterpret_cast<const uint4 *>(s + q0 + 8);
+        w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w;
+        w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
+#pragma unroll
+        for (int k = 0; k < PACK_ITEMS; k++)
+            if (q0 + k < m) bits += cw[(w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu] >> 24;
+    }
+    __shared__ uint32_t ls[PACK_THREADS / 64 + 2];
+    uint32_t tot;
+    const uint32_t ex = block_excl_add(bits, ls, &tot);
+
+    const uint32_t *hb = bt.hdrbits + (size_t)b * 4;
+    const uint64_t tile_bit = bit_base + bt.bitoff[b] + hb[0] + hb[1] + hb[2] + bt.symbits[(size_t)b * PT + tile];
+    const uint64_t word0 = tile_bit >> 5;
+    uint32_t lb = (uint32_t)(tile_bit & 31u) + ex; // bit offset inside buf
+    if (q0 < m) {
+        uint32_t wi = lb >> 5, fill = lb & 31u, nacc = 0;
+        uint64_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < PACK_ITEMS; k++) {
+            if (q0 + k < m) {
+                const uint32_t c = cw[(w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu];
+                const uint32_t L = c >> 24;
+                acc = (acc << L) | (c & 0xFFFFFFu);
+                nacc += L;
+                if (fill + nacc >= 32) {
+                    const uint32_t t = 32 - fill;
+                    const uint32_t word = (uint32_t)(acc >> (nacc - t)) & (t == 32 ? 0xFFFFFFFFu : ((1u << t) - 1u));
+                    atomicOr(&buf[wi], word);
+                    nacc -= t;
+                    acc &= (1ull << nacc) - 1ull;
+                    wi++;
+                    fill = 0;
+                }
+            }
+        }
+        if (nacc) atomicOr(&buf[wi], (uint32_t)(acc << (32 - fill - nacc)));
+    }
+    __syncthreads();
+    const uint32_t total_bits = (uint32_t)(tile_bit & 31u) + tot;
+    const uint32_t nw = (total_bits + 31) >> 5;
+    for (uint32_t k = threadIdx.x; k < nw; k += PACK_THREADS) {
+        if (k == 0 || k == nw - 1)
+            or_be32(out, word0 + k, buf[k]); // words shared with the neighbouring tile / header
+        else
+            out[word0 + k] = __builtin_bswap32(buf[k]);
+    }
+}
+
+// Copies `nbits` bits from src (MSB-first bytes, zero padded to words) to bit position `pos` of out.
+__device__ void or_bits(uint32_t *out, uint64_t pos, const uint8_t *src, uint32_t nbits, uint32_t lane)
+{
+    const uint32_t nw = (nbits + 31) >> 5;
+    const uint32_t sh = (uint32_t)(pos & 31u);
+    const uint64_t w0 = pos >> 5;
+    for (uint32_t k = lane; k < nw; k += 64) {
+        const uint32_t v = __builtin_bswap32(reinterpret_cast<const uint32_t *>(src)[k]);
+        or_be32(out, w0 + k, v >> sh);
+        if (sh) or_be32(out, w0 + k + 1, v << (32 - sh));
+    }
+}
+
+__global__ void __launch_bounds__(64) pack_headers(Batch bt, uint32_t *out, uint64_t bit_base)
+{
+    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+    const uint32_t *hb = bt.hdrbits + (size_t)b * 4;
+    const uint8_t *hdr = bt.hdr + (size_t)b * HDR_BYTES;
+    const uint64_t pos = bit_base + bt.bitoff[b];
+    or_bits(out, pos, hdr, hb[0], lane);
+    or_bits(out, pos + hb[0] + hb[1], hdr + HDR_A, hb[2], lane);
+}
+
+// ---- host drivers --------------------------------------------------------------------------------------------
+// Tables, header strings, per-block bit totals and bitoff[] for blocks 0..B-1 (needs bt.syms, bt.m,
+// bt.freqs, bt.nsyms, bt.ptr, bt.hasbyte, bt.desc[].crc).
+int huff_prepare(bzh_ctx *ctx, uint32_t B, uint32_t mmax)
+{
+    Batch &bt = ctx->bt;
+    if (B == 0) return BZH_OK;
+    hipStream_t st = ctx->stream;
+    uint32_t *ranges = reinterpret_cast<uint32_t *>(bt.tagg); // B*8 words <= B*TPB*2
+    const uint32_t nsegmax = (mmax + SEG - 1) / SEG;
+    const uint32_t PT = (bt.S + 64 + PACK_TILE - 1) / PACK_TILE;
+    const uint32_t ptiles = (mmax + PACK_TILE - 1) / PACK_TILE;
+    huff_init<<<dim3(B), 64, 0, st>>>(bt, ranges);
+    huff_segments<<<dim3((nsegmax + 255) / 256, B), 256, 0, st>>>(bt, ranges);
+    huff_build<<<dim3(B), 192, 0, st>>>(bt);
+    huff_header<<<dim3(B), 64, 0, st>>>(bt);
+    block_scan<<<dim3(1), 1024, 0, st>>>(bt, B);
+    pack_tilebits<<<dim3(ptiles, B), PACK_THREADS, 0, st>>>(bt, PT);
+    pack_tilescan<<<dim3(B), 1024, 0, st>>>(bt, PT);
+    HIP_TRY(ctx, hipGetLastError());
+    return BZH_OK;
+}
+
+// Writes blocks 0..B-1 at bit_base + bitoff[b] of d_out (zero-initialised, 4-byte aligned).
+int huff_pack(bzh_ctx *ctx, uint32_t B, uint32_t mmax, uint8_t *d_out, uint64_t bit_base)
+{
+    Batch &bt = ctx->bt;
+    if (B == 0) return BZH_OK;
+    hipStream_t st = ctx->stream;
+    const uint32_t PT = (bt.S + 64 + PACK_TILE - 1) / PACK_TILE;
+    const uint32_t ptiles = (mmax + PACK_TILE - 1) / PACK_TILE;
+    uint32_t *out = reinterpret_cast<uint32_t *>(d_out);
+    pack_symbols<<<dim3(ptiles, B), PACK_THREADS, 0, st>>>(bt, PT, out, bit_base);
+    pack_headers<<<dim3(B), 64, 0, st>>>(bt, out, bit_base);
+    HIP_TRY(ctx, hipGetLastError());
+    return BZH_OK;
+}

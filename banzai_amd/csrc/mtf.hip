@@ -1,0 +1,380 @@
+// mtf.hip -- move-to-front + RLE2 (RUNA/RUNB) + symbol histogram for a batch of blocks.
+//
+// Replaces mtf::mtf_and_rle (reference lib/mtf.rs:14-121).  Same outputs: output: Vec<u16>
+// (here syms[b][0..m)), num_syms = names + 2, freqs[258] with freqs[EOB] = 1.
+//
+// MTF without a list: the position of byte c in the recency list equals the number of present
+// symbols whose "key" is larger than c's key, where key = time of last occurrence, and a symbol
+// not seen yet has key -1-c (so unseen symbols keep ascending order behind all seen ones --
+// the identity initial list of lib/mtf.rs:39-43).  Absent bytes get INT_MIN and never count.
+// Keys at a tile entry are a prefix-max over tiles of per-tile last occurrences, so tiles are
+// independent: one wavefront walks 2048 bytes with its 256 keys in 4 VGPRs (symbol c lives in
+// lane c&63, register c>>6); one step = scalar readlane + 4 ballots/popcounts.  A byte equal to
+// the current front symbol (zero run, the common case after a BWT) costs one scalar compare.
+//
+// RLE2 is then fully parallel over the position array: every non-zero position emits the
+// bijective base-2 digits (lib/mtf.rs:46-65) of the zero run that ends just before it, then its
+// own symbol pos+1; offsets by scan; the trailing run and EOB are written by the per-block kernel.
+#include "common.h"
+
+constexpr int RLE_THREADS = 256;
+constexpr int RLE_ITEMS = 16;
+constexpr int RLE_TILE = RLE_THREADS * RLE_ITEMS; // == SORT_TILE, so bt.TPB tiles per block
+
+__device__ __forceinline__ uint32_t run_digits(uint32_t z) // symbols emitted for a zero run of length z
+{
+    return z ? (31u - __clz(z + 1u)) : 0u;
+}
+
+// ---- per-tile last occurrence ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256) mtf_tile_last(Batch bt, int32_t *tlast, uint32_t MT)
+{
+    const uint32_t b = blockIdx.y, tile = blockIdx.x;
+    const uint32_t n = bt.n[b];
+    if (tile * MTF_TILE >= n) return;
+    __shared__ int last[256];
+    last[threadIdx.x] = -1;
+    __syncthreads();
+    const uint8_t *s = bt.bwt + (size_t)b * bt.S;
+    const uint32_t p0 = tile * MTF_TILE + threadIdx.x * 8;
+    if (p0 < n) {
+        uint2 w = *reinterpret_cast<const uint2 *>(s + p0);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            uint32_t p = p0 + k;
+            if (p < n) {
+                uint32_t c = ((k < 4 ? w.x : w.y) >> ((k & 3) * 8)) & 255u;
+                atomicMax(&last[c], (int)p);
+            }
+        }
+    }
+    __syncthreads();
+    tlast[((size_t)b * MT + tile) * 256 + threadIdx.x] = last[threadIdx.x];
+}
+
+// One workgroup per block: turn per-tile last occurrences into keys at tile entry (exclusive
+// running "latest occurrence"), seeded with the initial order; also num_syms.
+__global__ void __launch_bounds__(256) mtf_prefix(Batch bt, int32_t *tlast, uint32_t MT)
+{
+    const uint32_t b = blockIdx.x;
+    const uint32_t n = bt.n[b];
+    const uint32_t ntile = (n + MTF_TILE - 1) / MTF_TILE;
+    const uint32_t c = threadIdx.x;
+    const bool present = bt.hasbyte[(size_t)b * 256 + c] != 0;
+    int run = present ? -1 - (int)c : INT32_MIN;
+    int32_t *t = tlast + (size_t)b * MT * 256 + c;
+    uint32_t tile = 0;
+    for (; tile + 8 <= ntile; tile += 8) {
+        int v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = t[(size_t)(tile + k) * 256];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            t[(size_t)(tile + k) * 256] = run;
+            if (v[k] >= 0) run = v[k];
+        }
+    }
+    for (; tile < ntile; tile++) {
+        int v = t[(size_t)tile * 256];
+        t[(size_t)tile * 256] = run;
+        if (v >= 0) run = v;
+    }
+    // num_syms = names + 2 (lib/mtf.rs:118)
+    uint32_t cnt = __popcll(__ballot(present));
+    __shared__ uint32_t w[4];
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) bt.nsyms[b] = w[0] + w[1] + w[2] + w[3] + 2;
+}
+
+// ---- the walk: one wavefront per tile ---------------------------------------------------------------
+__device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+// clang exposes no writelane builtin; a compare+select on a uniform lane index does the same
+__device__ __forceinline__ int wrlane(int val, int l, int old) { return (int)(threadIdx.x & 63) == l ? val : old; }
+
+__global__ void __launch_bounds__(64) mtf_walk(Batch bt, const int32_t *tlast, uint32_t MT)
+{
+    const uint32_t b = blockIdx.y, tile = blockIdx.x;
+    const uint32_t n = bt.n[b];
+    const uint32_t base_p = tile * MTF_TILE;
+    if (base_p >= n) return;
+    const int lane = threadIdx.x;
+    const int32_t *keys = tlast + ((size_t)b * MT + tile) * 256;
+    int k0 = keys[lane], k1 = keys[64 + lane], k2 = keys[128 + lane], k3 = keys[192 + lane];
+    const uint8_t *s = bt.bwt + (size_t)b * bt.S + base_p;
+    uint8_t *o = bt.mtfpos + (size_t)b * bt.S + base_p;
+
+    // front symbol at tile entry = arg max key
+    int front;
+    {
+        int best = max(max(k0, k1), max(k2, k3));
+        int bsym = best == k0 ? lane : best == k1 ? 64 + lane : best == k2 ? 128 + lane : 192 + lane;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            int ob = __shfl_xor(best, d, 64), os = __shfl_xor(bsym, d, 64);
+            if (ob > best) {
+                best = ob;
+                bsym = os;
+            }
+        }
+        front = __builtin_amdgcn_readfirstlane(bsym); // keys are distinct, every lane agrees
+    }
+
+    const uint32_t remain = n - base_p;
+    const uint32_t tile_len = remain < MTF_TILE ? remain : MTF_TILE;
+#pragma unroll 1
+    for (uint32_t chunk = 0; chunk < MTF_TILE / 1024; chunk++) {
+        const uint32_t cbase = chunk * 1024;
+        if (cbase >= tile_len) break;
+        // 16 bytes per lane; S is padded so the vector load stays inside the arena
+        const uint4 in = *reinterpret_cast<const uint4 *>(s + cbase + lane * 16);
+        int o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+        const uint32_t clen = tile_len - cbase < 1024 ? tile_len - cbase : 1024;
+        const uint32_t nl = (clen + 15) / 16;
+#pragma unroll 1
+        for (uint32_t li = 0; li < nl; li++) {
+            const uint32_t lim = clen - li * 16; // bytes valid in this lane (>= 1)
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const uint32_t w = (uint32_t)rdlane((int)(d == 0 ? in.x : d == 1 ? in.y : d == 2 ? in.z : in.w), (int)li);
+                uint32_t ow = 0;
+#pragma unroll
+                for (int kb = 0; kb < 4; kb++) {
+                    if ((uint32_t)(d * 4 + kb) < lim) {
+                        const int c = (int)((w >> (8 * kb)) & 255u);
+                        if (c != front) {
+                            const int p = (int)(base_p + cbase + li * 16 + d * 4 + kb);
+                            const int l = c & 63;
+                            int prev;
+                            switch (c >> 6) {
+                            case 0: prev = rdlane(k0, l); k0 = wrlane(p, l, k0); break;
+                            case 1: prev = rdlane(k1, l); k1 = wrlane(p, l, k1); break;
+                            case 2: prev = rdlane(k2, l); k2 = wrlane(p, l, k2); break;
+                            default: prev = rdlane(k3, l); k3 = wrlane(p, l, k3); break;
+                            }
+                            // c's own key is already p (> prev), every other key is unchanged:
+                            // position = (keys above prev) - 1 for the symbol itself.
+                            uint32_t cnt = (uint32_t)__popcll(__ballot(k0 > prev)) + (uint32_t)__popcll(__ballot(k1 > prev)) +
+                                           (uint32_t)__popcll(__ballot(k2 > prev)) + (uint32_t)__popcll(__ballot(k3 > prev)) - 1u;
+                            ow |= cnt << (8 * kb);
+                            front = c;
+                        }
+                    }
+                }
+                if (d == 0) o0 = wrlane((int)ow, (int)li, o0);
+                else if (d == 1) o1 = wrlane((int)ow, (int)li, o1);
+                else if (d == 2) o2 = wrlane((int)ow, (int)li, o2);
+                else o3 = wrlane((int)ow, (int)li, o3);
+            }
+        }
+        if ((uint32_t)lane < nl) *reinterpret_cast<uint4 *>(o + cbase + lane * 16) = make_uint4(o0, o1, o2, o3);
+    }
+}
+
+// ---- RLE2 --------------------------------------------------------------------------------------------
+struct RleTile {
+    int first_nz; // global position of the first non-zero MTF position in the tile, -1 if none
+    int last_nz;  // last one, -1 if none; after rle_block: last non-zero position BEFORE the tile
+    uint32_t cnt; // symbols emitted by the tile, not counting the zero-run digits of first_nz
+    uint32_t off; // after rle_block: output offset of the tile
+};
+
+// Loads 16 positions of the tile into v[], returns the number valid.
+__device__ __forceinline__ uint32_t rle_load(const uint8_t *r, uint32_t q0, uint32_t n, uint32_t v[4])
+{
+    if (q0 >= n) return 0;
+    uint4 w = *reinterpret_cast<const uint4 *>(r + q0);
+    v[0] = w.x;
+    v[1] = w.y;
+    v[2] = w.z;
+    v[3] = w.w;
+    return n - q0 < 16 ? n - q0 : 16;
+}
+
+__global__ void __launch_bounds__(RLE_THREADS) rle_tiles(Batch bt, RleTile *rt)
+{
+    const uint32_t b = blockIdx.y, tile = blockIdx.x;
+    const uint32_t n = bt.n[b];
+    if (tile * RLE_TILE >= n) return;
+    const uint8_t *r = bt.mtfpos + (size_t)b * bt.S;
+    const uint32_t q0 = tile * RLE_TILE + threadIdx.x * RLE_ITEMS;
+    uint32_t v[4];
+    const uint32_t valid = rle_load(r, q0, n, v);
+    int tfirst = INT32_MAX, tlastnz = -1;
+    for (uint32_t k = 0; k < valid; k++) {
+        if ((v[k >> 2] >> ((k & 3) * 8)) & 255u) {
+            if (tfirst == INT32_MAX) tfirst = (int)(q0 + k);
+            tlastnz = (int)(q0 + k);
+        }
+    }
+    __shared__ int lm[RLE_THREADS / 64];
+    __shared__ int ex[RLE_THREADS];
+    int inc = block_incl_max(tlastnz, lm);
+    ex[threadIdx.x] = inc;
+    __syncthreads();
+    int cur = threadIdx.x ? ex[threadIdx.x - 1] : -1;
+    uint32_t cnt = 0;
+    for (uint32_t k = 0; k < valid; k++) {
+        if ((v[k >> 2] >> ((k & 3) * 8)) & 255u) {
+            const int p = (int)(q0 + k);
+            cnt += 1 + (cur >= 0 ? run_digits((uint32_t)(p - 1 - cur)) : 0u);
+            cur = p;
+        }
+    }
+    // reductions: sum cnt, min first, max last
+    __shared__ uint32_t ls[RLE_THREADS / 64 + 2];
+    __shared__ int lf[RLE_THREADS / 64];
+    uint32_t tot;
+    (void)block_excl_add(cnt, ls, &tot);
+    int f = tfirst;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) f = min(f, __shfl_xor(f, d, 64));
+    if ((threadIdx.x & 63) == 0) lf[threadIdx.x >> 6] = f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < RLE_THREADS / 64; w++) f = min(f, lf[w]);
+        RleTile t;
+        t.first_nz = f == INT32_MAX ? -1 : f;
+        t.last_nz = ex[RLE_THREADS - 1];
+        t.cnt = tot;
+        t.off = 0;
+        rt[(size_t)b * bt.TPB + tile] = t;
+    }
+}
+
+// One workgroup per block: carries across tiles, output offsets, trailing run + EOB, m, freqs init.
+__global__ void __launch_bounds__(1024) rle_block(Batch bt, RleTile *rt)
+{
+    const uint32_t b = blockIdx.x;
+    const uint32_t n = bt.n[b];
+    const uint32_t ntile = (n + RLE_TILE - 1) / RLE_TILE; // <= TPB <= 1024
+    const uint32_t t = threadIdx.x;
+    uint32_t *freqs = bt.freqs + (size_t)b * 258;
+    for (uint32_t k = t; k < 258; k += 1024) freqs[k] = 0;
+    RleTile me{-1, -1, 0, 0};
+    if (t < ntile) me = rt[(size_t)b * bt.TPB + t];
+    __shared__ int lm[16];
+    __shared__ int incl[1024];
+    incl[t] = block_incl_max(me.last_nz, lm);
+    __syncthreads();
+    const int carry = t ? incl[t - 1] : -1;
+    uint32_t cnt = me.cnt;
+    if (me.first_nz >= 0) cnt += run_digits((uint32_t)(me.first_nz - 1 - carry));
+    __shared__ uint32_t ls[20];
+    uint32_t total;
+    const uint32_t off = block_excl_add(cnt, ls, &total);
+    if (t < ntile) {
+        me.last_nz = carry;
+        me.off = off;
+        rt[(size_t)b * bt.TPB + t] = me;
+    }
+    if (t == 0) {
+        const int lastnz = incl[1023];
+        const uint32_t z = (uint32_t)((int)n - 1 - lastnz);
+        const uint32_t d = run_digits(z);
+        uint16_t *out = bt.syms + (size_t)b * (bt.S + 64);
+        uint32_t fa = 0, fb = 0;
+        for (uint32_t k = 0; k < d; k++) {
+            uint32_t bit = ((z + 1) >> k) & 1u;
+            out[total + k] = (uint16_t)bit;
+            fa += bit ^ 1u;
+            fb += bit;
+        }
+        const uint32_t eob = bt.nsyms[b] - 1; // names + 1 (lib/mtf.rs:30)
+        out[total + d] = (uint16_t)eob;
+        bt.m[b] = total + d + 1;
+        // freqs were zeroed above by other threads of this workgroup
+        __threadfence_block();
+        atomicAdd(&freqs[0], fa);
+        atomicAdd(&freqs[1], fb);
+        atomicAdd(&freqs[eob], 1u);
+    }
+}
+
+__global__ void __launch_bounds__(RLE_THREADS) rle_emit(Batch bt, const RleTile *rt)
+{
+    const uint32_t b = blockIdx.y, tile = blockIdx.x;
+    const uint32_t n = bt.n[b];
+    if (tile * RLE_TILE >= n) return;
+    const RleTile me = rt[(size_t)b * bt.TPB + tile];
+    const uint8_t *r = bt.mtfpos + (size_t)b * bt.S;
+    const uint32_t q0 = tile * RLE_TILE + threadIdx.x * RLE_ITEMS;
+    uint32_t v[4];
+    const uint32_t valid = rle_load(r, q0, n, v);
+    int tlastnz = -1;
+    for (uint32_t k = 0; k < valid; k++)
+        if ((v[k >> 2] >> ((k & 3) * 8)) & 255u) tlastnz = (int)(q0 + k);
+
+    __shared__ int lm[RLE_THREADS / 64];
+    __shared__ int ex[RLE_THREADS];
+    __shared__ uint32_t hist[258];
+    for (int k = threadIdx.x; k < 258; k += RLE_THREADS) hist[k] = 0;
+    int inc = block_incl_max(tlastnz, lm);
+    ex[threadIdx.x] = inc;
+    __syncthreads();
+    const int cur0 = max(me.last_nz, threadIdx.x ? ex[threadIdx.x - 1] : -1);
+    int cur = cur0;
+    uint32_t cnt = 0;
+    for (uint32_t k = 0; k < valid; k++) {
+        if ((v[k >> 2] >> ((k & 3) * 8)) & 255u) {
+            const int p = (int)(q0 + k);
+            cnt += 1 + run_digits((uint32_t)(p - 1 - cur));
+            cur = p;
+        }
+    }
+    __shared__ uint32_t ls[RLE_THREADS / 64 + 2];
+    uint32_t tot;
+    uint32_t off = me.off + block_excl_add(cnt, ls, &tot);
+    uint16_t *out = bt.syms + (size_t)b * (bt.S + 64);
+    cur = cur0;
+    uint32_t fa = 0, fb = 0;
+    for (uint32_t k = 0; k < valid; k++) {
+        const uint32_t pos = (v[k >> 2] >> ((k & 3) * 8)) & 255u;
+        if (pos) {
+            const int p = (int)(q0 + k);
+            const uint32_t z = (uint32_t)(p - 1 - cur);
+            const uint32_t d = run_digits(z);
+            for (uint32_t j = 0; j < d; j++) {
+                uint32_t bit = ((z + 1) >> j) & 1u;
+                out[off++] = (uint16_t)bit;
+                fa += bit ^ 1u;
+                fb += bit;
+            }
+            out[off++] = (uint16_t)(pos + 1); // lib/mtf.rs:91-92
+            atomicAdd(&hist[pos + 1], 1u);
+            cur = p;
+        }
+    }
+    fa = wave_reduce_add(fa);
+    fb = wave_reduce_add(fb);
+    if ((threadIdx.x & 63) == 0) {
+        if (fa) atomicAdd(&hist[0], fa);
+        if (fb) atomicAdd(&hist[1], fb);
+    }
+    __syncthreads();
+    uint32_t *freqs = bt.freqs + (size_t)b * 258;
+    for (int k = threadIdx.x; k < 258; k += RLE_THREADS)
+        if (hist[k]) atomicAdd(&freqs[k], hist[k]);
+}
+
+// MTF + RLE2 for blocks 0..B-1 (bt.bwt / bt.n / bt.hasbyte filled).  tlast and RleTile scratch
+// live in the sort lists, which are free once the BWT is emitted.
+int mtf_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax)
+{
+    Batch &bt = ctx->bt;
+    if (B == 0) return BZH_OK;
+    hipStream_t st = ctx->stream;
+    const uint32_t MT = (bt.S + MTF_TILE - 1) / MTF_TILE;
+    int32_t *tlast = reinterpret_cast<int32_t *>(bt.listA);  // B*MT*256*4 <= B*S*8
+    RleTile *rt = reinterpret_cast<RleTile *>(bt.listB);     // B*TPB*16
+    const uint32_t mt = (nmax + MTF_TILE - 1) / MTF_TILE;
+    const uint32_t rtiles = (nmax + RLE_TILE - 1) / RLE_TILE;
+    mtf_tile_last<<<dim3(mt, B), 256, 0, st>>>(bt, tlast, MT);
+    mtf_prefix<<<dim3(B), 256, 0, st>>>(bt, tlast, MT);
+    mtf_walk<<<dim3(mt, B), 64, 0, st>>>(bt, tlast, MT);
+    rle_tiles<<<dim3(rtiles, B), RLE_THREADS, 0, st>>>(bt, rt);
+    rle_block<<<dim3(B), 1024, 0, st>>>(bt, rt);
+    rle_emit<<<dim3(rtiles, B), RLE_THREADS, 0, st>>>(bt, rt);
+    HIP_TRY(ctx, hipGetLastError());
+    return BZH_OK;
+}
