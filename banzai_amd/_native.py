@@ -199,3 +199,74 @@ class Context:
         self.check(lib().bzh_huffman(self._h, ptr(s, u16p), s.size, num_syms, ptr(f, u32p), ptr(out), cap,
                                      ctypes.byref(nb), ptr(lens), ctypes.byref(nt)))
         return out[:(nb.value + 7) // 8].tobytes(), int(nb.value), lens.reshape(3, 258)[:nt.value].copy()
+
+    def crc32(self, data):
+        a = np.frombuffer(bytes(data), dtype=np.uint8).copy() if len(data) else np.zeros(1, np.uint8)
+        c = ctypes.c_uint32(0)
+        self.check(lib().bzh_crc32(self._h, ptr(a), len(data), ctypes.byref(c)))
+        return int(c.value)
+
+    def rle1_split(self, data, want_bytes=True):
+        """-> ([(in_off, in_len, rle_len, crc)], [rle bytes per block])"""
+        n = len(data)
+        a = np.frombuffer(bytes(data), dtype=np.uint8).copy() if n else np.zeros(1, np.uint8)
+        maxb = n // (4 * (100000 * self.level - 1) // 5 - 4) + 8
+        blocks = (Block * maxb)()
+        nb = ctypes.c_size_t(0)
+        cap = n + n // 4 + 64
+        out = np.zeros(cap if want_bytes else 1, dtype=np.uint8)
+        self.check(lib().bzh_rle1_split(self._h, ptr(a), n, blocks, maxb, ctypes.byref(nb),
+                                        ptr(out) if want_bytes else None, cap))
+        infos = [(int(blocks[k].in_off), int(blocks[k].in_len), int(blocks[k].rle_len), int(blocks[k].crc))
+                 for k in range(nb.value)]
+        chunks = []
+        if want_bytes:
+            pos = 0
+            for (_, _, rl, _) in infos:
+                chunks.append(out[pos:pos + rl].tobytes())
+                pos += rl
+        return infos, chunks
+
+    def encode(self, data):
+        """bzh_encode: complete .bz2 stream of `data` (host buffers)."""
+        n = len(data)
+        a = np.frombuffer(bytes(data), dtype=np.uint8).copy() if n else np.zeros(1, np.uint8)
+        cap = n + n // 4 + 65536 + (n // 70000 + 2) * 4096
+        out = np.zeros(cap, dtype=np.uint8)
+        olen = ctypes.c_size_t(0)
+        used = ctypes.c_size_t(0)
+        self.check(lib().bzh_encode(self._h, ptr(a), n, ptr(out), cap, ctypes.byref(olen), ctypes.byref(used)))
+        assert used.value == n
+        return out[:olen.value].tobytes()
+
+    def encode_device(self, d_in, n, d_out, cap):
+        """Device-resident encode; d_in/d_out are integer device addresses.  -> stream length."""
+        olen = ctypes.c_size_t(0)
+        used = ctypes.c_size_t(0)
+        self.check(lib().bzh_encode_device(self._h, ctypes.c_void_p(d_in), n, ctypes.c_void_p(d_out), cap,
+                                           ctypes.byref(olen), ctypes.byref(used)))
+        return int(olen.value)
+
+    def plan_device(self, d_in, n):
+        nb = ctypes.c_size_t(0)
+        self.check(lib().bzh_plan_device(self._h, ctypes.c_void_p(d_in), n, ctypes.byref(nb)))
+        blocks = (Block * max(1, nb.value))()
+        self.check(lib().bzh_plan_blocks(self._h, blocks, max(1, nb.value)))
+        return [(int(blocks[k].in_off), int(blocks[k].in_len), int(blocks[k].rle_len), int(blocks[k].crc))
+                for k in range(nb.value)]
+
+    def encode_range_device(self, b0, b1, d_out, cap):
+        nbits = ctypes.c_uint64(0)
+        self.check(lib().bzh_encode_range_device(self._h, b0, b1, ctypes.c_void_p(d_out), cap, ctypes.byref(nbits)))
+        return int(nbits.value)
+
+    def assemble_device(self, segs, crcs, d_out, cap):
+        """segs: [(device address, nbits)], crcs: block CRCs in block order -> stream length."""
+        nseg = len(segs)
+        ptrs = (ctypes.c_void_p * max(1, nseg))(*[ctypes.c_void_p(p) for p, _ in segs])
+        bits = np.array([b for _, b in segs] or [0], dtype=np.uint64)
+        c = np.array(list(crcs) or [0], dtype=np.uint32)
+        olen = ctypes.c_size_t(0)
+        self.check(lib().bzh_assemble_device(self._h, ptrs, ptr(bits, u64p), nseg, ptr(c, u32p), len(crcs),
+                                             ctypes.c_void_p(d_out), cap, ctypes.byref(olen)))
+        return int(olen.value)

@@ -144,6 +144,7 @@ extern "C" void bzh_destroy(bzh_ctx *ctx)
     if (ctx->d_stage_in) hipFree(ctx->d_stage_in);
     if (ctx->d_stage_out) hipFree(ctx->d_stage_out);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+    if (ctx->d_crctab) hipFree(ctx->d_crctab);
     delete ctx;
 }
 
@@ -332,4 +333,339 @@ extern "C" int bzh_huffman(bzh_ctx *ctx, const uint16_t *syms, size_t m, uint32_
     }
     if (pay % 8) bits_out[need - 1] &= (uint8_t)(0xFF << (8 - pay % 8));
     return BZH_OK;
+}
+
+// ================================================================================================
+// Whole path
+// ================================================================================================
+__device__ __forceinline__ void or_word_be(uint32_t *out, uint64_t word_idx, uint32_t v)
+{
+    if (v) atomicOr(out + word_idx, __builtin_bswap32(v));
+}
+
+// ORs nbits bits of src (MSB-first, from bit 0) into dst at bit position dst_bit.  dst zeroed.
+__global__ void __launch_bounds__(256) concat_bits(uint32_t *dst, uint64_t dst_bit, const uint32_t *src, uint64_t nbits)
+{
+    const uint64_t nw = (nbits + 31) >> 5;
+    const uint32_t sh = (uint32_t)(dst_bit & 31u);
+    const uint64_t w0 = dst_bit >> 5;
+    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < nw; k += (uint64_t)gridDim.x * 256) {
+        uint32_t v = __builtin_bswap32(src[k]);
+        if (k == nw - 1 && (nbits & 31u)) v &= 0xFFFFFFFFu << (32 - (uint32_t)(nbits & 31u));
+        or_word_be(dst, w0 + k, v >> sh);
+        if (sh) or_word_be(dst, w0 + k + 1, v << (32 - sh));
+    }
+}
+
+// Stream header "BZh"+level at bit 0 and footer + stream CRC at bit 32+body_bits (lib/lib.rs:18-22, :66-70).
+__global__ void stream_frame(uint32_t *out, int level, uint64_t body_bits, uint32_t stream_crc)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    or_word_be(out, 0, 0x425A6800u | (uint32_t)('0' + level));
+    const uint32_t words[3] = {0x17724538u, 0x50900000u | (stream_crc >> 16), stream_crc << 16}; // 80 bits
+    const uint64_t pos = 32 + body_bits;
+    const uint32_t sh = (uint32_t)(pos & 31u);
+    const uint64_t w0 = pos >> 5;
+    for (int k = 0; k < 3; k++) {
+        or_word_be(out, w0 + k, words[k] >> sh);
+        if (sh) or_word_be(out, w0 + k + 1, words[k] << (32 - sh));
+    }
+}
+
+static uint32_t fold_stream_crc(const uint32_t *crcs, size_t nb) // lib/lib.rs:107-108
+{
+    uint32_t s = 0;
+    for (size_t k = 0; k < nb; k++) s = crcs[k] ^ ((s << 1) | (s >> 31));
+    return s;
+}
+
+static float span_ms(hipEvent_t a, hipEvent_t b)
+{
+    float t = 0;
+    return hipEventElapsedTime(&t, a, b) == hipSuccess ? t : 0.f;
+}
+
+// Encodes plan blocks [b0, b1) into d_out starting at bit `bit_base`; words of d_out from
+// bit_base/32 on are zeroed here as needed (words before that are the caller's).
+static int encode_range(bzh_ctx *ctx, size_t b0, size_t b1, uint8_t *d_out, size_t cap, uint64_t bit_base,
+                        uint64_t *nbits)
+{
+    if (((uintptr_t)d_out & 3u) != 0) {
+        bzh_set_error(ctx, "output buffer must be 4-byte aligned");
+        return BZH_E_ARG;
+    }
+    hipStream_t st = ctx->stream;
+    Batch &bt = ctx->bt;
+    const uint64_t cap_words = cap / 4;
+    uint64_t zeroed_upto = bit_base / 32; // first word not yet known to be zero (exclusive bound of zeroed range)
+    uint64_t cur = 0;
+    struct Ev { hipEvent_t e[6]; };
+    std::vector<Ev> evs;
+    for (size_t k0 = b0; k0 < b1; k0 += ctx->max_batch) {
+        const uint32_t B = (uint32_t)std::min<size_t>(ctx->max_batch, b1 - k0);
+        uint32_t nmax = 0;
+        for (uint32_t b = 0; b < B; b++) {
+            nmax = std::max(nmax, ctx->plan_blocks[k0 + b].rle_len);
+            ctx->stats.rle_bytes += ctx->plan_blocks[k0 + b].rle_len;
+            ctx->stats.raw_bytes += ctx->plan_blocks[k0 + b].in_len;
+        }
+        ctx->stats.blocks += B;
+        Ev ev{};
+        auto mark = [&](int i) {
+            if (ctx->profiling) {
+                ev.e[i] = bzh_event(ctx);
+                hipEventRecord(ev.e[i], st);
+            }
+        };
+        mark(0);
+        BZH_TRY(rle1_emit(ctx, k0, B));
+        mark(1);
+        BZH_TRY(bwt_run(ctx, B, nmax));
+        mark(2);
+        BZH_TRY(mtf_run(ctx, B, nmax));
+        mark(3);
+        const uint32_t mmax = nmax + 1; // m <= n + 1 (lib/mtf.rs:36)
+        BZH_TRY(huff_prepare(ctx, B, mmax));
+        mark(4);
+        uint64_t T = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&T, bt.bitoff + B, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        const uint64_t need_upto = (bit_base + cur + T + 31) / 32 + 1;
+        if (need_upto > cap_words) {
+            bzh_set_error(ctx, "output needs more than %zu bytes", cap);
+            return BZH_E_CAP;
+        }
+        if (need_upto > zeroed_upto) {
+            HIP_TRY(ctx, hipMemsetAsync(d_out + zeroed_upto * 4, 0, (size_t)(need_upto - zeroed_upto) * 4, st));
+            zeroed_upto = need_upto;
+        }
+        BZH_TRY(huff_pack(ctx, B, mmax, d_out, bit_base + cur));
+        mark(5);
+        cur += T;
+        if (ctx->profiling) {
+            evs.push_back(ev);
+            std::vector<uint32_t> hm(B);
+            HIP_TRY(ctx, hipMemcpyAsync(hm.data(), bt.m, B * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            for (uint32_t b = 0; b < B; b++) ctx->stats.mtf_syms += hm[b];
+        }
+    }
+    if (ctx->profiling) {
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        for (auto &ev : evs) {
+            ctx->stats.ms_rle1 += span_ms(ev.e[0], ev.e[1]);
+            ctx->stats.ms_bwt += span_ms(ev.e[1], ev.e[2]);
+            ctx->stats.ms_mtf += span_ms(ev.e[2], ev.e[3]);
+            ctx->stats.ms_huff += span_ms(ev.e[3], ev.e[4]);
+            ctx->stats.ms_pack += span_ms(ev.e[4], ev.e[5]);
+        }
+        stats_collect_sort(ctx);
+    }
+    ctx->stats.out_bits += cur;
+    *nbits = cur;
+    return BZH_OK;
+}
+
+static int check_in_ptr(bzh_ctx *ctx, const void *d_in)
+{
+    if (((uintptr_t)d_in & 15u) != 0) {
+        bzh_set_error(ctx, "device input must be 16-byte aligned");
+        return BZH_E_ARG;
+    }
+    return BZH_OK;
+}
+
+extern "C" int bzh_plan_device(bzh_ctx *ctx, const void *d_in, size_t n, size_t *nblocks)
+{
+    if (!ctx || (!d_in && n) || !nblocks) return BZH_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    BZH_TRY(check_in_ptr(ctx, d_in));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->profiling) {
+        ctx->evnext = 0;
+        e0 = bzh_event(ctx);
+        hipEventRecord(e0, ctx->stream);
+    }
+    BZH_TRY(rle1_plan(ctx, (const uint8_t *)d_in, n));
+    if (ctx->profiling) {
+        e1 = bzh_event(ctx);
+        hipEventRecord(e1, ctx->stream);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        memset(&ctx->stats, 0, sizeof ctx->stats);
+        ctx->stats.ms_plan = span_ms(e0, e1);
+    }
+    *nblocks = ctx->plan_blocks.size();
+    return BZH_OK;
+}
+
+extern "C" int bzh_plan_blocks(const bzh_ctx *ctx, bzh_block *out, size_t max_blocks)
+{
+    if (!ctx || !out) return BZH_E_ARG;
+    if (max_blocks < ctx->plan_blocks.size()) return BZH_E_CAP;
+    for (size_t k = 0; k < ctx->plan_blocks.size(); k++) out[k] = ctx->plan_blocks[k];
+    return BZH_OK;
+}
+
+extern "C" int bzh_encode_range_device(bzh_ctx *ctx, size_t b0, size_t b1, void *d_out, size_t cap,
+                                       uint64_t *nbits)
+{
+    if (!ctx || !d_out || !nbits || b0 > b1) return BZH_E_ARG;
+    if (b1 > ctx->plan_blocks.size()) return BZH_E_STATE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const double keep_plan = ctx->stats.ms_plan;
+    memset(&ctx->stats, 0, sizeof ctx->stats);
+    ctx->stats.ms_plan = keep_plan;
+    ctx->sort_spans.clear();
+    ctx->evnext = 0;
+    *nbits = 0;
+    if (b0 == b1) return BZH_OK;
+    return encode_range(ctx, b0, b1, (uint8_t *)d_out, cap, 0, nbits);
+}
+
+extern "C" int bzh_assemble_device(bzh_ctx *ctx, const void *const *d_segs, const uint64_t *seg_bits, size_t nseg,
+                                   const uint32_t *block_crcs, size_t nblocks, void *d_out, size_t cap,
+                                   size_t *out_len)
+{
+    if (!ctx || !d_out || !out_len || (nseg && (!d_segs || !seg_bits)) || (nblocks && !block_crcs)) return BZH_E_ARG;
+    if (((uintptr_t)d_out & 3u) != 0) return BZH_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    uint64_t body = 0;
+    for (size_t k = 0; k < nseg; k++) body += seg_bits[k];
+    const uint64_t total_bits = 32 + body + 80;
+    const size_t bytes = (size_t)((total_bits + 7) / 8);
+    const size_t words = (size_t)((total_bits + 31) / 32) + 1;
+    *out_len = bytes;
+    if (words * 4 > cap) return BZH_E_CAP;
+    HIP_TRY(ctx, hipMemsetAsync(d_out, 0, words * 4, st));
+    uint64_t pos = 32;
+    for (size_t k = 0; k < nseg; k++) {
+        if (seg_bits[k] == 0) continue;
+        if (((uintptr_t)d_segs[k] & 3u) != 0) return BZH_E_ARG;
+        const uint64_t nw = (seg_bits[k] + 31) / 32;
+        uint32_t grid = (uint32_t)std::min<uint64_t>((nw + 255) / 256, 4096);
+        concat_bits<<<dim3(grid), 256, 0, st>>>((uint32_t *)d_out, pos, (const uint32_t *)d_segs[k], seg_bits[k]);
+        pos += seg_bits[k];
+    }
+    stream_frame<<<1, 64, 0, st>>>((uint32_t *)d_out, ctx->level, body, fold_stream_crc(block_crcs, nblocks));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return BZH_OK;
+}
+
+extern "C" int bzh_encode_device(bzh_ctx *ctx, const void *d_in, size_t n, void *d_out, size_t cap, size_t *out_len,
+                                 size_t *consumed)
+{
+    if (!ctx || (!d_in && n) || !d_out || !out_len) return BZH_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (((uintptr_t)d_out & 3u) != 0 || cap < 16) return BZH_E_ARG;
+    hipEvent_t t0 = nullptr, t1 = nullptr, t2 = nullptr;
+    ctx->evnext = 0;
+    ctx->sort_spans.clear();
+    memset(&ctx->stats, 0, sizeof ctx->stats);
+    if (ctx->profiling) {
+        t0 = bzh_event(ctx);
+        hipEventRecord(t0, st);
+    }
+    BZH_TRY(check_in_ptr(ctx, d_in));
+    BZH_TRY(rle1_plan(ctx, (const uint8_t *)d_in, n));
+    if (ctx->profiling) {
+        t1 = bzh_event(ctx);
+        hipEventRecord(t1, st);
+    }
+    // words 0 and 1 hold the stream header and the first body bits
+    HIP_TRY(ctx, hipMemsetAsync(d_out, 0, 4, st));
+    uint64_t body = 0;
+    const size_t nb = ctx->plan_blocks.size();
+    if (nb) {
+        BZH_TRY(encode_range(ctx, 0, nb, (uint8_t *)d_out, cap, 32, &body));
+    } else {
+        HIP_TRY(ctx, hipMemsetAsync(d_out, 0, 16, st));
+    }
+    const uint64_t total_bits = 32 + body + 80;
+    const size_t bytes = (size_t)((total_bits + 7) / 8);
+    *out_len = bytes;
+    // the footer may reach one word past what encode_range zeroed
+    const uint64_t zero_from = (32 + body + 31) / 32 + (nb ? 1 : 0), zero_to = (total_bits + 31) / 32 + 1;
+    if (zero_to * 4 > cap) return BZH_E_CAP;
+    if (zero_to > zero_from && nb)
+        HIP_TRY(ctx, hipMemsetAsync((uint8_t *)d_out + zero_from * 4, 0, (size_t)(zero_to - zero_from) * 4, st));
+    std::vector<uint32_t> crcs(nb);
+    for (size_t k = 0; k < nb; k++) crcs[k] = ctx->plan_blocks[k].crc;
+    stream_frame<<<1, 64, 0, st>>>((uint32_t *)d_out, ctx->level, body, fold_stream_crc(crcs.data(), nb));
+    HIP_TRY(ctx, hipGetLastError());
+    if (ctx->profiling) {
+        t2 = bzh_event(ctx);
+        hipEventRecord(t2, st);
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (ctx->profiling) {
+        ctx->stats.ms_plan = span_ms(t0, t1);
+        ctx->stats.ms_total = span_ms(t0, t2);
+    }
+    if (consumed) *consumed = n;
+    return BZH_OK;
+}
+
+extern "C" int bzh_encode(bzh_ctx *ctx, const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len,
+                          size_t *consumed)
+{
+    if (!ctx || (!in && n) || !out || !out_len) return BZH_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    BZH_TRY(ensure_stage(ctx, ctx->d_stage_in, ctx->stage_in_size, n + 16));
+    const size_t dcap = n + n / 4 + (n / ((size_t)ctx->M * 4 / 5) + 2) * 4096 + 65536;
+    BZH_TRY(ensure_stage(ctx, ctx->d_stage_out, ctx->stage_out_size, dcap));
+    if (n) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage_in, in, n, hipMemcpyHostToDevice, st));
+    size_t len = 0;
+    BZH_TRY(bzh_encode_device(ctx, ctx->d_stage_in, n, ctx->d_stage_out, ctx->stage_out_size & ~(size_t)3, &len,
+                              consumed));
+    *out_len = len;
+    if (len > cap) return BZH_E_CAP;
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_stage_out, len, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return BZH_OK;
+}
+
+// ---- stage seams: RLE1 split and CRC -------------------------------------------------------------------------
+extern "C" int bzh_rle1_split(bzh_ctx *ctx, const uint8_t *in, size_t n, bzh_block *blocks, size_t max_blocks,
+                              size_t *nblocks, uint8_t *rle_out, size_t rle_cap)
+{
+    if (!ctx || (!in && n) || !blocks || !nblocks) return BZH_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    stats_begin(ctx);
+    BZH_TRY(ensure_stage(ctx, ctx->d_stage_in, ctx->stage_in_size, n + 16));
+    if (n) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage_in, in, n, hipMemcpyHostToDevice, st));
+    BZH_TRY(rle1_plan(ctx, ctx->d_stage_in, n));
+    const size_t nb = ctx->plan_blocks.size();
+    *nblocks = nb;
+    if (nb > max_blocks) return BZH_E_CAP;
+    for (size_t k = 0; k < nb; k++) blocks[k] = ctx->plan_blocks[k];
+    if (rle_out) {
+        size_t pos = 0;
+        Batch &bt = ctx->bt;
+        for (size_t k0 = 0; k0 < nb; k0 += ctx->max_batch) {
+            const uint32_t B = (uint32_t)std::min<size_t>(ctx->max_batch, nb - k0);
+            BZH_TRY(rle1_emit(ctx, k0, B));
+            for (uint32_t b = 0; b < B; b++) {
+                const size_t len = ctx->plan_blocks[k0 + b].rle_len;
+                if (pos + len > rle_cap) return BZH_E_CAP;
+                HIP_TRY(ctx, hipMemcpyAsync(rle_out + pos, bt.rle + (size_t)b * bt.S, len, hipMemcpyDeviceToHost, st));
+                pos += len;
+            }
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+        }
+    }
+    return BZH_OK;
+}
+
+extern "C" int bzh_crc32(bzh_ctx *ctx, const uint8_t *in, size_t n, uint32_t *crc)
+{
+    if (!ctx || (!in && n) || !crc) return BZH_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    BZH_TRY(ensure_stage(ctx, ctx->d_stage_in, ctx->stage_in_size, n + 16));
+    if (n) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage_in, in, n, hipMemcpyHostToDevice, ctx->stream));
+    return crc_device(ctx, ctx->d_stage_in, n, crc);
 }

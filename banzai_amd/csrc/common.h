@@ -121,6 +121,7 @@ struct bzh_ctx {
     uint8_t *d_stage_out = nullptr;
     size_t stage_out_size = 0;
     uint32_t *h_pinned = nullptr; // small pinned readback area
+    void *d_crctab = nullptr;     // GF(2) tables of the block CRC (rle1.hip)
     bzh_stats stats{};
     std::vector<hipEvent_t> evpool;
     size_t evnext = 0;

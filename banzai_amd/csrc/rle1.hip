@@ -1,0 +1,616 @@
+// rle1.hip -- RLE1, block splitting and block CRCs on gfx950.
+//
+// Replaces rle::rle_one (reference lib/rle.rs:102-253) and crc32::checksum (lib/crc32.rs:31-48).
+//
+// rle_one is a sequential state machine; its result has a closed form (checked against the
+// literal restatement in oracle/ on randomized multi-block inputs, tests/test_rle1_model.py):
+//   * the RLE1 stream of a block is the canonical one -- every maximal run cut into chunks of
+//     255 input bytes, a chunk of l >= 4 bytes becoming 4 literals + count l-4, shorter chunks
+//     staying literal (lib/rle.rs:171-234) -- with chunking restarted at the block's first byte;
+//   * tokens are taken greedily while they fit in M = 100000*level-1 output bytes (:120-122),
+//     except that the 4th literal of a chunk is only taken when its count byte fits too
+//     (bound checks at :136-151, :179-182, :193-203); so a block may end at M-1 bytes.
+//
+// Plan (whole input, parallel):  run-start flags -> per-tile counts -> scan -> run table RS[],
+// canonical output length per run -> scan -> PO[].  Splitting (one wavefront, sequential over
+// blocks, 64-ary searches in PO) yields every block's (in_off, in_len, rle_len, first run).
+// CRC-32/BZIP2 per block: per-thread table CRC of 32-byte pieces, shifted by x^(8*bytes_after)
+// with GF(2) multiplies, XOR-reduced (CRC is linear), init/xorout folded in at the end.
+// Emit (per batch): one thread per input byte places its literal and, at chunk ends, the count.
+#include "common.h"
+
+constexpr int RL_THREADS = 256;
+constexpr int RL_ITEMS = 16;
+constexpr uint32_t RL_TILE = RL_THREADS * RL_ITEMS; // 4096 input bytes per workgroup
+
+struct PlanArrays {
+    const uint8_t *in;
+    uint64_t n;
+    uint32_t ntiles;   // input tiles
+    uint32_t *tbase;   // [ntiles+1] run starts before each tile (exclusive scan of counts)
+    uint32_t *rs;      // [J+1] run start positions, rs[J] = n
+    uint64_t *po;      // [J+1] canonical output offset of each run, po[J] = total
+    uint64_t *rtsum;   // [run tiles + 1] scan scratch
+    uint32_t *nruns;   // [1] J
+    BlockDesc *blocks; // [maxblocks]
+    uint32_t *first;   // [maxblocks] index of the run containing in_off
+    uint32_t *nblocks; // [1]
+    uint32_t maxblocks;
+    uint32_t M;
+};
+
+__device__ __forceinline__ uint32_t canon_len(uint32_t L) // RLE1 bytes of a run of L equal bytes
+{
+    const uint32_t q = L / 255u, r = L - q * 255u;
+    return 5u * q + (r < 4u ? r : 5u);
+}
+
+// 16 input bytes at p0 (p0 and `in` 16-byte aligned); the ragged tail is read byte by byte so
+// nothing past in[n-1] is touched.
+__device__ __forceinline__ void load16(const uint8_t *in, uint64_t n, uint64_t p0, uint32_t v[4])
+{
+    if (p0 + 16 <= n) {
+        const uint4 w = *reinterpret_cast<const uint4 *>(in + p0);
+        v[0] = w.x;
+        v[1] = w.y;
+        v[2] = w.z;
+        v[3] = w.w;
+    } else {
+        v[0] = v[1] = v[2] = v[3] = 0;
+        for (uint32_t k = 0; p0 + k < n; k++) v[k >> 2] |= (uint32_t)in[p0 + k] << ((k & 3) * 8);
+    }
+}
+
+// Returns a 16-bit mask of run starts among the 16 bytes at p0 (needs the byte before p0).
+__device__ __forceinline__ uint32_t start_mask(const uint8_t *in, uint64_t n, uint64_t p0, uint32_t &valid,
+                                               uint32_t v[4])
+{
+    valid = 0;
+    if (p0 >= n) return 0;
+    load16(in, n, p0, v);
+    valid = n - p0 < 16 ? (uint32_t)(n - p0) : 16u;
+    uint32_t prev = p0 ? in[p0 - 1] : 0x100u;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t c = (v[k >> 2] >> ((k & 3) * 8)) & 255u;
+        if ((uint32_t)k < valid && c != prev) mask |= 1u << k;
+        prev = c;
+    }
+    return mask;
+}
+
+__global__ void __launch_bounds__(RL_THREADS) plan_count(PlanArrays pa)
+{
+    const uint32_t tile = blockIdx.x;
+    const uint64_t p0 = (uint64_t)tile * RL_TILE + threadIdx.x * RL_ITEMS;
+    uint32_t valid, v[4];
+    const uint32_t cnt = __popc(start_mask(pa.in, pa.n, p0, valid, v));
+    __shared__ uint32_t ls[RL_THREADS / 64 + 2];
+    uint32_t tot;
+    (void)block_excl_add(cnt, ls, &tot);
+    if (threadIdx.x == 0) pa.tbase[tile] = tot;
+}
+
+// Single workgroup: exclusive scan of 32-bit counts (in place), total to out[count] and *total.
+__global__ void __launch_bounds__(1024) scan_u32(uint32_t *v, uint32_t count, uint32_t *total)
+{
+    __shared__ uint32_t ls[20];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < count; base += 1024) {
+        const uint32_t e = base + threadIdx.x;
+        const uint32_t x = e < count ? v[e] : 0;
+        uint32_t tot;
+        const uint32_t ex = block_excl_add(x, ls, &tot);
+        if (e < count) v[e] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) {
+        v[count] = carry;
+        if (total) *total = carry;
+    }
+}
+
+__global__ void __launch_bounds__(1024) scan_u64(uint64_t *v, uint32_t count)
+{
+    __shared__ uint64_t sh[1024];
+    uint64_t carry = 0;
+    const uint32_t t = threadIdx.x;
+    for (uint32_t base = 0; base < count; base += 1024) {
+        const uint32_t e = base + t;
+        sh[t] = e < count ? v[e] : 0;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1) {
+            const uint64_t x = t >= d ? sh[t - d] : 0;
+            __syncthreads();
+            sh[t] += x;
+            __syncthreads();
+        }
+        if (e < count) v[e] = carry + (t ? sh[t - 1] : 0);
+        const uint64_t tot = sh[1023];
+        __syncthreads();
+        carry += tot;
+    }
+    if (t == 0) v[count] = carry;
+}
+
+__global__ void __launch_bounds__(RL_THREADS) plan_runs(PlanArrays pa)
+{
+    const uint32_t tile = blockIdx.x;
+    const uint64_t p0 = (uint64_t)tile * RL_TILE + threadIdx.x * RL_ITEMS;
+    uint32_t valid, v[4];
+    const uint32_t mask = start_mask(pa.in, pa.n, p0, valid, v);
+    __shared__ uint32_t ls[RL_THREADS / 64 + 2];
+    uint32_t tot;
+    uint32_t j = pa.tbase[tile] + block_excl_add(__popc(mask), ls, &tot);
+    for (uint32_t m = mask; m; m &= m - 1) pa.rs[j++] = (uint32_t)(p0 + (uint32_t)__ffs(m) - 1u);
+    if (tile == 0 && threadIdx.x == 0) pa.rs[pa.tbase[pa.ntiles]] = (uint32_t)pa.n;
+}
+
+// Canonical output length per run, tile sums (phase 0) / offsets (phase 1) over tiles of 4096 runs.
+__global__ void __launch_bounds__(RL_THREADS) plan_outlen(PlanArrays pa, int phase)
+{
+    const uint32_t J = *pa.nruns;
+    const uint32_t j0 = blockIdx.x * RL_TILE + threadIdx.x * RL_ITEMS;
+    if (blockIdx.x * RL_TILE >= J) return;
+    uint32_t ol[RL_ITEMS];
+    uint32_t sum = 0;
+    if (j0 < J) {
+        uint32_t prev = pa.rs[j0];
+#pragma unroll
+        for (int k = 0; k < RL_ITEMS; k++) {
+            ol[k] = 0;
+            if (j0 + k < J) {
+                const uint32_t nx = pa.rs[j0 + k + 1];
+                ol[k] = canon_len(nx - prev);
+                prev = nx;
+            }
+            sum += ol[k];
+        }
+    }
+    __shared__ uint32_t ls[RL_THREADS / 64 + 2];
+    uint32_t tot;
+    const uint32_t ex = block_excl_add(sum, ls, &tot);
+    if (phase == 0) {
+        if (threadIdx.x == 0) pa.rtsum[blockIdx.x] = tot;
+        return;
+    }
+    if (j0 < J) {
+        uint64_t off = pa.rtsum[blockIdx.x] + ex;
+#pragma unroll
+        for (int k = 0; k < RL_ITEMS; k++) {
+            if (j0 + k < J) {
+                pa.po[j0 + k] = off;
+                off += ol[k];
+            }
+        }
+        if (j0 + RL_ITEMS >= J) pa.po[J] = off; // the thread holding the last run
+    }
+}
+
+// ---- block splitting: one wavefront, sequential over blocks ----------------------------------------------
+__device__ __forceinline__ void cut_in_run(uint32_t Lr, uint32_t R, uint32_t &k, uint32_t &t)
+{
+    const uint32_t nf = Lr / 255u;
+    k = R / 5u < nf ? R / 5u : nf;
+    const uint32_t rho = R - 5u * k;
+    const uint32_t ell = k < nf ? 255u : Lr - 255u * nf;
+    t = ell >= 4u ? (rho < 3u ? rho : 3u) : rho;
+}
+
+__global__ void __launch_bounds__(64) plan_split(PlanArrays pa)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t J = *pa.nruns;
+    const uint64_t N = pa.n;
+    const uint32_t M = pa.M;
+    uint64_t s = 0;
+    uint32_t j0 = 0, nb = 0;
+    while (s < N && nb < pa.maxblocks) {
+        const uint32_t Lr = (uint32_t)(pa.rs[j0 + 1] - s);
+        const uint32_t A = canon_len(Lr);
+        uint64_t consumed;
+        uint32_t out, nj0;
+        uint64_t ns;
+        if (A > M) {
+            uint32_t k, t;
+            cut_in_run(Lr, M, k, t);
+            consumed = 255ull * k + t;
+            out = 5u * k + t;
+            ns = s + consumed;
+            nj0 = j0;
+        } else {
+            const uint64_t pj = pa.po[j0 + 1];
+            const uint64_t lim = (uint64_t)(M - A) + pj;
+            // largest x in [j0+1, J] with po[x] <= lim (po strictly increasing), 64-ary search
+            uint32_t lo = j0 + 1, hi = J;
+            while (lo < hi) {
+                const uint32_t span = hi - lo;
+                const uint32_t step = (span + 63u) / 64u;
+                const uint64_t x = (uint64_t)lo + (uint64_t)(lane + 1) * step;
+                const bool ok = x <= hi && pa.po[x] <= lim;
+                const uint32_t c = (uint32_t)__popcll(__ballot(ok));
+                lo += c * step;
+                const uint64_t nh = (uint64_t)lo + step - 1;
+                if (nh < hi) hi = (uint32_t)nh;
+            }
+            const uint32_t x = lo;
+            const uint32_t cum = A + (uint32_t)(pa.po[x] - pj);
+            if (x == J) {
+                consumed = N - s;
+                out = cum;
+                ns = N;
+                nj0 = J;
+            } else {
+                const uint32_t rsx = pa.rs[x];
+                const uint32_t Lx = pa.rs[x + 1] - rsx;
+                uint32_t k, t;
+                cut_in_run(Lx, M - cum, k, t);
+                consumed = (uint64_t)rsx - s + 255ull * k + t;
+                out = cum + 5u * k + t;
+                ns = (uint64_t)rsx + 255ull * k + t;
+                nj0 = x;
+            }
+        }
+        if (lane == 0) {
+            BlockDesc d;
+            d.in_off = s;
+            d.in_len = consumed;
+            d.rle_len = out;
+            d.crc = 0;
+            pa.blocks[nb] = d;
+            pa.first[nb] = j0;
+        }
+        nb++;
+        s = ns;
+        j0 = nj0;
+    }
+    if (lane == 0) *pa.nblocks = (s < N) ? 0xFFFFFFFFu : nb; // overflow marker
+}
+
+// ---- CRC-32/BZIP2 ----------------------------------------------------------------------------------------
+constexpr uint32_t CRC_POLY = 0x04C11DB7u;
+constexpr uint32_t CRC_PIECE = 32;                         // bytes per thread
+constexpr uint32_t CRC_TILE = RL_THREADS * CRC_PIECE;      // 8192 bytes per workgroup
+
+struct CrcTables {
+    uint32_t pow2[40];   // x^(2^k) mod P, k = 0..39 (bit exponents)
+    uint32_t shift[256]; // x^(8*32*i) mod P: moves a 32-byte piece i pieces to the left
+};
+
+__device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b) // a*b mod P, bit 31 = x^31
+{
+    uint32_t r = 0;
+#pragma unroll 8
+    for (int i = 31; i >= 0; i--) {
+        r = (r << 1) ^ ((r >> 31) ? CRC_POLY : 0u);
+        if ((b >> i) & 1u) r ^= a;
+    }
+    return r;
+}
+
+// x^e mod P for a wave-uniform exponent e (< 2^40): lanes take one bit each, product by butterfly.
+__device__ __forceinline__ uint32_t gf_pow_x(const CrcTables &ct, uint64_t e, uint32_t lane)
+{
+    uint32_t f = 1u; // polynomial 1
+    if (lane < 40 && ((e >> lane) & 1ull)) f = ct.pow2[lane];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) f = gf_mul(f, __shfl_xor(f, d, 64));
+    return f;
+}
+
+__global__ void __launch_bounds__(RL_THREADS) crc_tiles(const uint8_t *in, const BlockDesc *blocks, uint32_t *acc,
+                                                         const CrcTables *ctp)
+{
+    const uint32_t b = blockIdx.y;
+    const BlockDesc d = blocks[b];
+    const uint64_t t0 = (uint64_t)blockIdx.x * CRC_TILE;
+    if (t0 >= d.in_len) return;
+    const CrcTables &ct = *ctp;
+    __shared__ uint32_t tab[256];
+    {
+        uint32_t c = threadIdx.x << 24;
+#pragma unroll
+        for (int k = 0; k < 8; k++) c = (c << 1) ^ ((c >> 31) ? CRC_POLY : 0u);
+        tab[threadIdx.x] = c;
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t tile_len = d.in_len - t0 < CRC_TILE ? (uint32_t)(d.in_len - t0) : CRC_TILE;
+    // pieces: a ragged first piece of r bytes (if any), then full 32-byte pieces, so that the bytes
+    // after every piece are a multiple of 32
+    const uint32_t r = tile_len % CRC_PIECE, np = tile_len / CRC_PIECE + (r ? 1u : 0u);
+    uint32_t crc = 0;
+    if (threadIdx.x < np) {
+        uint32_t off, len;
+        if (r) {
+            off = threadIdx.x ? r + (threadIdx.x - 1) * CRC_PIECE : 0;
+            len = threadIdx.x ? CRC_PIECE : r;
+        } else {
+            off = threadIdx.x * CRC_PIECE;
+            len = CRC_PIECE;
+        }
+        const uint8_t *p = in + d.in_off + t0 + off;
+        for (uint32_t k = 0; k < len; k++) crc = (crc << 8) ^ tab[(crc >> 24) ^ p[k]];
+        crc = gf_mul(crc, ct.shift[np - 1 - threadIdx.x]);
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) crc ^= __shfl_xor(crc, s, 64);
+    __shared__ uint32_t wred[RL_THREADS / 64];
+    if (lane == 0) wred[threadIdx.x >> 6] = crc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        uint32_t c = 0;
+        for (int w = 0; w < RL_THREADS / 64; w++) c ^= wred[w];
+        const uint64_t after_tile = d.in_len - t0 - tile_len;
+        const uint32_t pw = gf_pow_x(ct, 8ull * after_tile, lane);
+        if (lane == 0) atomicXor(&acc[b], gf_mul(c, pw));
+    }
+}
+
+__global__ void __launch_bounds__(64) crc_finish(BlockDesc *blocks, const uint32_t *acc, uint32_t nb,
+                                                  const CrcTables *ctp)
+{
+    const uint32_t b = blockIdx.x;
+    if (b >= nb) return;
+    const CrcTables &ct = *ctp;
+    const uint32_t pw = gf_pow_x(ct, 8ull * blocks[b].in_len, threadIdx.x);
+    if (threadIdx.x == 0) blocks[b].crc = acc[b] ^ gf_mul(0xFFFFFFFFu, pw) ^ 0xFFFFFFFFu;
+}
+
+// Device copy of the GF(2) tables, created on first use (one context = one GPU).
+static int crc_tables(bzh_ctx *ctx, const CrcTables **out);
+
+static CrcTables make_crc_tables()
+{
+    CrcTables ct;
+    auto mul = [](uint32_t a, uint32_t b) {
+        uint32_t r = 0;
+        for (int i = 31; i >= 0; i--) {
+            r = (r << 1) ^ ((r >> 31) ? CRC_POLY : 0u);
+            if ((b >> i) & 1u) r ^= a;
+        }
+        return r;
+    };
+    uint32_t p = 2u; // x
+    for (int k = 0; k < 40; k++) {
+        ct.pow2[k] = p;
+        p = mul(p, p);
+    }
+    const uint32_t step = ct.pow2[8]; // x^256 = one 32-byte piece
+    uint32_t sft = 1u;
+    for (int i = 0; i < 256; i++) {
+        ct.shift[i] = sft;
+        sft = mul(sft, step);
+    }
+    return ct;
+}
+
+static int crc_tables(bzh_ctx *ctx, const CrcTables **out)
+{
+    if (!ctx->d_crctab) {
+        const CrcTables ct = make_crc_tables();
+        if (hipMalloc(&ctx->d_crctab, sizeof ct) != hipSuccess) return BZH_E_NOMEM;
+        HIP_TRY(ctx, hipMemcpy(ctx->d_crctab, &ct, sizeof ct, hipMemcpyHostToDevice));
+    }
+    *out = (const CrcTables *)ctx->d_crctab;
+    return BZH_OK;
+}
+
+// ---- emit: RLE1 bytes of a batch of blocks -----------------------------------------------------------------
+struct EmitArgs {
+    const uint8_t *in;
+    uint64_t n;
+    const uint32_t *tbase;
+    const uint32_t *rs;
+    const uint64_t *po;
+    const BlockDesc *blocks; // plan blocks, already offset to the batch's first block
+    const uint32_t *first;
+};
+
+__global__ void __launch_bounds__(RL_THREADS) rle1_emit_kernel(EmitArgs ea, Batch bt)
+{
+    const uint32_t b = blockIdx.y;
+    const BlockDesc d = ea.blocks[b];
+    const uint64_t in_end = d.in_off + d.in_len;
+    const uint32_t tile = (uint32_t)(d.in_off / RL_TILE) + blockIdx.x;
+    const uint64_t p0 = (uint64_t)tile * RL_TILE + threadIdx.x * RL_ITEMS;
+    if ((uint64_t)tile * RL_TILE >= in_end) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        bt.n[b] = d.rle_len;
+        bt.desc[b] = d;
+    }
+    uint32_t valid, v[4];
+    const uint32_t mask = start_mask(ea.in, ea.n, p0, valid, v);
+    __shared__ uint32_t ls[RL_THREADS / 64 + 2];
+    uint32_t tot;
+    // run index of the byte BEFORE this thread's first byte
+    uint32_t j = ea.tbase[tile] + block_excl_add(__popc(mask), ls, &tot) - 1u;
+    if (p0 >= in_end || p0 + valid <= d.in_off) return;
+
+    const uint32_t jf = ea.first[b];
+    const uint64_t pof = ea.po[jf + 1];
+    const uint32_t A = canon_len((uint32_t)(ea.rs[jf + 1] - d.in_off));
+    uint8_t *out = bt.rle + (size_t)b * bt.S;
+
+    uint32_t curj = 0xFFFFFFFFu, rstart = 0, rend = 0, origin = 0, base = 0;
+    for (uint32_t k = 0; k < valid; k++) {
+        if (mask & (1u << k)) j++;
+        const uint64_t p = p0 + k;
+        if (p < d.in_off || p >= in_end) continue;
+        if (j != curj) {
+            curj = j;
+            rstart = ea.rs[j];
+            rend = ea.rs[j + 1];
+            if (rstart <= d.in_off) { // the run the block starts in: chunking restarts at in_off
+                origin = (uint32_t)d.in_off;
+                base = 0;
+            } else {
+                origin = rstart;
+                base = A + (uint32_t)(ea.po[j] - pof);
+            }
+        }
+        const uint32_t dd = (uint32_t)p - origin;
+        const uint32_t c = dd / 255u, kk = dd - c * 255u;
+        const uint32_t o = base + 5u * c;
+        const uint32_t byte = (v[k >> 2] >> ((k & 3) * 8)) & 255u;
+        if (kk < 4u) out[o + kk] = (uint8_t)byte;
+        if (kk >= 3u && (kk == 254u || p + 1 == rend)) out[o + 4u] = (uint8_t)(kk - 3u); // lib/rle.rs:212-226
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------
+struct PlanWs { // layout of ctx->plan_ws
+    PlanArrays pa;
+    uint32_t *crcacc;
+    size_t bytes;
+};
+
+static size_t a256(size_t v) { return (v + 255) / 256 * 256; }
+
+static PlanWs plan_layout(uint8_t *base, uint64_t n, uint32_t M)
+{
+    PlanWs w{};
+    const uint64_t ntiles = (n + RL_TILE - 1) / RL_TILE;
+    const uint64_t maxruns = n;
+    const uint64_t rtiles = (maxruns + RL_TILE - 1) / RL_TILE;
+    const uint64_t maxblocks = n / ((uint64_t)(M - 1) * 4 / 5) + 4;
+    uint8_t *p = base;
+    auto take = [&](size_t bytes) {
+        uint8_t *r = p;
+        p += a256(bytes);
+        return r;
+    };
+    w.pa.n = n;
+    w.pa.M = M;
+    w.pa.ntiles = (uint32_t)ntiles;
+    w.pa.maxblocks = (uint32_t)maxblocks;
+    w.pa.tbase = (uint32_t *)take((ntiles + 2) * 4);
+    w.pa.rs = (uint32_t *)take((maxruns + 2) * 4);
+    w.pa.po = (uint64_t *)take((maxruns + 2) * 8);
+    w.pa.rtsum = (uint64_t *)take((rtiles + 2) * 8);
+    w.pa.nruns = (uint32_t *)take(256);
+    w.pa.blocks = (BlockDesc *)take(maxblocks * sizeof(BlockDesc));
+    w.pa.first = (uint32_t *)take(maxblocks * 4);
+    w.pa.nblocks = (uint32_t *)take(256);
+    w.crcacc = (uint32_t *)take(maxblocks * 4);
+    w.bytes = (size_t)(p - base);
+    return w;
+}
+
+// Plan over d_in[0..n): d_in must be readable up to the next multiple of 16 bytes.
+int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n)
+{
+    hipStream_t st = ctx->stream;
+    ctx->plan_blocks.clear();
+    ctx->plan_in = d_in;
+    ctx->plan_n = n;
+    if (n == 0) return BZH_OK;
+    if (n > 0xFFFF0000ull) {
+        bzh_set_error(ctx, "input of %zu bytes exceeds the 32-bit position range of one plan", n);
+        return BZH_E_ARG;
+    }
+    PlanWs probe = plan_layout(nullptr, n, ctx->M);
+    if (probe.bytes > ctx->plan_ws_size) {
+        if (ctx->plan_ws) hipFree(ctx->plan_ws);
+        ctx->plan_ws = nullptr;
+        ctx->plan_ws_size = 0;
+        if (hipMalloc(&ctx->plan_ws, probe.bytes) != hipSuccess) {
+            bzh_set_error(ctx, "hipMalloc(%zu) for the plan failed", probe.bytes);
+            return BZH_E_NOMEM;
+        }
+        ctx->plan_ws_size = probe.bytes;
+    }
+    PlanWs w = plan_layout((uint8_t *)ctx->plan_ws, n, ctx->M);
+    PlanArrays &pa = w.pa;
+    pa.in = d_in;
+
+    plan_count<<<dim3(pa.ntiles), RL_THREADS, 0, st>>>(pa);
+    scan_u32<<<dim3(1), 1024, 0, st>>>(pa.tbase, pa.ntiles, pa.nruns);
+    plan_runs<<<dim3(pa.ntiles), RL_THREADS, 0, st>>>(pa);
+    uint32_t J = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&J, pa.nruns, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    const uint32_t rtiles = (J + RL_TILE - 1) / RL_TILE;
+    plan_outlen<<<dim3(rtiles), RL_THREADS, 0, st>>>(pa, 0);
+    scan_u64<<<dim3(1), 1024, 0, st>>>(pa.rtsum, rtiles);
+    plan_outlen<<<dim3(rtiles), RL_THREADS, 0, st>>>(pa, 1);
+    plan_split<<<dim3(1), 64, 0, st>>>(pa);
+    uint32_t nb = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&nb, pa.nblocks, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (nb == 0 || nb == 0xFFFFFFFFu || nb > pa.maxblocks) {
+        bzh_set_error(ctx, "block split failed (nb=%u)", nb);
+        return BZH_E_HIP;
+    }
+    std::vector<BlockDesc> hb(nb);
+    HIP_TRY(ctx, hipMemcpyAsync(hb.data(), pa.blocks, nb * sizeof(BlockDesc), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    uint64_t maxlen = 0;
+    for (auto &d : hb) maxlen = d.in_len > maxlen ? d.in_len : maxlen;
+    // block CRCs
+    const CrcTables *ct = nullptr;
+    BZH_TRY(crc_tables(ctx, &ct));
+    HIP_TRY(ctx, hipMemsetAsync(w.crcacc, 0, (size_t)nb * 4, st));
+    const uint32_t ctiles = (uint32_t)((maxlen + CRC_TILE - 1) / CRC_TILE);
+    for (uint32_t b0 = 0; b0 < nb; b0 += 32768) { // grid.y limit
+        const uint32_t cnt = nb - b0 < 32768 ? nb - b0 : 32768;
+        crc_tiles<<<dim3(ctiles, cnt), RL_THREADS, 0, st>>>(d_in, pa.blocks + b0, w.crcacc + b0, ct);
+    }
+    crc_finish<<<dim3(nb), 64, 0, st>>>(pa.blocks, w.crcacc, nb, ct);
+    HIP_TRY(ctx, hipMemcpyAsync(hb.data(), pa.blocks, nb * sizeof(BlockDesc), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->plan_blocks.resize(nb);
+    for (uint32_t b = 0; b < nb; b++) {
+        ctx->plan_blocks[b].in_off = hb[b].in_off;
+        ctx->plan_blocks[b].in_len = hb[b].in_len;
+        ctx->plan_blocks[b].rle_len = hb[b].rle_len;
+        ctx->plan_blocks[b].crc = hb[b].crc;
+    }
+    return BZH_OK;
+}
+
+// Fills bt.rle / bt.n / bt.desc for plan blocks [b0, b0+B).
+int rle1_emit(bzh_ctx *ctx, size_t b0, uint32_t B)
+{
+    if (B == 0) return BZH_OK;
+    PlanWs w = plan_layout((uint8_t *)ctx->plan_ws, ctx->plan_n, ctx->M);
+    EmitArgs ea{};
+    ea.in = ctx->plan_in;
+    ea.n = ctx->plan_n;
+    ea.tbase = w.pa.tbase;
+    ea.rs = w.pa.rs;
+    ea.po = w.pa.po;
+    ea.blocks = w.pa.blocks + b0;
+    ea.first = w.pa.first + b0;
+    uint64_t maxspan = 0;
+    for (uint32_t b = 0; b < B; b++) {
+        const bzh_block &pb = ctx->plan_blocks[b0 + b];
+        const uint64_t t0 = pb.in_off / RL_TILE, t1 = (pb.in_off + pb.in_len - 1) / RL_TILE;
+        maxspan = std::max<uint64_t>(maxspan, t1 - t0 + 1);
+    }
+    rle1_emit_kernel<<<dim3((uint32_t)maxspan, B), RL_THREADS, 0, ctx->stream>>>(ea, ctx->bt);
+    HIP_TRY(ctx, hipGetLastError());
+    return BZH_OK;
+}
+
+// CRC of d_in[0..n) as one block (seam for the parity tests).
+int crc_device(bzh_ctx *ctx, const uint8_t *d_in, size_t n, uint32_t *crc_out)
+{
+    hipStream_t st = ctx->stream;
+    const CrcTables *ct = nullptr;
+    BZH_TRY(crc_tables(ctx, &ct));
+    BlockDesc d{0, n, 0, 0};
+    BlockDesc *dd = ctx->bt.desc;        // scratch
+    uint32_t *acc = ctx->bt.nactA;       // scratch
+    HIP_TRY(ctx, hipMemcpyAsync(dd, &d, sizeof d, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(acc, 0, 4, st));
+    const uint32_t ctiles = (uint32_t)((n + CRC_TILE - 1) / CRC_TILE);
+    if (ctiles) crc_tiles<<<dim3(ctiles, 1), RL_THREADS, 0, st>>>(d_in, dd, acc, ct);
+    crc_finish<<<dim3(1), 64, 0, st>>>(dd, acc, 1, ct);
+    HIP_TRY(ctx, hipMemcpyAsync(&d, dd, sizeof d, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    *crc_out = d.crc;
+    return BZH_OK;
+}
