@@ -1,0 +1,50 @@
+"""banzai_amd -- MI355X-native bzip2 block encoder with banzai's API and banzai's bits.
+
+Mirrors the public surface of jgbyrne/banzai v0.3.1 (reference lib/lib.rs:84-153):
+
+    encode(reader, writer, level) -> bytes consumed      (lib/lib.rs:84-132)
+    encode_file(in_path, out_path) -> bytes consumed     (lib/lib.rs:141-153, level 9)
+
+Everything is computed by hand-written HIP kernels behind the C ABI in include/bzhip.h
+(libbzhip.so); there is no CPU path.  `reader` is any object with .read(), `writer` any object
+with .write() (the Rust signature takes BufRead / BufWriter<W>).
+"""
+from . import _native
+
+__all__ = ["encode", "encode_file", "Context", "BzhError"]
+
+Context = _native.Context
+BzhError = _native.BzhError
+
+_ctx_cache = {}
+
+
+def _ctx(level, device=0):
+    key = (device, level)
+    if key not in _ctx_cache:
+        _ctx_cache[key] = _native.Context(device, level, 0)
+    return _ctx_cache[key]
+
+
+def encode(reader, writer, level, device=0):
+    """bzip2-encode everything `reader` yields and write the stream to `writer`.
+
+    Same contract as banzai::encode: `level` in 1..=9 is the block size in 100 kB units
+    (anything else raises, the reference asserts at lib/lib.rs:89); returns the number of input
+    bytes encoded; I/O errors of reader/writer propagate."""
+    if not isinstance(level, int) or not 1 <= level <= 9:
+        raise ValueError("level must be in 1..=9")
+    data = reader.read()
+    if not isinstance(data, (bytes, bytearray, memoryview)):
+        raise TypeError("reader.read() must return bytes")
+    stream = _ctx(level, device).encode(bytes(data))
+    writer.write(stream)
+    if hasattr(writer, "flush"):
+        writer.flush()
+    return len(data)
+
+
+def encode_file(in_path, out_path, device=0):
+    """bzip2-encode a file into another file at level 9 (banzai::encode_file)."""
+    with open(in_path, "rb") as inf, open(out_path, "wb") as outf:
+        return encode(inf, outf, 9, device)

@@ -1,0 +1,120 @@
+"""Deterministic synthetic inputs for the configs of BASELINE.json (there is no network, so
+enwik8/enwik9 themselves are only used when a local copy is pointed to by $BZH_ENWIK8).
+
+  xorshift_bytes      C2: uniform random bytes (xorshift64*, seed 0x9E3779B97F4A7C15), SURVEY 8(d)
+  enwik_synthetic     C3/C4: "enwik8-synthetic" -- Zipfian word model with wiki-ish markup tokens
+                      and a few percent of long verbatim repeats (real wiki dumps contain duplicated
+                      passages; they are what drives the number of prefix-doubling rounds)
+  pathological        C5: long single-byte runs + periodic repeats
+"""
+import os
+
+import numpy as np
+
+_LETTERS = np.frombuffer(b"etaoinshrdlcumwfgypbvkjxqz", dtype=np.uint8)
+_LETTER_P = np.array([12.7, 9.1, 8.2, 7.5, 7.0, 6.7, 6.3, 6.1, 6.0, 4.3, 4.0, 2.8, 2.8, 2.4, 2.4, 2.2, 2.0, 2.0,
+                      1.9, 1.5, 1.0, 0.8, 0.15, 0.15, 0.1, 0.07])
+_MARKUP = [b"<page>\n", b"</page>\n", b"<title>", b"</title>\n", b"<text xml:space=\"preserve\">", b"</text>\n",
+           b"[[", b"]]", b"{{", b"}}", b"&quot;", b"&amp;", b"==", b"'''", b"\n\n", b"\n* ", b"|", b"<ref>",
+           b"</ref>", b"[[Category:", b"<id>", b"</id>\n", b"<timestamp>2006-03-0", b"http://www."]
+_PUNCT = [b". ", b", ", b"; ", b": ", b".\n", b" (", b") ", b" - ", b"1", b"2", b"19", b"200", b"0", b"The ", b"In "]
+
+
+def xorshift_bytes(n, seed=0x9E3779B97F4A7C15):
+    """Top byte of xorshift64* outputs; the same generator is trivial to restate in C."""
+    out = np.empty(n, dtype=np.uint8)
+    x = np.uint64(seed)
+    # vectorised in lanes: 4096 independent streams seeded by splitting the seed sequence
+    lanes = 4096
+    st = (np.arange(1, lanes + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ x
+    mul = np.uint64(0x2545F4914F6CDD1D)
+    pos = 0
+    with np.errstate(over="ignore"):
+        while pos < n:
+            st ^= st >> np.uint64(12)
+            st ^= st << np.uint64(25)
+            st ^= st >> np.uint64(27)
+            v = ((st * mul) >> np.uint64(56)).astype(np.uint8)
+            k = min(lanes, n - pos)
+            out[pos:pos + k] = v[:k]
+            pos += k
+    return out
+
+
+def _vocab(rng, nwords):
+    lens = np.clip(1 + rng.poisson(4.2, nwords), 1, 14)
+    total = int(lens.sum())
+    letters = rng.choice(_LETTERS, size=total, p=_LETTER_P / _LETTER_P.sum())
+    words = []
+    pos = 0
+    for ln in lens:
+        words.append(letters[pos:pos + ln].tobytes() + b" ")
+        pos += ln
+    # sprinkle markup and punctuation tokens through the frequent ranks
+    for k, tok in enumerate(_PUNCT):
+        words.insert(3 + 4 * k, tok)
+    for k, tok in enumerate(_MARKUP):
+        words.insert(40 + 23 * k, tok)
+    vlen = np.array([len(w) for w in words], dtype=np.int64)
+    voff = np.concatenate(([0], np.cumsum(vlen)[:-1]))
+    vflat = np.frombuffer(b"".join(words), dtype=np.uint8)
+    return vflat, voff, vlen
+
+
+def enwik_synthetic(n, seed=20061, repeat_fraction=0.03):
+    """n bytes of enwik-like text (deterministic for a given (n, seed))."""
+    rng = np.random.default_rng(seed)
+    vflat, voff, vlen = _vocab(rng, 50000)
+    nv = len(vlen)
+    p = 1.0 / (np.arange(nv) + 2.7) ** 1.07
+    cdf = np.cumsum(p / p.sum())
+    out = np.empty(n, dtype=np.uint8)
+    pos = 0
+    chunk_words = 600_000
+    while pos < n:
+        ids = np.searchsorted(cdf, rng.random(chunk_words), side="right")
+        ids = np.minimum(ids, nv - 1)
+        lens = vlen[ids]
+        ends = np.cumsum(lens)
+        total = int(ends[-1])
+        src = np.repeat(voff[ids] - (ends - lens), lens) + np.arange(total)
+        take = min(total, n - pos)
+        out[pos:pos + take] = vflat[src[:take]]
+        pos += take
+    # verbatim repeats: copy earlier passages forward (lengths log-uniform in 200 .. 60000)
+    budget = int(n * repeat_fraction)
+    while budget > 0 and n > 200_000:
+        ln = int(np.exp(rng.uniform(np.log(200), np.log(60000))))
+        src0 = int(rng.integers(0, n - ln - 1))
+        dst0 = int(rng.integers(0, n - ln - 1))
+        out[dst0:dst0 + ln] = out[src0:src0 + ln].copy()
+        budget -= ln
+    return out
+
+
+def pathological(n, seed=5):
+    """C5: 1/4 zeros, 1/4 a 1024-byte random tile repeated, 1/4 'ab' repeated, 1/4 alternating runs
+    of lengths cycling {255, 256, 257, 3, 4, 5} over two byte values."""
+    rng = np.random.default_rng(seed)
+    q = n // 4
+    parts = [np.zeros(q, dtype=np.uint8)]
+    tile = rng.integers(0, 256, 1024, dtype=np.uint8)
+    parts.append(np.tile(tile, q // 1024 + 1)[:q])
+    parts.append(np.tile(np.frombuffer(b"ab", dtype=np.uint8), q // 2 + 1)[:q])
+    cyc = [255, 256, 257, 3, 4, 5]
+    reps = (n - 3 * q) // sum(cyc) + 1
+    lens = np.tile(np.array(cyc), reps)
+    vals = np.tile(np.array([0x41, 0x7A], dtype=np.uint8), len(lens) // 2 + 1)[:len(lens)]
+    parts.append(np.repeat(vals, lens)[:n - 3 * q])
+    return np.concatenate(parts)
+
+
+def workload(n=100_000_000, segment=0):
+    """The bench workload: real enwik8 if $BZH_ENWIK8 names a file, else enwik8-synthetic.
+    -> (uint8 array of n bytes, name)"""
+    path = os.environ.get("BZH_ENWIK8")
+    if path and os.path.exists(path):
+        data = np.fromfile(path, dtype=np.uint8)
+        if data.size >= n:
+            return data[:n].copy(), "enwik8"
+    return enwik_synthetic(n, seed=20061 + segment), "enwik8-synthetic"

@@ -212,8 +212,10 @@ extern "C" int bzh_bwt_batch(bzh_ctx *ctx, const uint8_t *in, const uint64_t *of
     for (size_t k0 = 0; k0 < nblk; k0 += ctx->max_batch) {
         uint32_t B = (uint32_t)std::min<size_t>(ctx->max_batch, nblk - k0);
         uint32_t nmax = 0;
+        uint64_t ntotal = 0;
         for (uint32_t b = 0; b < B; b++) {
             uint32_t n = lens[k0 + b];
+            ntotal += n;
             if (n == 0 || n > ctx->M) {
                 bzh_set_error(ctx, "block %zu length %u outside 1..%u", k0 + b, n, ctx->M);
                 return BZH_E_ARG;
@@ -223,7 +225,7 @@ extern "C" int bzh_bwt_batch(bzh_ctx *ctx, const uint8_t *in, const uint64_t *of
                                         ctx->stream));
         }
         HIP_TRY(ctx, hipMemcpyAsync(bt.n, lens + k0, B * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        BZH_TRY(bwt_run(ctx, B, nmax));
+        BZH_TRY(bwt_run(ctx, B, nmax, ntotal));
         for (uint32_t b = 0; b < B; b++)
             HIP_TRY(ctx, hipMemcpyAsync(bwt_out + offs[k0 + b], bt.bwt + (size_t)b * bt.S, lens[k0 + b],
                                         hipMemcpyDeviceToHost, ctx->stream));
@@ -404,8 +406,10 @@ static int encode_range(bzh_ctx *ctx, size_t b0, size_t b1, uint8_t *d_out, size
     for (size_t k0 = b0; k0 < b1; k0 += ctx->max_batch) {
         const uint32_t B = (uint32_t)std::min<size_t>(ctx->max_batch, b1 - k0);
         uint32_t nmax = 0;
+        uint64_t ntotal = 0;
         for (uint32_t b = 0; b < B; b++) {
             nmax = std::max(nmax, ctx->plan_blocks[k0 + b].rle_len);
+            ntotal += ctx->plan_blocks[k0 + b].rle_len;
             ctx->stats.rle_bytes += ctx->plan_blocks[k0 + b].rle_len;
             ctx->stats.raw_bytes += ctx->plan_blocks[k0 + b].in_len;
         }
@@ -420,7 +424,7 @@ static int encode_range(bzh_ctx *ctx, size_t b0, size_t b1, uint8_t *d_out, size
         mark(0);
         BZH_TRY(rle1_emit(ctx, k0, B));
         mark(1);
-        BZH_TRY(bwt_run(ctx, B, nmax));
+        BZH_TRY(bwt_run(ctx, B, nmax, ntotal));
         mark(2);
         BZH_TRY(mtf_run(ctx, B, nmax));
         mark(3);

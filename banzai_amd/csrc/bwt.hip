@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(256) bwt_emit(Batch bt)
 
 // ---- host driver -----------------------------------------------------------------------------------
 template <int BITS, int MODE>
-static void launch_pass(bzh_ctx *ctx, SortArgs &a, uint32_t B, uint32_t maxcnt)
+static void launch_pass(bzh_ctx *ctx, SortArgs &a, uint32_t B, uint32_t maxcnt, uint64_t elems)
 {
     uint32_t tiles = (maxcnt + SORT_TILE - 1) / SORT_TILE;
     if (tiles == 0) return;
@@ -437,6 +437,7 @@ static void launch_pass(bzh_ctx *ctx, SortArgs &a, uint32_t B, uint32_t maxcnt)
         hipEventRecord(e1, ctx->stream);
         ctx->sort_spans.push_back({e0, e1});
         ctx->stats.bwt_sort_launches += 1;
+        ctx->stats.bwt_sort_elems += elems; // (key, suffix) pairs this launch writes
     }
 }
 
@@ -450,8 +451,8 @@ static void launch_refine(bzh_ctx *ctx, RefineArgs &r, uint32_t B, uint32_t maxc
 }
 
 // Suffix-sort and emit the last column for blocks 0..B-1 of the batch (bt.rle / bt.n filled).
-// nmax = largest block length in the batch.
-int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax)
+// nmax = largest block length in the batch, ntotal = sum of block lengths (statistics only).
+int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
 {
     Batch &bt = ctx->bt;
     if (B == 0) return BZH_OK;
@@ -473,13 +474,13 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax)
     a.shift = 0;
     a.src = nullptr;
     a.dst = bt.listA;
-    launch_pass<8, GEN_BYTES4>(ctx, a, B, nmax);
+    launch_pass<8, GEN_BYTES4>(ctx, a, B, nmax, ntotal);
     uint2 *cur = bt.listA, *oth = bt.listB;
     for (int p = 1; p < 4; p++) {
         a.shift = 8 * p;
         a.src = cur;
         a.dst = oth;
-        launch_pass<8, GEN_LIST>(ctx, a, B, nmax);
+        launch_pass<8, GEN_LIST>(ctx, a, B, nmax, ntotal);
         uint2 *t = cur;
         cur = oth;
         oth = t;
@@ -532,17 +533,17 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax)
         a.shift = 0;
         a.src = nullptr;
         a.dst = bt.listA;
-        launch_pass<7, GEN_ROUND>(ctx, a, B, nmax);
+        launch_pass<7, GEN_ROUND>(ctx, a, B, nmax, sum);
         // passes 1, 2 over the compact list
         a.cnt = nact;
         a.shift = 7;
         a.src = bt.listA;
         a.dst = bt.listB;
-        launch_pass<7, GEN_LIST>(ctx, a, B, maxact);
+        launch_pass<7, GEN_LIST>(ctx, a, B, maxact, sum);
         a.shift = 14;
         a.src = bt.listB;
         a.dst = bt.listA;
-        launch_pass<7, GEN_LIST>(ctx, a, B, maxact);
+        launch_pass<7, GEN_LIST>(ctx, a, B, maxact, sum);
 
         r.cnt = nact;
         r.list = bt.listA;
