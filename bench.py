@@ -81,28 +81,17 @@ def main():
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
 
+    from banzai_amd import sharded
+    engine = None
     if world > 1:
         seg_cap = (seg_bytes // 3 + seg_bytes // 8 + (1 << 20)) & ~3
-        d_part = torch.zeros(seg_cap, dtype=torch.uint8, device=dev)
-        gather_list = [torch.empty(seg_cap, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
-        d_bits = torch.zeros(1, dtype=torch.int64, device=dev)
+        engine = sharded.DeviceEngine(ctx, d_in, total, d_out, seg_cap)
 
     def step():
         """One pass of the hot path; returns the stream length on rank 0."""
         if world == 1:
             return ctx.encode_device(d_in.data_ptr(), total, d_out.data_ptr(), out_cap)
-        blocks = ctx.plan_device(d_in.data_ptr(), total)           # replicated sequential split
-        nb = len(blocks)
-        b0, b1 = rank * nb // world, (rank + 1) * nb // world       # contiguous block ranges
-        nbits = ctx.encode_range_device(b0, b1, d_part.data_ptr(), seg_cap)
-        d_bits[0] = nbits
-        all_bits = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(all_bits, d_bits)
-        dist.gather(d_part, gather_list, dst=0)                     # encoded blocks -> rank 0 over xGMI
-        if rank != 0:
-            return 0
-        segs = [(gather_list[k].data_ptr(), int(all_bits[k].item())) for k in range(world)]
-        return ctx.assemble_device(segs, [b[3] for b in blocks], d_out.data_ptr(), out_cap)
+        return sharded.encode_sharded(engine, dist, rank, world)
 
     def barrier():
         if world > 1:

@@ -1,0 +1,53 @@
+"""Seeded inputs shared by the CPU and GPU tests (edge cases the reference's fuzzers reach:
+empty and ragged inputs, block-boundary offsets, run lengths around 4 / 255 / 256, periodic blocks)."""
+import random
+
+import numpy as np
+
+
+def gen(n, mode, seed):
+    rng = random.Random(seed * 1000003 + n * 7 + sum(mode.encode()))
+    if mode == "random":
+        return np.random.default_rng(seed + n).integers(0, 256, n, dtype=np.uint8).tobytes()
+    if mode == "lowalpha":
+        return np.random.default_rng(seed + n).integers(0, 3, n, dtype=np.uint8).tobytes()
+    if mode == "shortruns":
+        d = bytearray()
+        while len(d) < n:
+            d += bytes([rng.randrange(3)]) * rng.choice([1, 1, 2, 3, 4, 5, 6, 7, 8])
+        return bytes(d[:n])
+    if mode == "longruns":
+        d = bytearray()
+        while len(d) < n:
+            d += bytes([rng.randrange(2)]) * rng.choice([1, 3, 4, 5, 254, 255, 256, 257, 258, 259, 260, 509, 510,
+                                                         511, 1000, 70000])
+        return bytes(d[:n])
+    if mode == "text":
+        return (b"It was the best of times, it was the worst of times, it was the age of wisdom. " * (n // 70 + 1))[:n]
+    if mode == "same":
+        return bytes([rng.randrange(256)]) * n
+    if mode == "periodic":
+        w = bytes(rng.randrange(4) for _ in range(rng.choice([1, 2, 3, 5, 7, 64])))
+        return (w * (n // len(w) + 1))[:n]
+    raise ValueError(mode)
+
+
+MODES = ["random", "lowalpha", "shortruns", "longruns", "text", "same", "periodic"]
+
+# sizes around the level-1 block boundary (M = 99,999) and tiny / ragged inputs
+SIZES_L1 = [0, 1, 2, 3, 4, 5, 49, 50, 51, 255, 256, 257, 4095, 4096, 4097, 99998, 99999, 100000, 100001, 250000]
+SIZES_L9 = [1, 1000, 899999, 900000, 1800001]
+
+
+def boundary_cases(M=99999):
+    """Inputs whose runs straddle the block budget in every residue the cut rule distinguishes."""
+    out = []
+    for pre in range(M - 8, M + 3):
+        for runlen in (3, 4, 5, 6, 255, 256, 259, 600):
+            rng = np.random.default_rng(pre * 31 + runlen)
+            body = rng.integers(1, 200, pre, dtype=np.uint8)
+            # forbid accidental runs in the literal part
+            body[1:][body[1:] == body[:-1]] += 1
+            tail = rng.integers(1, 200, 3000, dtype=np.uint8)
+            out.append(body.tobytes() + bytes([250]) * runlen + tail.tobytes())
+    return out

@@ -1,0 +1,45 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import pyoracle
+    pyoracle.lib()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def native():
+    from banzai_amd import _native
+    _native.build()
+    _native.lib()
+    return _native
+
+
+def _make_ctx(native, level):
+    return native.Context(0, level, 8)
+
+
+@pytest.fixture(scope="session")
+def ctx9(native):
+    c = _make_ctx(native, 9)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="session")
+def ctx1(native):
+    c = _make_ctx(native, 1)
+    yield c
+    c.close()

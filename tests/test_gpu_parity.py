@@ -1,0 +1,275 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI (include/bzhip.h), against the oracle on the
+same seeded inputs -- bit-exact for every stage seam and for whole .bz2 streams -- plus the
+committed golden vectors and, at BASELINE.json's full size, size-independent properties
+(libbz2 reproduces the input; block table tiles the input; sharded == monolithic)."""
+import bz2
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def oracle_split(oracle, data, level):
+    off, res, chunks = 0, [], []
+    while off < len(data):
+        r, crc, used = oracle.rle_one(data[off:], level)
+        res.append((off, used, len(r), crc))
+        chunks.append(r)
+        off += used
+    return res, chunks
+
+
+# ---- stage seams -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", cases.MODES)
+def test_bwt_seam(oracle, ctx9, mode):
+    for n in (1, 2, 3, 5, 63, 64, 65, 257, 4095, 4096, 4097, 10000, 70000):
+        d = cases.gen(n, mode, 2)
+        g, o = ctx9.bwt(d), oracle.bwt(d)
+        assert g[0] == o[0] and g[1] == o[1] and np.array_equal(g[2], o[2]), (mode, n)
+
+
+def test_bwt_golden_vectors(ctx9):
+    """reference KAT (lib/bwt.rs:758-772) and the debug/bwt.py vectors, straight on the GPU"""
+    v = json.load(open(os.path.join(GOLDEN, "ref_debug_vectors.json")))
+    for c in v["bwt"]:
+        b, ptr, _ = ctx9.bwt(c["input"].encode())
+        assert b.decode() == c["bwt"] and ptr == c["ptr"], c["input"][:40]
+
+
+def test_bwt_full_block_config2(oracle, ctx9):
+    """BASELINE.json configs[1]: one 899,999-byte block of uniform-random bytes, BWT only"""
+    from banzai_amd import corpus
+    d = corpus.xorshift_bytes(899_999).tobytes()
+    g, o = ctx9.bwt(d), oracle.bwt(d)
+    assert g[0] == o[0] and g[1] == o[1] and np.array_equal(g[2], o[2])
+
+
+def test_bwt_batch_and_worst_cases(oracle, ctx9):
+    near = (b"\0\0\0\0\xfb" * 180000)[:899_998]          # RLE1 image of a zero-filled input: ~18 rounds
+    exact = (b"abcab" * 180000)[:899_995]                 # S = w^k: ties resolved by descending index (T6)
+    text = cases.gen(600_000, "text", 1)
+    blocks = [near, exact, text, b"z", text[:77777]]
+    res = ctx9.bwt_batch(blocks)
+    for r, b in zip(res, blocks):
+        o = oracle.bwt(b)
+        assert r[0] == o[0] and r[1] == o[1] and np.array_equal(r[2], o[2])
+
+
+@pytest.mark.parametrize("mode", cases.MODES)
+def test_mtf_seam(oracle, ctx9, mode):
+    for n in (1, 2, 15, 16, 17, 1023, 1024, 1025, 2047, 2048, 2049, 4096, 4097, 20000, 300000):
+        d = cases.gen(n, mode, 4)
+        b, _, hb = oracle.bwt(d)
+        gs, gf, gn = ctx9.mtf(b, hb)
+        os_, of, on = oracle.mtf_and_rle(b, hb)
+        assert gn == on and np.array_equal(gs, os_) and np.array_equal(gf, of), (mode, n)
+
+
+def test_mtf_kat_on_gpu(ctx9):
+    """reference lib/mtf.rs:139-158"""
+    test = [153, 45, 45, 38, 135, 179, 26, 154, 165, 170, 170, 170, 170, 18, 109, 240, 174, 150, 87, 164, 30, 30,
+            30, 30, 30, 30, 30, 148, 190, 10, 60, 13, 13, 13, 13, 13, 6, 81, 200, 13, 225, 32, 17, 43, 22, 179, 13,
+            13, 17, 236, 236, 236, 236, 236, 236, 236, 121, 211, 2, 211, 185, 54, 16] + [5] * 22 + [50] + [5] * 22 + [40]
+    expected = [27, 17, 0, 15, 25, 33, 15, 29, 31, 32, 0, 0, 17, 28, 40, 34, 33, 31, 34, 25, 1, 1, 34, 36, 23, 33, 25,
+                1, 0, 25, 34, 37, 4, 39, 32, 31, 34, 33, 26, 7, 0, 5, 40, 1, 1, 38, 40, 34, 2, 40, 40, 38, 38, 0, 1,
+                1, 0, 40, 2, 0, 1, 1, 0, 40, 41]
+    hb = np.zeros(256, np.uint8)
+    hb[list(set(test))] = 1
+    syms, _, ns = ctx9.mtf(bytes(test), hb)
+    assert list(syms) == expected and ns == len(set(test)) + 2
+
+
+@pytest.mark.parametrize("mode", cases.MODES)
+def test_huffman_seam(oracle, ctx9, mode):
+    for n in (1, 3, 49, 50, 51, 1000, 4096, 4097, 70000, 300000):
+        d = cases.gen(n, mode, 6)
+        b, _, hb = oracle.bwt(d)
+        s, f, ns = oracle.mtf_and_rle(b, hb)
+        gbits, gn, glens = ctx9.huffman(s, ns, f)
+        obits, on, olens = oracle.huffman_block(s, ns, f)
+        assert gn == on and gbits == obits, (mode, n)
+        assert np.array_equal(glens[:, :ns], olens[:, :ns])
+
+
+def test_huffman_three_tables_and_rescale(oracle, ctx9):
+    """>= 200 symbols -> 3 tables (T10); a geometric histogram forces the > 17-bit rescale loop (T13)"""
+    rng = np.random.default_rng(3)
+    d = np.minimum(rng.geometric(0.35, 400_000) - 1 + rng.integers(0, 2, 400_000) * 128, 255).astype(np.uint8).tobytes()
+    b, _, hb = oracle.bwt(d)
+    s, f, ns = oracle.mtf_and_rle(b, hb)
+    gbits, gn, glens = ctx9.huffman(s, ns, f)
+    obits, on, olens = oracle.huffman_block(s, ns, f)
+    assert gn == on and gbits == obits and np.array_equal(glens[:, :ns], olens[:, :ns])
+    # direct check of the code-length builder on Fibonacci-like weights (needs scaling > 1)
+    fib = [1, 1]
+    while len(fib) < 40:
+        fib.append(fib[-1] + fib[-2])
+    freqs = np.zeros(258, np.uint32)
+    freqs[:40] = np.minimum(fib, 2 ** 31)
+    assert oracle.build_table_from_freqs(40, freqs).max() <= 17
+
+
+@pytest.mark.parametrize("level,ctxname", [(1, "ctx1"), (9, "ctx9")])
+def test_rle1_split_and_crc_seam(oracle, request, level, ctxname):
+    ctx = request.getfixturevalue(ctxname)
+    sizes = cases.SIZES_L1 if level == 1 else cases.SIZES_L9
+    for mode in cases.MODES:
+        for n in sizes:
+            d = cases.gen(n, mode, 8)
+            infos, chunks = ctx.rle1_split(d)
+            oi, oc = oracle_split(oracle, d, level)
+            assert infos == oi and chunks == oc, (level, mode, n)
+            if n:
+                assert ctx.crc32(d) == oracle.crc32(d)
+
+
+def test_rle1_boundary_residues(oracle, ctx1):
+    for d in cases.boundary_cases()[::3]:
+        infos, chunks = ctx1.rle1_split(d)
+        oi, oc = oracle_split(oracle, d, 1)
+        assert infos == oi and chunks == oc
+
+
+def test_rle1_golden_vectors(ctx9):
+    """debug/rle1.py vectors (unbounded RLE1; inputs < M so the bound never bites)"""
+    v = json.load(open(os.path.join(GOLDEN, "ref_debug_vectors.json")))
+    for c in v["rle1"]:
+        d = bytes.fromhex(c["input_hex"])
+        infos, chunks = ctx9.rle1_split(d)
+        assert len(infos) == 1 and chunks[0].hex() == c["rle1_hex"] and infos[0][1] == len(d)
+
+
+def test_crc_check_value(ctx9):
+    assert ctx9.crc32(b"123456789") == 0xFC891918
+
+
+# ---- whole streams ---------------------------------------------------------------------------------------
+def test_golden_streams(ctx1, ctx9):
+    g = json.load(open(os.path.join(GOLDEN, "streams.json")))
+    for c in g["streams"]:
+        data = bytes.fromhex(c["input_hex"]) if "input_hex" in c else bytes([c["fill"]]) * c["count"]
+        ctx = ctx1 if c["level"] == 1 else ctx9
+        assert ctx.encode(data).hex() == c["stream_hex"], c["name"]
+
+
+@pytest.mark.parametrize("mode", cases.MODES)
+def test_stream_bit_exact_level1(oracle, ctx1, mode):
+    for n in cases.SIZES_L1:
+        d = cases.gen(n, mode, 12)
+        g = ctx1.encode(d)
+        assert g == oracle.encode(d, 1), (mode, n)
+        assert bz2.decompress(g) == d
+
+
+@pytest.mark.parametrize("mode", ["random", "text", "longruns", "shortruns", "same"])
+def test_stream_bit_exact_level9(oracle, ctx9, mode):
+    for n in cases.SIZES_L9:
+        d = cases.gen(n, mode, 13)
+        g = ctx9.encode(d)
+        assert g == oracle.encode(d, 9), (mode, n)
+
+
+def test_other_levels(oracle, native):
+    d = cases.gen(1_234_567, "text", 2) + cases.gen(300_000, "longruns", 2)
+    for level in (2, 5, 8):
+        with native.Context(0, level, 4) as ctx:
+            assert ctx.encode(d) == oracle.encode(d, level), level
+
+
+def test_public_api_matches_reference_surface(oracle, tmp_path):
+    """encode(reader, writer, level) -> consumed; encode_file(in, out) at level 9 (lib/lib.rs:84-153)"""
+    import banzai_amd
+    d = cases.gen(250_000, "text", 3)
+    out = io.BytesIO()
+    assert banzai_amd.encode(io.BytesIO(d), out, 1) == len(d)
+    assert out.getvalue() == oracle.encode(d, 1)
+    src, dst = tmp_path / "in.bin", tmp_path / "out.bz2"
+    src.write_bytes(d)
+    assert banzai_amd.encode_file(str(src), str(dst)) == len(d)
+    assert dst.read_bytes() == oracle.encode(d, 9)
+
+
+def test_pathological_config5(oracle, ctx9):
+    """BASELINE.json configs[4] (scaled to 8 MB): long single-byte runs + periodic repeats"""
+    from banzai_amd import corpus
+    d = corpus.pathological(8_000_000).tobytes()
+    g = ctx9.encode(d)
+    assert g == oracle.encode(d, 9)
+    assert bz2.decompress(g) == d
+
+
+# ---- device-resident and sharded paths ------------------------------------------------------------------
+def test_device_path_and_sharded_equals_monolithic(oracle, native):
+    """bzh_encode_device == oracle, and plan + 3 x encode_range + assemble (the N>1 protocol, here
+    on one GPU) gives the identical stream."""
+    import torch
+    from banzai_amd import corpus, sharded
+    n = 12_345_678
+    data = corpus.enwik_synthetic(n, seed=3)
+    want = oracle.encode(data.tobytes(), 9)
+    dev = torch.device("cuda", 0)
+    d_in = torch.zeros(n + 16, dtype=torch.uint8, device=dev)
+    d_in[:n] = torch.from_numpy(data).to(dev)
+    cap = (n // 2 + (1 << 20)) & ~3
+    d_out = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    with native.Context(0, 9, 8) as ctx:  # max_batch 8 < 14 blocks: exercises batching
+        ln = ctx.encode_device(d_in.data_ptr(), n, d_out.data_ptr(), cap)
+        assert d_out[:ln].cpu().numpy().tobytes() == want
+        blocks = ctx.plan_device(d_in.data_ptr(), n)
+        assert blocks[0][0] == 0 and sum(b[1] for b in blocks) == n
+        assert all(blocks[k][0] + blocks[k][1] == blocks[k + 1][0] for k in range(len(blocks) - 1))
+        world, segs, keep = 3, [], []
+        for r in range(world):
+            b0, b1 = sharded.block_range(len(blocks), r, world)
+            buf = torch.zeros(cap, dtype=torch.uint8, device=dev)
+            nbits = ctx.encode_range_device(b0, b1, buf.data_ptr(), cap)
+            keep.append(buf)
+            segs.append((buf.data_ptr(), nbits))
+        d_out.zero_()
+        ln2 = ctx.assemble_device(segs, [b[3] for b in blocks], d_out.data_ptr(), cap)
+        assert d_out[:ln2].cpu().numpy().tobytes() == want
+
+
+def test_output_capacity_error(native):
+    import torch
+    dev = torch.device("cuda", 0)
+    data = np.random.default_rng(0).integers(0, 256, 500_000, dtype=np.uint8)
+    d_in = torch.zeros(data.size + 16, dtype=torch.uint8, device=dev)
+    d_in[:data.size] = torch.from_numpy(data).to(dev)
+    d_out = torch.zeros(1024, dtype=torch.uint8, device=dev)
+    with native.Context(0, 9, 4) as ctx:
+        with pytest.raises(native.BzhError) as e:
+            ctx.encode_device(d_in.data_ptr(), data.size, d_out.data_ptr(), 1024)
+        assert e.value.status == -4
+
+
+def test_full_size_properties_config3(native):
+    """BASELINE.json configs[2] at full size (100,000,000 bytes): properties that do not need the
+    oracle -- libbz2 reproduces the input (pins every CRC, table and block cut), the block table
+    tiles the input, RLE1 lengths respect the level, and two runs give identical bytes."""
+    import torch
+    from banzai_amd import corpus
+    n = 100_000_000
+    data, _ = corpus.workload(n)
+    dev = torch.device("cuda", 0)
+    d_in = torch.zeros(n + 16, dtype=torch.uint8, device=dev)
+    d_in[:n] = torch.from_numpy(data).to(dev)
+    cap = (n // 2 + (1 << 20)) & ~3
+    d_out = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    with native.Context(0, 9, 128) as ctx:
+        ln = ctx.encode_device(d_in.data_ptr(), n, d_out.data_ptr(), cap)
+        first = d_out[:ln].cpu().numpy().tobytes()
+        blocks = ctx.plan_device(d_in.data_ptr(), n)
+        d_out.zero_()
+        ln2 = ctx.encode_device(d_in.data_ptr(), n, d_out.data_ptr(), cap)
+        assert d_out[:ln2].cpu().numpy().tobytes() == first
+    assert sum(b[1] for b in blocks) == n and all(0 < b[2] <= 899_999 for b in blocks)
+    assert first[:4] == b"BZh9"
+    assert bz2.decompress(first) == data.tobytes()

@@ -1,0 +1,107 @@
+"""CPU, world_size 2 over gloo: the block-sharded protocol of banzai_amd/sharded.py (range
+partition, gather order, bit-level assembly, stream-CRC fold) reproduces the single stream.
+The per-rank compute is a test engine built on the oracle (no GPU here); on a GPU box the same
+protocol runs with sharded.DeviceEngine (covered by tests/test_gpu_parity.py on one device)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests import cases
+
+
+def _strip_framing(stream):
+    """block bits of a .bz2 stream: drop 'BZh9' (32 bits) and footer (48+32 bits) + padding."""
+    bits = np.unpackbits(np.frombuffer(stream, dtype=np.uint8))
+    # footer magic 0x177245385090 starts 80 bits before the (padded) end; find the last occurrence
+    magic = np.unpackbits(np.frombuffer(bytes.fromhex("177245385090"), dtype=np.uint8))
+    for pad in range(8):
+        end = len(bits) - pad - 32
+        if end - 48 >= 32 and np.array_equal(bits[end - 48:end], magic):
+            return bits[32:end - 48]
+    raise AssertionError("footer not found")
+
+
+class OracleEngine:
+    def __init__(self, oracle, data, level, cap):
+        self.o, self.data, self.level, self.cap = oracle, data, level, cap
+        self.stream = None
+
+    def plan(self):
+        _, infos = self.o.encode(self.data, self.level, want_blocks=True)
+        self.blocks = [(int(b.in_off), int(b.in_len), int(b.rle_len), int(b.crc)) for b in infos]
+        return self.blocks
+
+    def encode_range(self, b0, b1):
+        buf = torch.zeros(self.cap, dtype=torch.uint8)
+        if b0 == b1:
+            return buf, 0
+        lo, hi = self.blocks[b0][0], self.blocks[b1 - 1][0] + self.blocks[b1 - 1][1]
+        bits = _strip_framing(self.o.encode(self.data[lo:hi], self.level))
+        packed = np.packbits(bits)
+        buf[:len(packed)] = torch.from_numpy(packed)
+        return buf, int(len(bits))
+
+    def assemble(self, segments, crcs):
+        allbits = [np.unpackbits(np.frombuffer(b"BZh" + bytes([48 + self.level]), dtype=np.uint8))]
+        for t, nb in segments:
+            allbits.append(np.unpackbits(t.numpy())[:nb])
+        s = 0
+        for c in crcs:
+            s = (c ^ (((s << 1) | (s >> 31)) & 0xFFFFFFFF)) & 0xFFFFFFFF
+        allbits.append(np.unpackbits(np.frombuffer(bytes.fromhex("177245385090") + s.to_bytes(4, "big"), dtype=np.uint8)))
+        self.stream = np.packbits(np.concatenate(allbits)).tobytes()
+        return len(self.stream)
+
+
+def _worker(rank, world, port, data, level, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from banzai_amd import sharded
+    from oracle import pyoracle
+    eng = OracleEngine(pyoracle, data, level, cap=len(data) + 4096)
+    n = sharded.encode_sharded(eng, dist, rank, world)
+    if rank == 0:
+        q.put((n, eng.stream))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("mode,n", [("text", 450_000), ("longruns", 700_001), ("random", 99_000)])
+def test_two_ranks_reproduce_single_stream(oracle, mode, n):
+    data = cases.gen(n, mode, 11)
+    want = oracle.encode(data, 1)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, data, 1, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    n_out, stream = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert n_out == len(want) and stream == want
+
+
+def test_block_range_partition():
+    from banzai_amd.sharded import block_range
+    for nb in (0, 1, 7, 111, 1112):
+        for world in (1, 2, 4, 8):
+            got = [block_range(nb, r, world) for r in range(world)]
+            assert got[0][0] == 0 and got[-1][1] == nb
+            assert all(got[k][1] == got[k + 1][0] for k in range(world - 1))
+            assert max(b - a for a, b in got) - min(b - a for a, b in got) <= 1
