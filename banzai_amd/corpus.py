@@ -2,9 +2,9 @@
 enwik8/enwik9 themselves are only used when a local copy is pointed to by $BZH_ENWIK8).
 
   xorshift_bytes      C2: uniform random bytes (xorshift64*, seed 0x9E3779B97F4A7C15), SURVEY 8(d)
-  enwik_synthetic     C3/C4: "enwik8-synthetic" -- Zipfian word model with wiki-ish markup tokens
-                      and a few percent of long verbatim repeats (real wiki dumps contain duplicated
-                      passages; they are what drives the number of prefix-doubling rounds)
+  enwik_synthetic     C3/C4: "enwik8-synthetic" -- Zipfian word + reusable-phrase model with wiki-ish
+                      markup tokens and a few percent of long verbatim repeats (real wiki dumps contain
+                      duplicated passages; they are what drives the number of prefix-doubling rounds)
   pathological        C5: long single-byte runs + periodic repeats
 """
 import os
@@ -41,7 +41,8 @@ def xorshift_bytes(n, seed=0x9E3779B97F4A7C15):
     return out
 
 
-def _vocab(rng, nwords):
+def _vocab(rng, nwords, nphrases):
+    """Token table: single words (Zipf rank = index) followed by multi-word phrases."""
     lens = np.clip(1 + rng.poisson(4.2, nwords), 1, 14)
     total = int(lens.sum())
     letters = rng.choice(_LETTERS, size=total, p=_LETTER_P / _LETTER_P.sum())
@@ -55,25 +56,41 @@ def _vocab(rng, nwords):
         words.insert(3 + 4 * k, tok)
     for k, tok in enumerate(_MARKUP):
         words.insert(40 + 23 * k, tok)
-    vlen = np.array([len(w) for w in words], dtype=np.int64)
+    nw = len(words)
+    pw = 1.0 / (np.arange(nw) + 2.7) ** 1.07
+    cdf_w = np.cumsum(pw / pw.sum())
+    # phrases: 2..9 words drawn from the same Zipf law; reused phrases are what gives natural text
+    # its long common prefixes (and the BWT its deep sorts)
+    plen = rng.integers(2, 10, nphrases)
+    ids = np.minimum(np.searchsorted(cdf_w, rng.random(int(plen.sum())), side="right"), nw - 1)
+    phrases = []
+    pos = 0
+    for ln in plen:
+        phrases.append(b"".join(words[i] for i in ids[pos:pos + ln]))
+        pos += ln
+    toks = words + phrases
+    vlen = np.array([len(w) for w in toks], dtype=np.int64)
     voff = np.concatenate(([0], np.cumsum(vlen)[:-1]))
-    vflat = np.frombuffer(b"".join(words), dtype=np.uint8)
-    return vflat, voff, vlen
+    vflat = np.frombuffer(b"".join(toks), dtype=np.uint8)
+    return vflat, voff, vlen, nw, cdf_w
 
 
-def enwik_synthetic(n, seed=20061, repeat_fraction=0.03):
+def enwik_synthetic(n, seed=20061, repeat_fraction=0.03, phrase_prob=0.4):
     """n bytes of enwik-like text (deterministic for a given (n, seed))."""
     rng = np.random.default_rng(seed)
-    vflat, voff, vlen = _vocab(rng, 50000)
-    nv = len(vlen)
-    p = 1.0 / (np.arange(nv) + 2.7) ** 1.07
-    cdf = np.cumsum(p / p.sum())
+    nphrases = 200_000
+    vflat, voff, vlen, nw, cdf_w = _vocab(rng, 50000, nphrases)
+    pp = 1.0 / (np.arange(nphrases) + 5.0) ** 0.9
+    cdf_p = np.cumsum(pp / pp.sum())
     out = np.empty(n, dtype=np.uint8)
     pos = 0
-    chunk_words = 600_000
+    chunk_toks = 400_000
     while pos < n:
-        ids = np.searchsorted(cdf, rng.random(chunk_words), side="right")
-        ids = np.minimum(ids, nv - 1)
+        u = rng.random(chunk_toks)
+        is_phrase = rng.random(chunk_toks) < phrase_prob
+        ids = np.where(is_phrase,
+                       nw + np.minimum(np.searchsorted(cdf_p, u, side="right"), nphrases - 1),
+                       np.minimum(np.searchsorted(cdf_w, u, side="right"), nw - 1))
         lens = vlen[ids]
         ends = np.cumsum(lens)
         total = int(ends[-1])
@@ -81,13 +98,17 @@ def enwik_synthetic(n, seed=20061, repeat_fraction=0.03):
         take = min(total, n - pos)
         out[pos:pos + take] = vflat[src[:take]]
         pos += take
-    # verbatim repeats: copy earlier passages forward (lengths log-uniform in 200 .. 60000)
+    # verbatim repeats: copy passages a short distance forward (lengths log-uniform in 200 .. 60000,
+    # distance log-uniform up to 600 kB so that most copies share a 900 kB block with their source,
+    # as templated / duplicated wiki passages do)
     budget = int(n * repeat_fraction)
     while budget > 0 and n > 200_000:
         ln = int(np.exp(rng.uniform(np.log(200), np.log(60000))))
-        src0 = int(rng.integers(0, n - ln - 1))
-        dst0 = int(rng.integers(0, n - ln - 1))
-        out[dst0:dst0 + ln] = out[src0:src0 + ln].copy()
+        dist = int(np.exp(rng.uniform(np.log(ln + 1), np.log(600_000))))
+        src0 = int(rng.integers(0, max(1, n - ln - dist - 1)))
+        dst0 = src0 + dist
+        if dst0 + ln <= n:
+            out[dst0:dst0 + ln] = out[src0:src0 + ln].copy()
         budget -= ln
     return out
 

@@ -79,6 +79,12 @@ static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
     carve(p, bt.tagg, NB * bt.TPB);
     carve(p, bt.nactA, NB);
     carve(p, bt.nactB, NB);
+    carve(p, bt.nactC, NB);
+    carve(p, bt.gateR, NB);
+    carve(p, bt.gateT, NB);
+    carve(p, bt.maxgrp, NB);
+    carve(p, bt.errflag, 64);
+    carve(p, bt.alive, NB * ((S + 2047) / 2048));
     carve(p, bt.mtfpos, NB * S);
     carve(p, bt.tilelist, NB * MT * 256);
     carve(p, bt.tinfo, NB * MT * 4);

@@ -5,78 +5,127 @@
 // between identical rotations broken by DESCENDING start index (lib/bwt.rs:564-573 sorts S||S);
 // ptr = k with sa_k = 0; has_byte[c] = c in S.
 //
-// Method: cyclic prefix doubling.  All bzip2 blocks of a batch are sorted at once
-// (blockIdx.y = bzip2 block).  An initial LSD radix sort on the 4-byte cyclic prefix gives
-// SA_4 / rank_4 (rank = first SA position of the suffix's group).  A doubling round with depth h
-// needs every unresolved group ordered by rank[i+h]; instead of sorting on that second key, the
-// unresolved suffixes are ENUMERATED in SA order of suffix i+h (one coalesced sweep of SA plus a
-// rank gather) and stably radix-sorted by their own group rank only (20 bits -> 3 passes of 7
-// bits).  Stability keeps the enumeration order inside each group, which is exactly the order by
-// rank[i+h].  Group boundaries are re-flagged, ranks refined, resolved suffixes drop out.
-// When h >= n the survivors are identical rotations: one last round enumerates them by
-// descending index (the reference's tie rule).
+// Method: cyclic prefix doubling, all bzip2 blocks of a batch at once.  Every sort element is one
+// 64-bit word
+//      init pass :  [ 4-byte cyclic prefix : 32 ][ 0 : 12 ][ suffix : 20 ]
+//      rounds    :  [ 0:4 ][ group rank r : 20 ][ key2 = rank[i+h] : 20 ][ suffix i : 20 ]
+// (n < 2^20 at every level).  rank = first SA position of the suffix's group, bit 31 = resolved.
+// Initial LSD radix sort on the prefix (4 passes x 8 bits).  A doubling round with depth h comes
+// in two forms, chosen per round from the unresolved fraction:
+//   SWEEP  (most suffixes unresolved): unresolved suffixes are ENUMERATED in SA order of suffix
+//          i+h (a coalesced sweep of SA + rank gathers) and stably sorted by r only -- 3 passes of
+//          7 bits; stability leaves every group in key2 order, key2 is carried only for flagging;
+//   ACTIVE (few unresolved): the previous round's sorted list is re-keyed and sorted on (r, key2)
+//          -- 5 passes of 8 bits over the unresolved suffixes only, nothing proportional to n.
+// Then boundary flags, max-scan of group heads, rank/SA update; resolved suffixes drop out.
+// When h >= n the survivors are identical rotations (block = w^k): key2 becomes n-1-i (ACTIVE) or
+// the enumeration runs over descending i (SWEEP), the reference's tie rule.
 //
-// Kernels (all integer, HBM/LDS bound, no MFMA):
-//   radix_hist     per-tile digit histogram in LDS            -> hist[b][digit][tile]
+// Launch geometry: workgroup ids are mapped so that all tiles of bzip2 block b run on XCD b mod 8
+// (wg_map), keeping the block's rank/SA arrays (3.6 MB each) inside one 4 MiB L2.
+// Kernels (integer only, HBM/LDS bound, no MFMA):
+//   radix_hist     per-tile digit histogram in LDS                -> hist[b][digit][tile]
 //   radix_scan     per-block exclusive scan of hist (1 workgroup per bzip2 block)
-//   radix_scatter  stable scatter: wave match-any ranking + per-wave LDS cursors
+//   radix_scatter  stable scatter: wave match-any ranking, per-wave LDS cursors, elements
+//                  reordered in LDS so each digit's run leaves the CU as coalesced stores
 //   flag_tiles / flag_carry / refine   boundary flags, max-scan of group heads, rank + SA update
+//                  (tiles staged through LDS: coalesced global access, blocked per-thread scans)
 //   bwt_emit       last column, ptr, has_byte
+#include <vector>
+
 #include "common.h"
 
+typedef unsigned long long u64;
+
 enum GenMode : int {
-    GEN_BYTES4 = 0, // element e is suffix e, key = 4-byte big-endian cyclic prefix
-    GEN_ROUND = 1,  // doubling round: SA-order (h < n) or descending-index (h >= n) enumeration
-    GEN_LIST = 2    // element e is src[e]
+    GEN_BYTES4 = 0, // element e is suffix e keyed by its 4-byte cyclic prefix
+    GEN_SWEEP = 1,  // doubling round, SA-order enumeration
+    GEN_ACTIVE = 2, // doubling round, re-key the previous sorted list
+    GEN_LIST = 3    // element e is src[e]
 };
 
+constexpr u64 SUF_MASK = 0xFFFFFull;
+constexpr uint32_t RANK_MASK = 0x7FFFFFFFu;
+
 struct SortArgs {
-    const uint8_t *blk;    // [B][S]
-    const uint32_t *n;     // [B]
-    const uint32_t *cnt;   // [B] elements enumerated this pass
-    const uint32_t *gate;  // [B] skip block when 0
-    const uint32_t *rank;  // [B][S]
-    const uint32_t *sa;    // [B][S]
-    const uint2 *src;      // [B][S]
-    uint2 *dst;            // [B][S]
-    uint32_t *hist;        // [B][NBMAX*TPB]
+    const uint8_t *blk;   // [B][S]
+    const uint32_t *n;    // [B]
+    const uint32_t *cnt;  // [B] elements enumerated this pass
+    const uint32_t *gate; // [B] skip block when 0
+    const uint32_t *rank; // [B][S]
+    const uint32_t *sa;   // [B][S]
+    const u64 *src;       // [B][S]
+    u64 *dst;             // [B][S]
+    uint32_t *hist;       // [B][NBMAX*TPB]
     uint32_t S, TPB, h, shift;
+    uint32_t T, B; // launch geometry: tiles per block in this launch, blocks
 };
 
 constexpr int NBMAX = 256;
 
-template <int MODE>
-__device__ __forceinline__ bool gen_elem(const SortArgs &a, uint32_t b, uint32_t e, uint32_t n, uint32_t &key,
-                                         uint32_t &val)
+// XCD-aware workgroup -> (bzip2 block, tile) map.  Workgroups are dealt round-robin over the 8
+// XCDs (observed dispatch behaviour, used for speed only): ids congruent mod 8 share an XCD and
+// its private 4 MiB L2.  All tiles of block b get ids = b (mod 8).  Grid = 8*ceil(B/8)*T.
+__device__ __forceinline__ bool wg_map(uint32_t T, uint32_t B, uint32_t &b, uint32_t &tile)
+{
+    const uint32_t L = blockIdx.x;
+    const uint32_t slot = L >> 3;
+    const uint32_t k = slot / T;
+    tile = slot - k * T;
+    b = k * 8u + (L & 7u);
+    return b < B;
+}
+
+static inline uint32_t xcd_grid(uint32_t tiles, uint32_t B) { return 8u * ((B + 7u) / 8u) * tiles; }
+
+// WANT_K2 = false for histogram passes that only look at the r digits.
+template <int MODE, bool WANT_K2>
+__device__ __forceinline__ bool gen_elem(const SortArgs &a, uint32_t b, uint32_t e, uint32_t n, u64 &v)
 {
     const size_t base = (size_t)b * a.S;
     if (MODE == GEN_BYTES4) {
         const uint8_t *s = a.blk + base;
-        uint32_t i0 = e, i1 = e + 1, i2 = e + 2, i3 = e + 3;
+        uint32_t i1 = e + 1, i2 = e + 2, i3 = e + 3;
         if (i3 >= n) { // cyclic wrap (n may be smaller than 4)
             i1 %= n;
             i2 %= n;
             i3 %= n;
         }
-        key = ((uint32_t)s[i0] << 24) | ((uint32_t)s[i1] << 16) | ((uint32_t)s[i2] << 8) | (uint32_t)s[i3];
-        val = e;
+        const uint32_t key = ((uint32_t)s[e] << 24) | ((uint32_t)s[i1] << 16) | ((uint32_t)s[i2] << 8) | (uint32_t)s[i3];
+        v = ((u64)key << 32) | e;
         return true;
-    } else if (MODE == GEN_ROUND) {
-        uint32_t i;
-        if (a.h < n) { // suffix j = sa[e] is the e-th smallest; i = j - h sees it as its second half
-            uint32_t j = a.sa[base + e];
+    } else if (MODE == GEN_SWEEP) {
+        uint32_t i, k2;
+        if (a.h < n) { // suffix j = sa[e] is the e-th smallest; i = j - h has it as its second half
+            const uint32_t j = a.sa[base + e];
             i = j >= a.h ? j - a.h : j + n - a.h;
-        } else { // identical rotations: larger index first
-            i = n - 1 - e;
+            const uint32_t r = a.rank[base + i];
+            if (r & RANK_RESOLVED) return false;
+            k2 = WANT_K2 ? (a.rank[base + j] & RANK_MASK) : 0u;
+            v = ((u64)r << 40) | ((u64)k2 << 20) | i;
+            return true;
         }
-        uint32_t r = a.rank[base + i];
-        key = r;
-        val = i;
-        return (r & RANK_RESOLVED) == 0;
+        i = n - 1 - e; // identical rotations: larger index first; e doubles as a distinct key2
+        const uint32_t r = a.rank[base + i];
+        if (r & RANK_RESOLVED) return false;
+        v = ((u64)r << 40) | ((u64)e << 20) | i;
+        return true;
+    } else if (MODE == GEN_ACTIVE) {
+        const uint32_t i = (uint32_t)(a.src[base + e] & SUF_MASK);
+        const uint32_t r = a.rank[base + i];
+        if (r & RANK_RESOLVED) return false;
+        uint32_t k2;
+        if (a.h < n) {
+            uint32_t i2 = i + a.h;
+            if (i2 >= n) i2 -= n;
+            k2 = a.rank[base + i2] & RANK_MASK;
+        } else {
+            k2 = n - 1 - i;
+        }
+        v = ((u64)r << 40) | ((u64)k2 << 20) | i;
+        return true;
     } else {
-        uint2 kv = a.src[base + e];
-        key = kv.x;
-        val = kv.y;
+        v = a.src[base + e];
         return true;
     }
 }
@@ -85,7 +134,8 @@ template <int BITS, int MODE>
 __global__ void __launch_bounds__(SORT_THREADS) radix_hist(SortArgs a)
 {
     constexpr int NB = 1 << BITS;
-    const uint32_t b = blockIdx.y, tile = blockIdx.x;
+    uint32_t b, tile;
+    if (!wg_map(a.T, a.B, b, tile)) return;
     if (a.gate[b] == 0) return;
     const uint32_t cnt = a.cnt[b], n = a.n[b];
     const uint32_t ntile = (cnt + SORT_TILE - 1) / SORT_TILE;
@@ -95,10 +145,11 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_hist(SortArgs a)
     __syncthreads();
 #pragma unroll 4
     for (int k = 0; k < SORT_ITEMS; k++) {
-        uint32_t e = tile * SORT_TILE + k * SORT_THREADS + threadIdx.x;
+        const uint32_t e = tile * SORT_TILE + k * SORT_THREADS + threadIdx.x;
         if (e < cnt) {
-            uint32_t key, val;
-            if (gen_elem<MODE>(a, b, e, n, key, val)) atomicAdd(&h[(key >> a.shift) & (NB - 1)], 1u);
+            u64 v;
+            // in ACTIVE mode the first digit lies in key2, so it must be generated
+            if (gen_elem<MODE, MODE == GEN_ACTIVE>(a, b, e, n, v)) atomicAdd(&h[(uint32_t)(v >> a.shift) & (NB - 1)], 1u);
         }
     }
     __syncthreads();
@@ -120,15 +171,15 @@ __global__ void __launch_bounds__(1024) radix_scan(SortArgs a)
     __shared__ uint32_t lds[20];
     uint32_t carry = 0;
     for (uint32_t base = 0; base < total; base += 1024) {
-        uint32_t e = base + threadIdx.x;
+        const uint32_t e = base + threadIdx.x;
         uint32_t addr = 0, v = 0;
         if (e < total) {
-            uint32_t bin = e / ntile, t = e - bin * ntile;
+            const uint32_t bin = e / ntile, t = e - bin * ntile;
             addr = bin * a.TPB + t;
             v = hist[addr];
         }
         uint32_t tot;
-        uint32_t ex = block_excl_add(v, lds, &tot);
+        const uint32_t ex = block_excl_add(v, lds, &tot);
         if (e < total) hist[addr] = carry + ex;
         carry += tot;
     }
@@ -139,139 +190,163 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
 {
     constexpr int NB = 1 << BITS;
     constexpr int NW = SORT_THREADS / 64;
-    const uint32_t b = blockIdx.y, tile = blockIdx.x;
+    uint32_t b, tile;
+    if (!wg_map(a.T, a.B, b, tile)) return;
     if (a.gate[b] == 0) return;
     const uint32_t cnt = a.cnt[b], n = a.n[b];
     const uint32_t ntile = (cnt + SORT_TILE - 1) / SORT_TILE;
     if (tile >= ntile) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    __shared__ uint32_t cur[NW][NB]; // per-wave write cursors
+    __shared__ uint32_t cur[NW][NB];  // per-wave cursors (tile-local positions)
+    __shared__ uint32_t binstart[NB]; // tile-local start of each digit's run
+    __shared__ uint32_t goff[NB];     // global offset of this tile's run of each digit
+    __shared__ u64 stage[SORT_TILE];  // tile in digit order
+    __shared__ uint32_t ls[NW + 2];
     for (int k = threadIdx.x; k < NW * NB; k += SORT_THREADS) (&cur[0][0])[k] = 0;
 
     // wave w owns the contiguous run [w*ITEMS*64, (w+1)*ITEMS*64) of the tile, 64 elements a step
-    uint32_t key[SORT_ITEMS], val[SORT_ITEMS];
+    u64 v[SORT_ITEMS];
     uint32_t actmask = 0;
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; k++) {
-        uint32_t e = tile * SORT_TILE + wave * (SORT_ITEMS * 64) + k * 64 + lane;
-        key[k] = 0;
-        val[k] = 0;
-        if (e < cnt && gen_elem<MODE>(a, b, e, n, key[k], val[k])) actmask |= 1u << k;
+        const uint32_t e = tile * SORT_TILE + wave * (SORT_ITEMS * 64) + k * 64 + lane;
+        v[k] = 0;
+        if (e < cnt && gen_elem<MODE, true>(a, b, e, n, v[k])) actmask |= 1u << k;
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; k++)
-        if (actmask & (1u << k)) atomicAdd(&cur[wave][(key[k] >> a.shift) & (NB - 1)], 1u);
+        if (actmask & (1u << k)) atomicAdd(&cur[wave][(uint32_t)(v[k] >> a.shift) & (NB - 1)], 1u);
     __syncthreads();
-    {
-        const uint32_t *hist = a.hist + (size_t)b * NBMAX * a.TPB;
-        for (int bin = threadIdx.x; bin < NB; bin += SORT_THREADS) {
-            uint32_t g = hist[(size_t)bin * a.TPB + tile];
+    // digit totals -> tile-local exclusive starts; cursors = start + counts of earlier waves
+    uint32_t mytot = 0;
+    if (threadIdx.x < NB) {
 #pragma unroll
-            for (int w = 0; w < NW; w++) {
-                uint32_t t = cur[w][bin];
-                cur[w][bin] = g;
-                g += t;
-            }
+        for (int w = 0; w < NW; w++) mytot += cur[w][threadIdx.x];
+    }
+    uint32_t tile_total;
+    const uint32_t ex = block_excl_add(mytot, ls, &tile_total);
+    if (threadIdx.x < NB) {
+        const uint32_t bin = threadIdx.x;
+        binstart[bin] = ex;
+        goff[bin] = a.hist[(size_t)b * NBMAX * a.TPB + (size_t)bin * a.TPB + tile];
+        uint32_t g = ex;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const uint32_t t = cur[w][bin];
+            cur[w][bin] = g;
+            g += t;
         }
     }
     __syncthreads();
-    uint2 *dst = a.dst + (size_t)b * a.S;
     volatile uint32_t *mycur = cur[wave];
-    const uint64_t lt = (1ull << lane) - 1ull;
+    const u64 lt = (1ull << lane) - 1ull;
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; k++) {
         const bool act = (actmask >> k) & 1u;
-        const uint32_t d = (key[k] >> a.shift) & (NB - 1);
-        uint64_t m = __ballot(act);
+        const uint32_t d = (uint32_t)(v[k] >> a.shift) & (NB - 1);
+        u64 m = __ballot(act);
 #pragma unroll
         for (int bit = 0; bit < BITS; bit++) {
             const bool one = (d >> bit) & 1u;
-            const uint64_t bm = __ballot(act && one);
+            const u64 bm = __ballot(act && one);
             m &= one ? bm : ~bm;
         }
         if (act) {
             const uint32_t basepos = mycur[d];
             const uint32_t off = __popcll(m & lt);
             if (off == 0) mycur[d] = basepos + __popcll(m); // lowest lane of the digit group advances
-            dst[basepos + off] = make_uint2(key[k], val[k]);
+            stage[basepos + off] = v[k];
         }
+    }
+    __syncthreads();
+    u64 *dst = a.dst + (size_t)b * a.S;
+    for (uint32_t e = threadIdx.x; e < tile_total; e += SORT_THREADS) {
+        const u64 x = stage[e];
+        const uint32_t d = (uint32_t)(x >> a.shift) & (NB - 1);
+        dst[goff[d] + (e - binstart[d])] = x;
     }
 }
 
 // ---- group refinement ---------------------------------------------------------------------------
 struct RefineArgs {
-    const uint32_t *n;    // [B]
-    const uint32_t *cnt;  // [B] list length (n for the init pass, active count in rounds)
-    const uint2 *list;    // [B][S] sorted (group rank | key, suffix)
-    uint32_t *rank;       // [B][S]
-    uint32_t *sa;         // [B][S]
-    uint8_t *flg;         // [B][S]
-    int2 *tagg;           // [B][TPB]
-    uint32_t *nact_next;  // [B]
-    uint32_t S, TPB, h;
+    const uint32_t *n;   // [B]
+    const uint32_t *cnt; // [B] list length (n for the init pass, unresolved count in rounds)
+    const u64 *list;     // [B][S] sorted elements
+    uint32_t *rank;      // [B][S]
+    uint32_t *sa;        // [B][S]
+    uint8_t *flg;        // [B][S]
+    int2 *tagg;          // [B][TPB]
+    uint32_t *nact_next; // [B]
+    uint32_t *maxgrp;    // [B] largest refined group (members), atomicMax
+    const uint32_t *gate; // [B] skip block when 0 (nullptr = no gating)
+    uint32_t S, TPB;
     int init;
+    uint32_t T, B;
 };
+
+// LDS staging of one tile: coalesced global loads, then each thread owns 16 consecutive elements.
+// Element e lives at slot e + (e >> 4): the +1 per 16 keeps the blocked ds_read_b64 conflict free.
+constexpr int STAGE_SLOTS = SORT_TILE + SORT_TILE / 16;
+__device__ __forceinline__ uint32_t slot_of(uint32_t e) { return e + (e >> 4); }
+
+__device__ __forceinline__ void stage_tile(const u64 *list, uint32_t tile0, uint32_t cnt, u64 *lds)
+{
+#pragma unroll
+    for (int k = 0; k < SORT_ITEMS; k++) {
+        const uint32_t e = k * SORT_THREADS + threadIdx.x;
+        const uint32_t q = tile0 + e;
+        lds[slot_of(e)] = q < cnt ? list[q] : 0ull;
+    }
+}
+
+__device__ __forceinline__ void elem_flags(const RefineArgs &a, uint32_t q, u64 cur, u64 prev, bool &gs, bool &bd)
+{
+    if (a.init) {
+        gs = (q == 0);
+        bd = gs || (cur >> 32) != (prev >> 32);
+    } else {
+        gs = (q == 0) || (cur >> 40) != (prev >> 40);
+        bd = gs || (cur >> 20) != (prev >> 20);
+    }
+}
 
 // flag bit0: first element of its (old) group; bit1: first element of its refined group
 __global__ void __launch_bounds__(SORT_THREADS) flag_tiles(RefineArgs a)
 {
-    const uint32_t b = blockIdx.y, tile = blockIdx.x;
-    const uint32_t cnt = a.cnt[b], n = a.n[b];
+    uint32_t b, tile;
+    if (!wg_map(a.T, a.B, b, tile)) return;
+    if (a.gate && a.gate[b] == 0) return;
+    const uint32_t cnt = a.cnt[b];
     const uint32_t ntile = (cnt + SORT_TILE - 1) / SORT_TILE;
     if (tile >= ntile) return;
     const size_t base = (size_t)b * a.S;
-    const uint2 *list = a.list + base;
-    const uint32_t *rank = a.rank + base;
-    const bool desc = !a.init && a.h >= n;
-    const uint32_t q0 = tile * SORT_TILE + threadIdx.x * SORT_ITEMS;
-
+    const u64 *list = a.list + base;
+    const uint32_t tile0 = tile * SORT_TILE;
+    __shared__ u64 lds[STAGE_SLOTS];
+    stage_tile(list, tile0, cnt, lds);
+    __syncthreads();
+    const uint32_t e0 = threadIdx.x * SORT_ITEMS, q0 = tile0 + e0;
     uint32_t packed[SORT_ITEMS / 4] = {0, 0, 0, 0};
     int lastgs = -1, lastbd = -1;
     if (q0 < cnt) {
-        uint2 prev = make_uint2(0, 0);
-        uint32_t prevk2 = 0;
-        if (q0 > 0) {
-            prev = list[q0 - 1];
-            if (!a.init && !desc) {
-                uint32_t i2 = prev.y + a.h;
-                if (i2 >= n) i2 -= n;
-                prevk2 = rank[i2] & ~RANK_RESOLVED;
-            }
-        }
+        u64 prev = e0 ? lds[slot_of(e0 - 1)] : (q0 ? list[q0 - 1] : 0ull);
 #pragma unroll
         for (int k = 0; k < SORT_ITEMS; k++) {
             const uint32_t q = q0 + k;
             if (q < cnt) {
-                const uint2 cur = list[q];
-                uint32_t k2 = 0;
+                const u64 cur = lds[slot_of(e0 + k)];
                 bool gs, bd;
-                if (a.init) {
-                    gs = (q == 0);
-                    bd = gs || cur.x != prev.x;
-                } else {
-                    gs = (q == 0) || cur.x != prev.x;
-                    if (desc) {
-                        bd = true;
-                    } else {
-                        uint32_t i2 = cur.y + a.h;
-                        if (i2 >= n) i2 -= n;
-                        k2 = rank[i2] & ~RANK_RESOLVED;
-                        bd = gs || k2 != prevk2;
-                    }
-                }
+                elem_flags(a, q, cur, prev, gs, bd);
                 if (gs) lastgs = (int)q;
                 if (bd) lastbd = (int)q;
                 packed[k >> 2] |= ((gs ? 1u : 0u) | (bd ? 2u : 0u)) << ((k & 3) * 8);
                 prev = cur;
-                prevk2 = k2;
             }
         }
-        uint8_t *f = a.flg + base + q0; // q0 is a multiple of 16 and S a multiple of 4096
-        *reinterpret_cast<uint4 *>(f) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+        *reinterpret_cast<uint4 *>(a.flg + base + q0) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
     }
-    // tile aggregate: max over threads
     __shared__ int red[2][SORT_THREADS / 64];
     int g = lastgs, d = lastbd;
 #pragma unroll
@@ -298,6 +373,7 @@ __global__ void __launch_bounds__(SORT_THREADS) flag_tiles(RefineArgs a)
 __global__ void __launch_bounds__(1024) flag_carry(RefineArgs a)
 {
     const uint32_t b = blockIdx.x;
+    if (a.gate && a.gate[b] == 0) return;
     const uint32_t cnt = a.cnt[b];
     const uint32_t ntile = (cnt + SORT_TILE - 1) / SORT_TILE;
     if (ntile == 0) return;
@@ -305,7 +381,7 @@ __global__ void __launch_bounds__(1024) flag_carry(RefineArgs a)
     __shared__ int l0[16], l1[16];
     __shared__ int inc0[1024], inc1[1024];
     const uint32_t e = threadIdx.x;
-    int2 v = e < ntile ? t[e] : make_int2(-1, -1);
+    const int2 v = e < ntile ? t[e] : make_int2(-1, -1);
     inc0[e] = block_incl_max(v.x, l0);
     inc1[e] = block_incl_max(v.y, l1);
     __syncthreads();
@@ -314,79 +390,335 @@ __global__ void __launch_bounds__(1024) flag_carry(RefineArgs a)
 
 __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
 {
-    const uint32_t b = blockIdx.y, tile = blockIdx.x;
+    uint32_t b, tile;
+    if (!wg_map(a.T, a.B, b, tile)) return;
+    if (a.gate && a.gate[b] == 0) return;
     const uint32_t cnt = a.cnt[b];
     const uint32_t ntile = (cnt + SORT_TILE - 1) / SORT_TILE;
     if (tile >= ntile) return;
     const size_t base = (size_t)b * a.S;
-    const uint2 *list = a.list + base;
-    const uint32_t q0 = tile * SORT_TILE + threadIdx.x * SORT_ITEMS;
+    const uint32_t tile0 = tile * SORT_TILE;
+    __shared__ u64 lds[STAGE_SLOTS];
+    stage_tile(a.list + base, tile0, cnt, lds);
+    const uint32_t e0 = threadIdx.x * SORT_ITEMS, q0 = tile0 + e0;
 
     uint32_t packed[4] = {0, 0, 0, 0};
     uint32_t nextflag = 2; // flag of element q0+16 (end of list counts as a boundary)
     if (q0 < cnt) {
-        uint4 v = *reinterpret_cast<const uint4 *>(a.flg + base + q0);
-        packed[0] = v.x;
-        packed[1] = v.y;
-        packed[2] = v.z;
-        packed[3] = v.w;
+        const uint4 f = *reinterpret_cast<const uint4 *>(a.flg + base + q0);
+        packed[0] = f.x;
+        packed[1] = f.y;
+        packed[2] = f.z;
+        packed[3] = f.w;
         if (q0 + SORT_ITEMS < cnt) nextflag = a.flg[base + q0 + SORT_ITEMS];
     }
-    // per-thread last flagged index, then workgroup inclusive max-scan -> carry for each thread
     int tg = -1, td = -1;
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; k++) {
-        uint32_t f = (packed[k >> 2] >> ((k & 3) * 8)) & 3u;
+        const uint32_t f = (packed[k >> 2] >> ((k & 3) * 8)) & 3u;
         if (q0 + k < cnt) {
             if (f & 1u) tg = (int)(q0 + k);
             if (f & 2u) td = (int)(q0 + k);
         }
     }
     __shared__ int l0[SORT_THREADS / 64], l1[SORT_THREADS / 64];
-    int ig = block_incl_max(tg, l0);
-    int id = block_incl_max(td, l1);
-    // exclusive carry = inclusive value of the previous thread (or the tile carry)
     __shared__ int ex0[SORT_THREADS], ex1[SORT_THREADS];
-    ex0[threadIdx.x] = ig;
-    ex1[threadIdx.x] = id;
-    __syncthreads();
+    ex0[threadIdx.x] = block_incl_max(tg, l0);
+    ex1[threadIdx.x] = block_incl_max(td, l1);
+    __syncthreads(); // also orders stage_tile's stores before the blocked reads below
     const int2 tc = a.tagg[(size_t)b * a.TPB + tile];
     int cg = tc.x, cd = tc.y;
     if (threadIdx.x > 0) {
         cg = max(cg, ex0[threadIdx.x - 1]);
         cd = max(cd, ex1[threadIdx.x - 1]);
     }
-    if (q0 >= cnt) return;
-
     uint32_t *rank = a.rank + base;
     uint32_t *sa = a.sa + base;
-    uint32_t unresolved = 0;
+    uint32_t unresolved = 0, biggest = 0;
+    u64 outv[SORT_ITEMS]; // (SA position << 32 | suffix) per element, all ones = none
+#pragma unroll
+    for (int k = 0; k < SORT_ITEMS; k++) outv[k] = ~0ull;
+    if (q0 < cnt) {
+#pragma unroll
+        for (int k = 0; k < SORT_ITEMS; k++) {
+            const uint32_t q = q0 + k;
+            if (q < cnt) {
+                const uint32_t f = (packed[k >> 2] >> ((k & 3) * 8)) & 3u;
+                const uint32_t fn = (k + 1 < SORT_ITEMS) ? ((packed[(k + 1) >> 2] >> (((k + 1) & 3) * 8)) & 3u) : nextflag;
+                if (f & 1u) cg = (int)q;
+                if (f & 2u) cd = (int)q;
+                const u64 cur = lds[slot_of(e0 + k)];
+                const uint32_t i = (uint32_t)(cur & SUF_MASK);
+                // SA position of the group's first list entry, minus that entry's list index
+                const uint32_t gbase = a.init ? 0u : ((uint32_t)(cur >> 40) - (uint32_t)cg);
+                const uint32_t pos = gbase + q;
+                const uint32_t head = gbase + (uint32_t)cd;
+                const bool single = (f & 2u) && ((q + 1 == cnt) || (fn & 2u));
+                rank[i] = single ? (head | RANK_RESOLVED) : head;
+                outv[k] = ((u64)pos << 32) | i;
+                unresolved += single ? 0u : 1u;
+                if ((q + 1 == cnt) || (fn & 2u)) biggest = max(biggest, q - (uint32_t)cd + 1u); // last of its group
+            }
+        }
+    }
+    // SA update through LDS so that consecutive lanes store consecutive positions
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SORT_ITEMS; k++) lds[slot_of(e0 + k)] = outv[k];
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; k++) {
-        const uint32_t q = q0 + k;
-        if (q < cnt) {
-            const uint32_t f = (packed[k >> 2] >> ((k & 3) * 8)) & 3u;
-            const uint32_t fn = (k + 1 < SORT_ITEMS) ? ((packed[(k + 1) >> 2] >> (((k + 1) & 3) * 8)) & 3u) : nextflag;
-            if (f & 1u) cg = (int)q;
-            if (f & 2u) cd = (int)q;
-            const uint2 cur = list[q];
-            const uint32_t gbase = a.init ? 0u : (cur.x - (uint32_t)cg); // SA position of list entry 0 of the group, minus its list index
-            const uint32_t pos = gbase + q;
-            const uint32_t head = gbase + (uint32_t)cd;
-            const bool single = (f & 2u) && ((q + 1 == cnt) || (fn & 2u));
-            rank[cur.y] = single ? (head | RANK_RESOLVED) : head;
-            sa[pos] = cur.y;
+        const u64 x = lds[slot_of(k * SORT_THREADS + threadIdx.x)];
+        if (x != ~0ull) sa[(uint32_t)(x >> 32)] = (uint32_t)x;
+    }
+    unresolved = wave_reduce_add(unresolved);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) biggest = max(biggest, (uint32_t)__shfl_xor((int)biggest, d, 64));
+    if ((threadIdx.x & 63) == 0 && unresolved) {
+        atomicAdd(&a.nact_next[b], unresolved);
+        atomicMax(&a.maxgrp[b], biggest);
+    }
+}
+
+// ---- TAIL rounds: every group small -> sort groups locally, 4 small launches per round -------------
+// Precondition (tracked by refine's maxgrp): every unresolved group of the block has at most TAIL_G
+// members.  The block's unresolved suffixes sit, grouped and in SA order, in `len` slots of one list
+// buffer.  tail_sort: a workgroup owns the groups whose first member lies in its range of TAIL_T
+// slots and sees TAIL_G slots either side, so every owned group is complete in its window; it ranks
+// the members of each group by key2 and writes a record into the slot of the u-th member (in
+// place).  A neighbour may be rewriting the slots of ITS groups while this workgroup reads them:
+// it then sees a permutation of the same group's members (8-byte stores are single transactions)
+// and reaches the same ownership verdict.  tail_sort reads only OLD ranks; tail_apply stores the new
+// ranks / SA entries (the kernel boundary keeps rank reads consistent) and counts survivors per
+// tile; tail_scan + tail_compact move the still-unresolved records, order preserved, to the other
+// buffer, so the next round touches only what is left.
+constexpr int TAIL_T = 2048, TAIL_G = 256, TAIL_W = TAIL_T + 2 * TAIL_G, TAIL_THREADS = 256;
+constexpr int TAIL_PER = TAIL_W / TAIL_THREADS; // 10 slots per thread
+constexpr u64 LIST_INVALID = ~0ull;
+constexpr uint32_t NONE32 = 0xFFFFFFFFu;
+constexpr uint32_t TAIL_BUF_B = 0x80000000u; // gateT bit: the block's list lives in listB
+constexpr uint32_t TAIL_RECS = 0x40000000u;  // gateT bit: slots hold records of the previous tail round
+constexpr uint32_t TAIL_LEN = 0x3FFFFFFFu;
+
+struct TailArgs {
+    const uint32_t *n;   // [B]
+    const uint32_t *len; // [B] slot count | TAIL_BUF_B, 0 = block not in tail mode this round
+    u64 *bufA, *bufB;    // [B][S]
+    uint32_t *rank;      // [B][S]
+    uint32_t *sa;        // [B][S]
+    uint32_t *nact_next; // [B]
+    uint32_t *tcount;    // [B][TT] survivors per tile, then their exclusive scan
+    uint32_t *err;       // [1] precondition violations
+    uint32_t S, h, T, B, TT;
+};
+
+// record: [resolved:1 @60][new rank:20 @40][SA position:20 @20][suffix:20 @0]
+__global__ void __launch_bounds__(TAIL_THREADS) tail_sort(TailArgs a)
+{
+    uint32_t b, tile;
+    if (!wg_map(a.T, a.B, b, tile)) return;
+    const uint32_t lenw = a.len[b];
+    const uint32_t len = lenw & TAIL_LEN;
+    const uint32_t r0 = tile * TAIL_T;
+    if (r0 >= len) return;
+    const uint32_t r1 = min(len, r0 + (uint32_t)TAIL_T);
+    const uint32_t s_lo = r0 >= (uint32_t)TAIL_G ? r0 - TAIL_G : 0u;
+    const uint32_t s_hi = min(len, r1 + (uint32_t)TAIL_G);
+    const uint32_t nwin = s_hi - s_lo;
+    const uint32_t n = a.n[b];
+    const size_t base = (size_t)b * a.S;
+    u64 *buf = ((lenw & TAIL_BUF_B) ? a.bufB : a.bufA) + base;
+    const uint32_t *rank = a.rank + base;
+    __shared__ uint32_t A0[TAIL_W], A1[TAIL_W], A2[TAIL_W], A3[TAIL_W];
+    __shared__ uint32_t ls[TAIL_THREADS / 64 + 2];
+
+    // load by slot (coalesced); already-resolved suffixes (first tail round only) drop out
+#pragma unroll
+    for (int k = 0; k < TAIL_PER; k++) {
+        const uint32_t w = k * TAIL_THREADS + threadIdx.x;
+        uint32_t r = NONE32, i = 0;
+        if (w < nwin) {
+            const uint32_t sl = s_lo + w;
+            const u64 x = buf[sl];
+            if (x != LIST_INVALID) {
+                i = (uint32_t)(x & SUF_MASK);
+                if (lenw & TAIL_RECS) {
+                    r = (uint32_t)(x >> 40) & 0xFFFFFu; // compacted survivors carry their current rank
+                } else {
+                    const uint32_t rr = rank[i];
+                    if (!(rr & RANK_RESOLVED))
+                        r = rr;
+                    else if (sl >= r0 && sl < r1)
+                        buf[sl] = LIST_INVALID; // resolved before: a hole for tail_apply / tail_compact
+                }
+            }
+        }
+        A0[w] = r;
+        A1[w] = i;
+    }
+    __syncthreads();
+    // order-preserving compaction: thread owns TAIL_PER consecutive slots
+    const uint32_t w0 = threadIdx.x * TAIL_PER;
+    uint32_t rr[TAIL_PER], ii[TAIL_PER], cnt = 0;
+#pragma unroll
+    for (int k = 0; k < TAIL_PER; k++) {
+        rr[k] = A0[w0 + k];
+        ii[k] = A1[w0 + k];
+        cnt += rr[k] != NONE32;
+    }
+    uint32_t V;
+    uint32_t idx = block_excl_add(cnt, ls, &V);
+#pragma unroll
+    for (int k = 0; k < TAIL_PER; k++) {
+        if (rr[k] != NONE32) {
+            A0[idx] = rr[k];         // group rank
+            A1[idx] = ii[k];         // suffix
+            A2[idx] = s_lo + w0 + k; // slot
+            idx++;
+        }
+    }
+    __syncthreads();
+    // group start of every compacted element, ownership, key2 of owned elements
+    uint32_t gstart[TAIL_PER];
+    uint32_t owned = 0;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < TAIL_PER; k++) {
+        const uint32_t e = k * TAIL_THREADS + threadIdx.x;
+        gstart[k] = 0;
+        if (e < V) {
+            const uint32_t r = A0[e];
+            uint32_t g = e;
+            while (g > 0 && A0[g - 1] == r) g--;
+            gstart[k] = g;
+            const uint32_t fs = A2[g];
+            if (fs >= r0 && fs < r1) {
+                owned |= 1u << k;
+                if (A2[e] - fs >= (uint32_t)TAIL_G) bad = true; // span beyond the window guarantee
+                const uint32_t i = A1[e];
+                uint32_t k2;
+                if (a.h < n) {
+                    uint32_t i2 = i + a.h;
+                    if (i2 >= n) i2 -= n;
+                    k2 = rank[i2] & RANK_MASK;
+                } else {
+                    k2 = n - 1 - i; // identical rotations: larger index first
+                }
+                A3[e] = k2;
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t unresolved = 0;
+#pragma unroll
+    for (int k = 0; k < TAIL_PER; k++) {
+        const uint32_t e = k * TAIL_THREADS + threadIdx.x;
+        if (e < V && (owned & (1u << k))) {
+            const uint32_t r = A0[e], g = gstart[k], mykey = A3[e];
+            uint32_t less = 0, eq_before = 0, eq = 0;
+            for (uint32_t f = g; f < V && A0[f] == r; f++) {
+                const uint32_t kf = A3[f];
+                less += kf < mykey;
+                eq += kf == mykey;
+                eq_before += (kf == mykey) && (f < e);
+            }
+            const uint32_t u = less + eq_before;
+            const bool single = eq == 1;
             unresolved += single ? 0u : 1u;
+            const u64 rec = ((u64)(single ? 1u : 0u) << 60) | ((u64)(r + less) << 40) | ((u64)(r + u) << 20) | A1[e];
+            buf[A2[g + u]] = rec; // the u-th smallest member takes the slot of the u-th member
         }
     }
     unresolved = wave_reduce_add(unresolved);
     if ((threadIdx.x & 63) == 0 && unresolved) atomicAdd(&a.nact_next[b], unresolved);
+    if (bad) atomicOr(a.err, 1u);
+}
+
+// Applies the records of a tile and counts its survivors (records still unresolved).
+__global__ void __launch_bounds__(256) tail_apply(TailArgs a)
+{
+    uint32_t b, tile;
+    if (!wg_map(a.T, a.B, b, tile)) return;
+    const uint32_t lenw = a.len[b];
+    const uint32_t len = lenw & TAIL_LEN;
+    const uint32_t r0 = tile * TAIL_T;
+    if (r0 >= len) return;
+    const size_t base = (size_t)b * a.S;
+    const u64 *rec = ((lenw & TAIL_BUF_B) ? a.bufB : a.bufA) + base;
+    uint32_t *rank = a.rank + base;
+    uint32_t *sa = a.sa + base;
+    uint32_t alive = 0;
+#pragma unroll
+    for (int k = 0; k < TAIL_T / 256; k++) {
+        const uint32_t sl = r0 + k * 256 + threadIdx.x;
+        if (sl < len) {
+            const u64 x = rec[sl];
+            if (x != LIST_INVALID) {
+                const uint32_t i = (uint32_t)(x & SUF_MASK);
+                const uint32_t nr = (uint32_t)(x >> 40) & 0xFFFFFu;
+                const bool res = (x >> 60) & 1ull;
+                rank[i] = res ? (nr | RANK_RESOLVED) : nr;
+                sa[(uint32_t)(x >> 20) & 0xFFFFFu] = i;
+                alive += res ? 0u : 1u;
+            }
+        }
+    }
+    __shared__ uint32_t ls[256 / 64 + 2];
+    uint32_t tot;
+    (void)block_excl_add(alive, ls, &tot);
+    if (threadIdx.x == 0) a.tcount[(size_t)b * a.TT + tile] = tot;
+}
+
+// One workgroup per block: exclusive scan of the per-tile survivor counts (TT <= 512).
+__global__ void __launch_bounds__(512) tail_scan(TailArgs a)
+{
+    const uint32_t b = blockIdx.x;
+    const uint32_t len = a.len[b] & TAIL_LEN;
+    if (len == 0) return;
+    const uint32_t ntile = (len + TAIL_T - 1) / TAIL_T;
+    uint32_t *tc = a.tcount + (size_t)b * a.TT;
+    __shared__ uint32_t ls[512 / 64 + 2];
+    const uint32_t v = threadIdx.x < ntile ? tc[threadIdx.x] : 0;
+    uint32_t tot;
+    const uint32_t ex = block_excl_add(v, ls, &tot);
+    if (threadIdx.x < ntile) tc[threadIdx.x] = ex;
+}
+
+// Moves the surviving records of a tile to the other buffer, order preserved.
+__global__ void __launch_bounds__(256) tail_compact(TailArgs a)
+{
+    uint32_t b, tile;
+    if (!wg_map(a.T, a.B, b, tile)) return;
+    const uint32_t lenw = a.len[b];
+    const uint32_t len = lenw & TAIL_LEN;
+    const uint32_t r0 = tile * TAIL_T;
+    if (r0 >= len) return;
+    const size_t base = (size_t)b * a.S;
+    const u64 *src = ((lenw & TAIL_BUF_B) ? a.bufB : a.bufA) + base;
+    u64 *dst = ((lenw & TAIL_BUF_B) ? a.bufA : a.bufB) + base;
+    constexpr int PER = TAIL_T / 256;
+    const uint32_t s0 = r0 + threadIdx.x * PER;
+    u64 x[PER];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        x[k] = (s0 + k < len) ? src[s0 + k] : LIST_INVALID;
+        if (x[k] != LIST_INVALID && ((x[k] >> 60) & 1ull)) x[k] = LIST_INVALID;
+        cnt += x[k] != LIST_INVALID;
+    }
+    __shared__ uint32_t ls[256 / 64 + 2];
+    uint32_t tot;
+    uint32_t o = a.tcount[(size_t)b * a.TT + tile] + block_excl_add(cnt, ls, &tot);
+#pragma unroll
+    for (int k = 0; k < PER; k++)
+        if (x[k] != LIST_INVALID) dst[o++] = x[k];
 }
 
 // ---- last column ---------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) bwt_emit(Batch bt)
+__global__ void __launch_bounds__(256) bwt_emit(Batch bt, uint32_t T, uint32_t B)
 {
-    const uint32_t b = blockIdx.y;
+    uint32_t b, tile;
+    if (!wg_map(T, B, b, tile)) return;
     const uint32_t n = bt.n[b];
     const size_t base = (size_t)b * bt.S;
     const uint8_t *s = bt.rle + base;
@@ -396,15 +728,15 @@ __global__ void __launch_bounds__(256) bwt_emit(Batch bt)
     seen[threadIdx.x] = 0;
     __syncthreads();
     // 4 consecutive positions per thread -> one 32-bit store
-    for (uint32_t p0 = (blockIdx.x * 256 + threadIdx.x) * 4; p0 < n; p0 += gridDim.x * 256 * 4) {
+    for (uint32_t p0 = (tile * 256 + threadIdx.x) * 4; p0 < n; p0 += T * 256 * 4) {
         uint32_t w = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            uint32_t p = p0 + k;
+            const uint32_t p = p0 + k;
             if (p < n) {
-                uint32_t j = sa[p];
+                const uint32_t j = sa[p];
                 if (j == 0) bt.ptr[b] = p;
-                uint32_t c = s[j ? j - 1 : n - 1];
+                const uint32_t c = s[j ? j - 1 : n - 1];
                 w |= c << (8 * k);
                 seen[c] = 1; // every byte of S appears exactly once in the last column
             }
@@ -422,32 +754,36 @@ __global__ void __launch_bounds__(256) bwt_emit(Batch bt)
 template <int BITS, int MODE>
 static void launch_pass(bzh_ctx *ctx, SortArgs &a, uint32_t B, uint32_t maxcnt, uint64_t elems)
 {
-    uint32_t tiles = (maxcnt + SORT_TILE - 1) / SORT_TILE;
+    const uint32_t tiles = (maxcnt + SORT_TILE - 1) / SORT_TILE;
     if (tiles == 0) return;
+    a.T = tiles;
+    a.B = B;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    radix_hist<BITS, MODE><<<dim3(tiles, B), SORT_THREADS, 0, ctx->stream>>>(a);
+    radix_hist<BITS, MODE><<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(a);
     radix_scan<BITS><<<dim3(B), 1024, 0, ctx->stream>>>(a);
     if (ctx->profiling) { // HIP events bracket the dominant kernel only
         e0 = bzh_event(ctx);
         hipEventRecord(e0, ctx->stream);
     }
-    radix_scatter<BITS, MODE><<<dim3(tiles, B), SORT_THREADS, 0, ctx->stream>>>(a);
+    radix_scatter<BITS, MODE><<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(a);
     if (ctx->profiling) {
         e1 = bzh_event(ctx);
         hipEventRecord(e1, ctx->stream);
         ctx->sort_spans.push_back({e0, e1});
         ctx->stats.bwt_sort_launches += 1;
-        ctx->stats.bwt_sort_elems += elems; // (key, suffix) pairs this launch writes
+        ctx->stats.bwt_sort_elems += elems; // elements this launch writes
     }
 }
 
 static void launch_refine(bzh_ctx *ctx, RefineArgs &r, uint32_t B, uint32_t maxcnt)
 {
-    uint32_t tiles = (maxcnt + SORT_TILE - 1) / SORT_TILE;
+    const uint32_t tiles = (maxcnt + SORT_TILE - 1) / SORT_TILE;
     if (tiles == 0) return;
-    flag_tiles<<<dim3(tiles, B), SORT_THREADS, 0, ctx->stream>>>(r);
+    r.T = tiles;
+    r.B = B;
+    flag_tiles<<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(r);
     flag_carry<<<dim3(B), 1024, 0, ctx->stream>>>(r);
-    refine<<<dim3(tiles, B), SORT_THREADS, 0, ctx->stream>>>(r);
+    refine<<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(r);
 }
 
 // Suffix-sort and emit the last column for blocks 0..B-1 of the batch (bt.rle / bt.n filled).
@@ -457,6 +793,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     Batch &bt = ctx->bt;
     if (B == 0) return BZH_OK;
     hipStream_t st = ctx->stream;
+    u64 *bufA = reinterpret_cast<u64 *>(bt.listA), *bufB = reinterpret_cast<u64 *>(bt.listB);
 
     SortArgs a{};
     a.blk = bt.rle;
@@ -468,26 +805,32 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     a.TPB = bt.TPB;
     a.h = 0;
 
-    // ---- initial sort on the 4-byte cyclic prefix: 4 passes of 8 bits -------------------------
+    // ---- initial sort on the 4-byte cyclic prefix: 4 passes of 8 bits over bits 32..63 ---------
     a.cnt = bt.n;
     a.gate = bt.n;
-    a.shift = 0;
+    a.shift = 32;
     a.src = nullptr;
-    a.dst = bt.listA;
+    a.dst = bufA;
     launch_pass<8, GEN_BYTES4>(ctx, a, B, nmax, ntotal);
-    uint2 *cur = bt.listA, *oth = bt.listB;
+    u64 *cur = bufA, *oth = bufB;
     for (int p = 1; p < 4; p++) {
-        a.shift = 8 * p;
+        a.shift = 32 + 8 * p;
         a.src = cur;
         a.dst = oth;
         launch_pass<8, GEN_LIST>(ctx, a, B, nmax, ntotal);
-        uint2 *t = cur;
+        u64 *t = cur;
         cur = oth;
         oth = t;
     }
 
-    uint32_t *nact = bt.nactA, *nact_next = bt.nactB;
+    // three rotating count arrays: length of the list in `cur` (prevcnt), unresolved counts of the
+    // round being sorted (nact), counts that round's refine accumulates (nact_next)
+    uint32_t *cnts[3] = {bt.nactA, bt.nactB, bt.nactC};
+    int inext = 0;
+    uint32_t *nact = nullptr, *nact_next = cnts[inext];
     HIP_TRY(ctx, hipMemsetAsync(nact_next, 0, B * sizeof(uint32_t), st));
+    HIP_TRY(ctx, hipMemsetAsync(bt.maxgrp, 0, B * sizeof(uint32_t), st));
+    HIP_TRY(ctx, hipMemsetAsync(bt.errflag, 0, sizeof(uint32_t), st));
 
     RefineArgs r{};
     r.n = bt.n;
@@ -498,68 +841,178 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     r.flg = bt.flg;
     r.tagg = bt.tagg;
     r.nact_next = nact_next;
+    r.maxgrp = bt.maxgrp;
     r.S = bt.S;
     r.TPB = bt.TPB;
-    r.h = 0;
     r.init = 1;
     launch_refine(ctx, r, B, nmax);
 
     // ---- doubling rounds ---------------------------------------------------------------------------
+    const uint32_t mb = ctx->max_batch;
+    uint32_t *hact = ctx->h_pinned;       // unresolved counts read back this round
+    uint32_t *hn = ctx->h_pinned + mb;    // block lengths
+    uint32_t *hmax = ctx->h_pinned + 2 * mb; // largest group per block after the last radix round
+    uint32_t *hgR = ctx->h_pinned + 3 * mb;  // gates uploaded each round
+    uint32_t *hgT = ctx->h_pinned + 4 * mb;
+    HIP_TRY(ctx, hipMemcpyAsync(hn, bt.n, B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    std::vector<uint32_t> hprev(B), taillen(B, 0); // list length per block; frozen slots once in TAIL mode
+    std::vector<uint8_t> tailmode(B, 0);
+    bool active_mode = false, have_n = false;
+    const uint32_t *prevcnt = bt.n; // device: length of the list `cur` per block (radix blocks)
     uint32_t h = 4;
-    uint32_t *hact = ctx->h_pinned;
-    for (int round = 0; round < 40; round++) {
+    TailArgs ta{};
+    ta.n = bt.n;
+    ta.len = bt.gateT;
+    ta.bufA = bufA;
+    ta.bufB = bufB;
+    ta.rank = bt.rank;
+    ta.sa = bt.sa;
+    ta.err = bt.errflag;
+    ta.tcount = bt.alive;
+    ta.S = bt.S;
+    ta.TT = (bt.S + TAIL_T - 1) / TAIL_T; // <= 512 (S <= 2^20)
+    for (int round = 0; round < 48; round++) {
         HIP_TRY(ctx, hipMemcpyAsync(hact, nact_next, B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(hmax, bt.maxgrp, B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
-        uint32_t maxact = 0;
-        uint64_t sum = 0;
-        for (uint32_t b = 0; b < B; b++) {
-            maxact = hact[b] > maxact ? hact[b] : maxact;
-            sum += hact[b];
+        if (!have_n) {
+            for (uint32_t b = 0; b < B; b++) hprev[b] = hn[b];
+            have_n = true;
         }
-        if (maxact == 0) break;
-        ctx->stats.bwt_active_sum += sum;
+        // per-block mode: a block whose groups all fit a tail window leaves the radix path for good
+        uint32_t maxact = 0, prevmax = 0, maxtail = 0;
+        uint64_t sum = 0, nsum = 0, tot = 0;
+        for (uint32_t b = 0; b < B; b++) {
+            tot += hact[b];
+            if (!tailmode[b] && hact[b] && hmax[b] <= (uint32_t)TAIL_G) {
+                tailmode[b] = 1;
+                // the sorted list in `cur` keeps this many slots, in this buffer, from now on
+                taillen[b] = hprev[b] | (cur == bufB ? TAIL_BUF_B : 0u);
+            }
+            if (tailmode[b] == 2) // compacted last round: the list moved to the other buffer
+                taillen[b] = hact[b] | ((taillen[b] & TAIL_BUF_B) ^ TAIL_BUF_B) | TAIL_RECS;
+            if (tailmode[b]) {
+                tailmode[b] = 2;
+                hgR[b] = 0;
+                hgT[b] = hact[b] ? taillen[b] : 0;
+                maxtail = (hgT[b] & TAIL_LEN) > maxtail ? (hgT[b] & TAIL_LEN) : maxtail;
+            } else {
+                hgR[b] = hact[b];
+                hgT[b] = 0;
+                maxact = hact[b] > maxact ? hact[b] : maxact;
+                if (hact[b]) {
+                    prevmax = hprev[b] > prevmax ? hprev[b] : prevmax;
+                    sum += hact[b];
+                    nsum += hn[b];
+                }
+                hprev[b] = hact[b]; // length of the list this round's sort produces
+            }
+        }
+        if (tot == 0) break;
+        ctx->stats.bwt_active_sum += tot;
         ctx->stats.bwt_rounds = (uint64_t)(round + 1) > ctx->stats.bwt_rounds ? (uint64_t)(round + 1) : ctx->stats.bwt_rounds;
-        { // swap counters
-            uint32_t *t = nact;
-            nact = nact_next;
-            nact_next = t;
+        { // rotate: this round's counts stay readable next round as the length of `cur`
+            const int icur = inext;
+            int inew = (icur + 1) % 3;
+            if (cnts[inew] == prevcnt) inew = (icur + 2) % 3;
+            nact = cnts[icur];
+            nact_next = cnts[inew];
+            inext = inew;
         }
         HIP_TRY(ctx, hipMemsetAsync(nact_next, 0, B * sizeof(uint32_t), st));
+        HIP_TRY(ctx, hipMemsetAsync(bt.maxgrp, 0, B * sizeof(uint32_t), st));
+        HIP_TRY(ctx, hipMemcpyAsync(bt.gateR, hgR, B * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(bt.gateT, hgT, B * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        // ACTIVE costs ~5 list passes over the unresolved suffixes, SWEEP a full SA sweep (hist +
+        // scatter) plus 3 passes: switch once the unresolved fraction is small; never switch back.
+        if (!active_mode && nsum && sum * 3 < nsum) active_mode = true;
 
         a.h = h;
-        a.gate = nact;
-        // pass 0: enumerate unresolved suffixes in order of their second half, bucket by rank bits 0..6
-        a.cnt = bt.n;
-        a.shift = 0;
-        a.src = nullptr;
-        a.dst = bt.listA;
-        launch_pass<7, GEN_ROUND>(ctx, a, B, nmax, sum);
-        // passes 1, 2 over the compact list
-        a.cnt = nact;
-        a.shift = 7;
-        a.src = bt.listA;
-        a.dst = bt.listB;
-        launch_pass<7, GEN_LIST>(ctx, a, B, maxact, sum);
-        a.shift = 14;
-        a.src = bt.listB;
-        a.dst = bt.listA;
-        launch_pass<7, GEN_LIST>(ctx, a, B, maxact, sum);
+        a.gate = bt.gateR;
+        u64 *next_cur = cur, *next_oth = oth;
+        if (!maxact) {
+            // every unresolved block is in TAIL mode
+        } else if (!active_mode) {
+            a.cnt = bt.n; // enumerate SA positions
+            a.shift = 40;
+            a.src = nullptr;
+            a.dst = bufA;
+            launch_pass<7, GEN_SWEEP>(ctx, a, B, nmax, sum);
+            a.cnt = nact;
+            a.shift = 47;
+            a.src = bufA;
+            a.dst = bufB;
+            launch_pass<7, GEN_LIST>(ctx, a, B, maxact, sum);
+            a.shift = 54;
+            a.src = bufB;
+            a.dst = bufA;
+            launch_pass<7, GEN_LIST>(ctx, a, B, maxact, sum);
+            next_cur = bufA;
+            next_oth = bufB;
+        } else {
+            next_cur = oth; // 5 passes leave the new list in `oth`
+            next_oth = cur;
+            {
+                u64 *c = cur, *o = oth;
+                a.cnt = prevcnt; // re-key the previous sorted list
+                a.shift = 20;
+                a.src = c;
+                a.dst = o;
+                launch_pass<8, GEN_ACTIVE>(ctx, a, B, prevmax, sum);
+                a.cnt = nact;
+                for (int p = 1; p < 5; p++) {
+                    u64 *t = c;
+                    c = o;
+                    o = t;
+                    a.shift = 20 + 8 * p;
+                    a.src = c;
+                    a.dst = o;
+                    launch_pass<8, GEN_LIST>(ctx, a, B, maxact, sum);
+                }
+            }
+        }
+        if (maxtail) { // blocks in TAIL mode: in place in their own buffer, independent of cur/oth
+            ta.nact_next = nact_next;
+            ta.h = h;
+            ta.T = (maxtail + TAIL_T - 1) / TAIL_T;
+            ta.B = B;
+            tail_sort<<<dim3(xcd_grid(ta.T, B)), TAIL_THREADS, 0, st>>>(ta);
+            tail_apply<<<dim3(xcd_grid(ta.T, B)), 256, 0, st>>>(ta);
+            tail_scan<<<dim3(B), 512, 0, st>>>(ta);
+            tail_compact<<<dim3(xcd_grid(ta.T, B)), 256, 0, st>>>(ta);
+        }
+        if (maxact) {
+            cur = next_cur;
+            oth = next_oth;
+        }
 
-        r.cnt = nact;
-        r.list = bt.listA;
-        r.nact_next = nact_next;
-        r.h = h;
-        r.init = 0;
-        launch_refine(ctx, r, B, maxact);
+        if (maxact) {
+            r.cnt = nact;
+            r.list = cur;
+            r.nact_next = nact_next;
+            r.init = 0;
+            r.gate = bt.gateR;
+            launch_refine(ctx, r, B, maxact);
+        }
+        prevcnt = nact;
 
         if (h < (1u << 30)) h <<= 1;
+    }
+    {
+        uint32_t err = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&err, bt.errflag, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (err) {
+            bzh_set_error(ctx, "BWT tail rounds saw a group larger than their window (internal error)");
+            return BZH_E_HIP;
+        }
     }
 
     HIP_TRY(ctx, hipMemsetAsync(bt.hasbyte, 0, (size_t)B * 256, st));
     uint32_t gx = (nmax + 1023) / 1024;
     if (gx > 256) gx = 256;
     if (gx == 0) gx = 1;
-    bwt_emit<<<dim3(gx, B), 256, 0, st>>>(bt);
+    bwt_emit<<<dim3(xcd_grid(gx, B)), 256, 0, st>>>(bt, gx, B);
     HIP_TRY(ctx, hipGetLastError());
     return BZH_OK;
 }

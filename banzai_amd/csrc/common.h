@@ -66,6 +66,12 @@ struct Batch {
     int2 *tagg;     // [B][TPB] tile aggregates (last group start, last boundary)
     uint32_t *nactA; // [B]
     uint32_t *nactB; // [B]
+    uint32_t *nactC; // [B]
+    uint32_t *gateR; // [B] per-round gate of the radix kernels (unresolved count, 0 = skip)
+    uint32_t *gateT; // [B] per-round gate of the tail kernels (frozen list slots, 0 = skip)
+    uint32_t *maxgrp; // [B] largest refined group of the last radix round
+    uint32_t *errflag; // [1]
+    uint32_t *alive;   // [B][S/2048] tail-mode tile states
     // MTF / RLE2
     uint8_t *mtfpos;   // [B][S]   MTF position of every BWT byte
     uint8_t *tilelist; // [B][MT][256] recency list at each MTF tile entry

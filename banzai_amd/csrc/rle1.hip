@@ -408,14 +408,19 @@ struct EmitArgs {
     const uint32_t *first;
 };
 
+// One workgroup = one 4096-byte input tile of one block.  Every input byte yields at most one
+// literal and one count byte; the tile's output is one contiguous byte range (<= 5/4 of the tile),
+// staged in LDS and written out as aligned 32-bit words (ragged edges byte by byte: neighbouring
+// tiles own the other bytes of those words).
 __global__ void __launch_bounds__(RL_THREADS) rle1_emit_kernel(EmitArgs ea, Batch bt)
 {
     const uint32_t b = blockIdx.y;
     const BlockDesc d = ea.blocks[b];
     const uint64_t in_end = d.in_off + d.in_len;
     const uint32_t tile = (uint32_t)(d.in_off / RL_TILE) + blockIdx.x;
-    const uint64_t p0 = (uint64_t)tile * RL_TILE + threadIdx.x * RL_ITEMS;
-    if ((uint64_t)tile * RL_TILE >= in_end) return;
+    const uint64_t tile0 = (uint64_t)tile * RL_TILE;
+    const uint64_t p0 = tile0 + threadIdx.x * RL_ITEMS;
+    if (tile0 >= in_end) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         bt.n[b] = d.rle_len;
         bt.desc[b] = d;
@@ -423,24 +428,32 @@ __global__ void __launch_bounds__(RL_THREADS) rle1_emit_kernel(EmitArgs ea, Batc
     uint32_t valid, v[4];
     const uint32_t mask = start_mask(ea.in, ea.n, p0, valid, v);
     __shared__ uint32_t ls[RL_THREADS / 64 + 2];
+    __shared__ uint8_t stage[RL_TILE + RL_TILE / 4 + 16];
+    __shared__ uint32_t obase_s;
     uint32_t tot;
     // run index of the byte BEFORE this thread's first byte
     uint32_t j = ea.tbase[tile] + block_excl_add(__popc(mask), ls, &tot) - 1u;
-    if (p0 >= in_end || p0 + valid <= d.in_off) return;
 
     const uint32_t jf = ea.first[b];
     const uint64_t pof = ea.po[jf + 1];
     const uint32_t A = canon_len((uint32_t)(ea.rs[jf + 1] - d.in_off));
-    uint8_t *out = bt.rle + (size_t)b * bt.S;
+    // first / last input position of this tile that belongs to the block
+    const uint64_t pfirst = tile0 > d.in_off ? tile0 : d.in_off;
 
-    uint32_t curj = 0xFFFFFFFFu, rstart = 0, rend = 0, origin = 0, base = 0;
+    uint32_t curj = 0xFFFFFFFFu, rend = 0, origin = 0, base = 0;
+    uint32_t offs[RL_ITEMS]; // block-relative output offset of the byte's chunk
+    uint32_t kks[RL_ITEMS];  // position inside the chunk | 0x100 if it also emits the count byte
+    uint32_t inblk = 0;
+    uint32_t lastend = 0; // output offset just past everything this thread emits
     for (uint32_t k = 0; k < valid; k++) {
         if (mask & (1u << k)) j++;
         const uint64_t p = p0 + k;
+        offs[k] = 0;
+        kks[k] = 0;
         if (p < d.in_off || p >= in_end) continue;
         if (j != curj) {
             curj = j;
-            rstart = ea.rs[j];
+            const uint32_t rstart = ea.rs[j];
             rend = ea.rs[j + 1];
             if (rstart <= d.in_off) { // the run the block starts in: chunking restarts at in_off
                 origin = (uint32_t)d.in_off;
@@ -452,11 +465,43 @@ __global__ void __launch_bounds__(RL_THREADS) rle1_emit_kernel(EmitArgs ea, Batc
         }
         const uint32_t dd = (uint32_t)p - origin;
         const uint32_t c = dd / 255u, kk = dd - c * 255u;
-        const uint32_t o = base + 5u * c;
-        const uint32_t byte = (v[k >> 2] >> ((k & 3) * 8)) & 255u;
-        if (kk < 4u) out[o + kk] = (uint8_t)byte;
-        if (kk >= 3u && (kk == 254u || p + 1 == rend)) out[o + 4u] = (uint8_t)(kk - 3u); // lib/rle.rs:212-226
+        const bool cnt_byte = kk >= 3u && (kk == 254u || p + 1 == rend); // lib/rle.rs:212-226
+        offs[k] = base + 5u * c;
+        kks[k] = kk | (cnt_byte ? 0x100u : 0u);
+        inblk |= 1u << k;
+        if (p == pfirst) obase_s = offs[k] + (kk < 4u ? kk : 4u); // first byte this tile emits
+        const uint32_t e = offs[k] + (cnt_byte ? 5u : (kk < 4u ? kk + 1u : 0u));
+        lastend = e > lastend ? e : lastend;
     }
+    __shared__ uint32_t oend_s;
+    if (threadIdx.x == 0) oend_s = 0;
+    __syncthreads();
+    atomicMax(&oend_s, lastend);
+    __syncthreads();
+    const uint32_t obase = obase_s;
+    const uint32_t nout = oend_s > obase ? oend_s - obase : 0;
+    for (uint32_t k = 0; k < valid; k++) {
+        if (!(inblk & (1u << k))) continue;
+        const uint32_t kk = kks[k] & 0xFFu;
+        const uint32_t byte = (v[k >> 2] >> ((k & 3) * 8)) & 255u;
+        if (kk < 4u) stage[offs[k] + kk - obase] = (uint8_t)byte;
+        if (kks[k] & 0x100u) stage[offs[k] + 4u - obase] = (uint8_t)(kk - 3u);
+    }
+    __syncthreads();
+    uint8_t *out = bt.rle + (size_t)b * bt.S + obase;
+    // head bytes up to the first 4-byte aligned address, aligned words, tail bytes
+    const uint32_t mis = (uint32_t)((uintptr_t)out & 3u);
+    const uint32_t head = mis ? (4u - mis < nout ? 4u - mis : nout) : 0u;
+    const uint32_t nwords = (nout - head) / 4u;
+    const uint32_t tail0 = head + nwords * 4u;
+    if (threadIdx.x < head) out[threadIdx.x] = stage[threadIdx.x];
+    for (uint32_t w = threadIdx.x; w < nwords; w += RL_THREADS) {
+        const uint32_t o = head + w * 4u;
+        const uint32_t x = (uint32_t)stage[o] | ((uint32_t)stage[o + 1] << 8) | ((uint32_t)stage[o + 2] << 16) |
+                           ((uint32_t)stage[o + 3] << 24);
+        *reinterpret_cast<uint32_t *>(out + o) = x;
+    }
+    if (threadIdx.x < nout - tail0) out[tail0 + threadIdx.x] = stage[tail0 + threadIdx.x];
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------
