@@ -72,17 +72,20 @@ static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
     carve(p, bt.hasbyte, NB * 256);
     carve(p, bt.rank, NB * S);
     carve(p, bt.sa, NB * S);
+    carve(p, bt.headp, NB * S);
     carve(p, bt.listA, NB * S);
     carve(p, bt.listB, NB * S);
     carve(p, bt.hist, NB * 256 * bt.TPB);
     carve(p, bt.flg, NB * S);
     carve(p, bt.tagg, NB * bt.TPB);
-    carve(p, bt.nactA, NB);
-    carve(p, bt.nactB, NB);
-    carve(p, bt.nactC, NB);
-    carve(p, bt.gateR, NB);
-    carve(p, bt.gateT, NB);
-    carve(p, bt.maxgrp, NB);
+    // per-round state: three rotating {unresolved counts[NB], largest group[NB]} pairs, each pair
+    // contiguous so one copy / one memset moves it; the two gate arrays likewise
+    carve(p, bt.nactA, 6 * NB);
+    bt.nactB = bt.nactA + 2 * NB;
+    bt.nactC = bt.nactA + 4 * NB;
+    bt.maxgrp = nullptr; // = count array + NB, see bwt_run
+    carve(p, bt.gateR, 2 * NB);
+    bt.gateT = bt.gateR + NB;
     carve(p, bt.errflag, 64);
     carve(p, bt.alive, NB * ((S + 2047) / 2048));
     carve(p, bt.mtfpos, NB * S);

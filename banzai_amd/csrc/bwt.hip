@@ -54,6 +54,7 @@ struct SortArgs {
     const uint32_t *gate; // [B] skip block when 0
     const uint32_t *rank; // [B][S]
     const uint32_t *sa;   // [B][S]
+    const uint32_t *headp; // [B][S] group rank of the suffix at each SA position
     const u64 *src;       // [B][S]
     u64 *dst;             // [B][S]
     uint32_t *hist;       // [B][NBMAX*TPB]
@@ -101,7 +102,7 @@ __device__ __forceinline__ bool gen_elem(const SortArgs &a, uint32_t b, uint32_t
             i = j >= a.h ? j - a.h : j + n - a.h;
             const uint32_t r = a.rank[base + i];
             if (r & RANK_RESOLVED) return false;
-            k2 = WANT_K2 ? (a.rank[base + j] & RANK_MASK) : 0u;
+            k2 = WANT_K2 ? a.headp[base + e] : 0u; // = rank[j] without the gather
             v = ((u64)r << 40) | ((u64)k2 << 20) | i;
             return true;
         }
@@ -276,6 +277,7 @@ struct RefineArgs {
     const u64 *list;     // [B][S] sorted elements
     uint32_t *rank;      // [B][S]
     uint32_t *sa;        // [B][S]
+    uint32_t *headp;     // [B][S]
     uint8_t *flg;        // [B][S]
     int2 *tagg;          // [B][TPB]
     uint32_t *nact_next; // [B]
@@ -378,12 +380,14 @@ __global__ void __launch_bounds__(1024) flag_carry(RefineArgs a)
     const uint32_t ntile = (cnt + SORT_TILE - 1) / SORT_TILE;
     if (ntile == 0) return;
     int2 *t = a.tagg + (size_t)b * a.TPB;
-    __shared__ int l0[16], l1[16];
+    __shared__ int l01[32];
     __shared__ int inc0[1024], inc1[1024];
     const uint32_t e = threadIdx.x;
     const int2 v = e < ntile ? t[e] : make_int2(-1, -1);
-    inc0[e] = block_incl_max(v.x, l0);
-    inc1[e] = block_incl_max(v.y, l1);
+    int s0 = v.x, s1 = v.y;
+    block_incl_max2(s0, s1, l01);
+    inc0[e] = s0;
+    inc1[e] = s1;
     __syncthreads();
     if (e < ntile) t[e] = e == 0 ? make_int2(-1, -1) : make_int2(inc0[e - 1], inc1[e - 1]);
 }
@@ -421,10 +425,11 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
             if (f & 2u) td = (int)(q0 + k);
         }
     }
-    __shared__ int l0[SORT_THREADS / 64], l1[SORT_THREADS / 64];
+    __shared__ int l01[2 * SORT_THREADS / 64];
     __shared__ int ex0[SORT_THREADS], ex1[SORT_THREADS];
-    ex0[threadIdx.x] = block_incl_max(tg, l0);
-    ex1[threadIdx.x] = block_incl_max(td, l1);
+    block_incl_max2(tg, td, l01);
+    ex0[threadIdx.x] = tg;
+    ex1[threadIdx.x] = td;
     __syncthreads(); // also orders stage_tile's stores before the blocked reads below
     const int2 tc = a.tagg[(size_t)b * a.TPB + tile];
     int cg = tc.x, cd = tc.y;
@@ -434,8 +439,9 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
     }
     uint32_t *rank = a.rank + base;
     uint32_t *sa = a.sa + base;
+    uint32_t *headp = a.headp + base;
     uint32_t unresolved = 0, biggest = 0;
-    u64 outv[SORT_ITEMS]; // (SA position << 32 | suffix) per element, all ones = none
+    u64 outv[SORT_ITEMS]; // SA position : group rank : suffix (20 bits each), all ones = none
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; k++) outv[k] = ~0ull;
     if (q0 < cnt) {
@@ -455,7 +461,7 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
                 const uint32_t head = gbase + (uint32_t)cd;
                 const bool single = (f & 2u) && ((q + 1 == cnt) || (fn & 2u));
                 rank[i] = single ? (head | RANK_RESOLVED) : head;
-                outv[k] = ((u64)pos << 32) | i;
+                outv[k] = ((u64)pos << 40) | ((u64)head << 20) | i;
                 unresolved += single ? 0u : 1u;
                 if ((q + 1 == cnt) || (fn & 2u)) biggest = max(biggest, q - (uint32_t)cd + 1u); // last of its group
             }
@@ -469,7 +475,11 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; k++) {
         const u64 x = lds[slot_of(k * SORT_THREADS + threadIdx.x)];
-        if (x != ~0ull) sa[(uint32_t)(x >> 32)] = (uint32_t)x;
+        if (x != ~0ull) {
+            const uint32_t pos = (uint32_t)(x >> 40);
+            sa[pos] = (uint32_t)(x & SUF_MASK);
+            headp[pos] = (uint32_t)(x >> 20) & 0xFFFFFu;
+        }
     }
     unresolved = wave_reduce_add(unresolved);
 #pragma unroll
@@ -800,6 +810,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     a.n = bt.n;
     a.rank = bt.rank;
     a.sa = bt.sa;
+    a.headp = bt.headp;
     a.hist = bt.hist;
     a.S = bt.S;
     a.TPB = bt.TPB;
@@ -828,8 +839,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     uint32_t *cnts[3] = {bt.nactA, bt.nactB, bt.nactC};
     int inext = 0;
     uint32_t *nact = nullptr, *nact_next = cnts[inext];
-    HIP_TRY(ctx, hipMemsetAsync(nact_next, 0, B * sizeof(uint32_t), st));
-    HIP_TRY(ctx, hipMemsetAsync(bt.maxgrp, 0, B * sizeof(uint32_t), st));
+    const uint32_t mb = ctx->max_batch; // pair layout: counts at +0, largest group at +mb
+    HIP_TRY(ctx, hipMemsetAsync(nact_next, 0, 2 * mb * sizeof(uint32_t), st));
     HIP_TRY(ctx, hipMemsetAsync(bt.errflag, 0, sizeof(uint32_t), st));
 
     RefineArgs r{};
@@ -838,20 +849,20 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     r.list = cur;
     r.rank = bt.rank;
     r.sa = bt.sa;
+    r.headp = bt.headp;
     r.flg = bt.flg;
     r.tagg = bt.tagg;
     r.nact_next = nact_next;
-    r.maxgrp = bt.maxgrp;
+    r.maxgrp = nact_next + mb;
     r.S = bt.S;
     r.TPB = bt.TPB;
     r.init = 1;
     launch_refine(ctx, r, B, nmax);
 
     // ---- doubling rounds ---------------------------------------------------------------------------
-    const uint32_t mb = ctx->max_batch;
     uint32_t *hact = ctx->h_pinned;       // unresolved counts read back this round
-    uint32_t *hn = ctx->h_pinned + mb;    // block lengths
-    uint32_t *hmax = ctx->h_pinned + 2 * mb; // largest group per block after the last radix round
+    uint32_t *hmax = ctx->h_pinned + mb;     // largest group per block after the last radix round
+    uint32_t *hn = ctx->h_pinned + 2 * mb;   // block lengths
     uint32_t *hgR = ctx->h_pinned + 3 * mb;  // gates uploaded each round
     uint32_t *hgT = ctx->h_pinned + 4 * mb;
     HIP_TRY(ctx, hipMemcpyAsync(hn, bt.n, B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -872,8 +883,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     ta.S = bt.S;
     ta.TT = (bt.S + TAIL_T - 1) / TAIL_T; // <= 512 (S <= 2^20)
     for (int round = 0; round < 48; round++) {
-        HIP_TRY(ctx, hipMemcpyAsync(hact, nact_next, B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipMemcpyAsync(hmax, bt.maxgrp, B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(hact, nact_next, 2 * mb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
         if (!have_n) {
             for (uint32_t b = 0; b < B; b++) hprev[b] = hn[b];
@@ -919,10 +929,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             nact_next = cnts[inew];
             inext = inew;
         }
-        HIP_TRY(ctx, hipMemsetAsync(nact_next, 0, B * sizeof(uint32_t), st));
-        HIP_TRY(ctx, hipMemsetAsync(bt.maxgrp, 0, B * sizeof(uint32_t), st));
-        HIP_TRY(ctx, hipMemcpyAsync(bt.gateR, hgR, B * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(bt.gateT, hgT, B * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemsetAsync(nact_next, 0, 2 * mb * sizeof(uint32_t), st));
+        HIP_TRY(ctx, hipMemcpyAsync(bt.gateR, hgR, 2 * mb * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         // ACTIVE costs ~5 list passes over the unresolved suffixes, SWEEP a full SA sweep (hist +
         // scatter) plus 3 passes: switch once the unresolved fraction is small; never switch back.
         if (!active_mode && nsum && sum * 3 < nsum) active_mode = true;
@@ -990,6 +998,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             r.cnt = nact;
             r.list = cur;
             r.nact_next = nact_next;
+            r.maxgrp = nact_next + mb;
             r.init = 0;
             r.gate = bt.gateR;
             launch_refine(ctx, r, B, maxact);

@@ -59,6 +59,7 @@ struct Batch {
     // suffix sorting
     uint32_t *rank; // [B][S]
     uint32_t *sa;   // [B][S]
+    uint32_t *headp; // [B][S] group rank by SA position (SWEEP rounds read it instead of gathering)
     uint2 *listA;   // [B][S] (key, suffix)
     uint2 *listB;   // [B][S]
     uint32_t *hist; // [B][256*TPB]
@@ -196,6 +197,26 @@ __device__ __forceinline__ int block_incl_max(int v, int *lds)
     int res = max(inc, carry);
     __syncthreads();
     return res;
+}
+
+// Two inclusive max-scans at once (same barriers).  `lds` needs 2*(threads/64) ints.
+__device__ __forceinline__ void block_incl_max2(int &a, int &b, int *lds)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    const int ia = wave_incl_max(a, lane), ib = wave_incl_max(b, lane);
+    if (lane == 63) {
+        lds[wave] = ia;
+        lds[nw + wave] = ib;
+    }
+    __syncthreads();
+    int ca = INT32_MIN, cb = INT32_MIN;
+    for (int w = 0; w < wave; w++) {
+        ca = max(ca, lds[w]);
+        cb = max(cb, lds[nw + w]);
+    }
+    a = max(ia, ca);
+    b = max(ib, cb);
+    __syncthreads();
 }
 
 // ---- stage entry points (host side, defined in the stage files) ---------------------------------
