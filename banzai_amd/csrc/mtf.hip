@@ -26,15 +26,37 @@ __device__ __forceinline__ uint32_t run_digits(uint32_t z) // symbols emitted fo
     return z ? (31u - __clz(z + 1u)) : 0u;
 }
 
-// ---- per-tile last occurrence ---------------------------------------------------------------------
+// ---- dense names ------------------------------------------------------------------------------------
+// names[c] = rank of byte c among the present bytes (lib/mtf.rs:17-24).  MTF positions are the same
+// over names as over byte values (the renaming keeps order), and text blocks with <= 128 distinct
+// bytes then need 2 key registers instead of 4.  Every workgroup rebuilds the table from has_byte.
+__device__ __forceinline__ uint32_t build_names(const uint8_t *hasbyte, uint8_t *names /*LDS[256]*/, uint32_t *ls)
+{
+    // callable by 64..256 threads: thread t handles bytes t, t+blockDim, ...
+    const uint32_t per = 256 / blockDim.x, c0 = threadIdx.x * per;
+    uint32_t cnt = 0;
+    for (uint32_t k = 0; k < per; k++) cnt += hasbyte[c0 + k] ? 1u : 0u;
+    uint32_t total;
+    uint32_t idx = block_excl_add(cnt, ls, &total);
+    for (uint32_t k = 0; k < per; k++) {
+        names[c0 + k] = (uint8_t)idx;
+        idx += hasbyte[c0 + k] ? 1u : 0u;
+    }
+    __syncthreads();
+    return total;
+}
+
+// ---- per-tile last occurrence (indexed by name) -----------------------------------------------------
 __global__ void __launch_bounds__(256) mtf_tile_last(Batch bt, int32_t *tlast, uint32_t MT)
 {
     const uint32_t b = blockIdx.y, tile = blockIdx.x;
     const uint32_t n = bt.n[b];
     if (tile * MTF_TILE >= n) return;
     __shared__ int last[256];
+    __shared__ uint8_t names[256];
+    __shared__ uint32_t ls[8];
     last[threadIdx.x] = -1;
-    __syncthreads();
+    (void)build_names(bt.hasbyte + (size_t)b * 256, names, ls);
     const uint8_t *s = bt.bwt + (size_t)b * bt.S;
     const uint32_t p0 = tile * MTF_TILE + threadIdx.x * 8;
     if (p0 < n) {
@@ -44,7 +66,7 @@ __global__ void __launch_bounds__(256) mtf_tile_last(Batch bt, int32_t *tlast, u
             uint32_t p = p0 + k;
             if (p < n) {
                 uint32_t c = ((k < 4 ? w.x : w.y) >> ((k & 3) * 8)) & 255u;
-                atomicMax(&last[c], (int)p);
+                atomicMax(&last[names[c]], (int)p);
             }
         }
     }
@@ -61,7 +83,14 @@ __global__ void __launch_bounds__(256) mtf_prefix(Batch bt, int32_t *tlast, uint
     const uint32_t ntile = (n + MTF_TILE - 1) / MTF_TILE;
     const uint32_t c = threadIdx.x;
     const bool present = bt.hasbyte[(size_t)b * 256 + c] != 0;
-    int run = present ? -1 - (int)c : INT32_MIN;
+    uint32_t cnt = __popcll(__ballot(present));
+    __shared__ uint32_t w[4];
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    const uint32_t num_names = w[0] + w[1] + w[2] + w[3];
+    if (threadIdx.x == 0) bt.nsyms[b] = num_names + 2; // lib/mtf.rs:118
+    // thread = name: a never-seen name j sits behind every seen one, in name order (lib/mtf.rs:39-43)
+    int run = c < num_names ? -1 - (int)c : INT32_MIN;
     int32_t *t = tlast + (size_t)b * MT * 256 + c;
     uint32_t tile = 0;
     for (; tile + 8 <= ntile; tile += 8) {
@@ -79,36 +108,24 @@ __global__ void __launch_bounds__(256) mtf_prefix(Batch bt, int32_t *tlast, uint
         t[(size_t)tile * 256] = run;
         if (v >= 0) run = v;
     }
-    // num_syms = names + 2 (lib/mtf.rs:118)
-    uint32_t cnt = __popcll(__ballot(present));
-    __shared__ uint32_t w[4];
-    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) bt.nsyms[b] = w[0] + w[1] + w[2] + w[3] + 2;
 }
 
 // ---- the walk: one wavefront per tile ---------------------------------------------------------------
 __device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-// clang exposes no writelane builtin; a compare+select on a uniform lane index does the same
-__device__ __forceinline__ int wrlane(int val, int l, int old) { return (int)(threadIdx.x & 63) == l ? val : old; }
 
-__global__ void __launch_bounds__(64) mtf_walk(Batch bt, const int32_t *tlast, uint32_t MT)
+// NR = key registers in use (names < 64*NR).  All control flow is wave-uniform (scalar).
+template <int NR>
+__device__ __forceinline__ void walk_tile(const uint8_t *s, uint8_t *o, const int32_t *keys, const uint8_t *names,
+                                          uint32_t base_p, uint32_t tile_len, int lane)
 {
-    const uint32_t b = blockIdx.y, tile = blockIdx.x;
-    const uint32_t n = bt.n[b];
-    const uint32_t base_p = tile * MTF_TILE;
-    if (base_p >= n) return;
-    const int lane = threadIdx.x;
-    const int32_t *keys = tlast + ((size_t)b * MT + tile) * 256;
-    int k0 = keys[lane], k1 = keys[64 + lane], k2 = keys[128 + lane], k3 = keys[192 + lane];
-    const uint8_t *s = bt.bwt + (size_t)b * bt.S + base_p;
-    uint8_t *o = bt.mtfpos + (size_t)b * bt.S + base_p;
-
-    // front symbol at tile entry = arg max key
-    int front;
+    int k0 = keys[lane], k1 = NR > 1 ? keys[64 + lane] : INT32_MIN, k2 = NR > 2 ? keys[128 + lane] : INT32_MIN,
+        k3 = NR > 2 ? keys[192 + lane] : INT32_MIN;
+    int front; // name at the head of the recency list = arg max key
     {
-        int best = max(max(k0, k1), max(k2, k3));
-        int bsym = best == k0 ? lane : best == k1 ? 64 + lane : best == k2 ? 128 + lane : 192 + lane;
+        int best = k0, bsym = lane;
+        if (NR > 1 && k1 > best) { best = k1; bsym = 64 + lane; }
+        if (NR > 2 && k2 > best) { best = k2; bsym = 128 + lane; }
+        if (NR > 2 && k3 > best) { best = k3; bsym = 192 + lane; }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) {
             int ob = __shfl_xor(best, d, 64), os = __shfl_xor(bsym, d, 64);
@@ -119,24 +136,27 @@ __global__ void __launch_bounds__(64) mtf_walk(Batch bt, const int32_t *tlast, u
         }
         front = __builtin_amdgcn_readfirstlane(bsym); // keys are distinct, every lane agrees
     }
-
-    const uint32_t remain = n - base_p;
-    const uint32_t tile_len = remain < MTF_TILE ? remain : MTF_TILE;
 #pragma unroll 1
-    for (uint32_t chunk = 0; chunk < MTF_TILE / 1024; chunk++) {
-        const uint32_t cbase = chunk * 1024;
-        if (cbase >= tile_len) break;
-        // 16 bytes per lane; S is padded so the vector load stays inside the arena
-        const uint4 in = *reinterpret_cast<const uint4 *>(s + cbase + lane * 16);
+    for (uint32_t cbase = 0; cbase < tile_len; cbase += 1024) {
+        // 16 bytes per lane (S is padded so the vector load stays inside the arena), renamed once
+        const uint4 raw = *reinterpret_cast<const uint4 *>(s + cbase + lane * 16);
+        uint32_t in[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const uint32_t w = in[d];
+            in[d] = (uint32_t)names[w & 255u] | ((uint32_t)names[(w >> 8) & 255u] << 8) |
+                    ((uint32_t)names[(w >> 16) & 255u] << 16) | ((uint32_t)names[w >> 24] << 24);
+        }
         int o0 = 0, o1 = 0, o2 = 0, o3 = 0;
         const uint32_t clen = tile_len - cbase < 1024 ? tile_len - cbase : 1024;
         const uint32_t nl = (clen + 15) / 16;
 #pragma unroll 1
         for (uint32_t li = 0; li < nl; li++) {
             const uint32_t lim = clen - li * 16; // bytes valid in this lane (>= 1)
+            const bool me = (uint32_t)lane == li;
 #pragma unroll
             for (int d = 0; d < 4; d++) {
-                const uint32_t w = (uint32_t)rdlane((int)(d == 0 ? in.x : d == 1 ? in.y : d == 2 ? in.z : in.w), (int)li);
+                const uint32_t w = (uint32_t)rdlane((int)in[d], (int)li);
                 uint32_t ow = 0;
 #pragma unroll
                 for (int kb = 0; kb < 4; kb++) {
@@ -144,31 +164,63 @@ __global__ void __launch_bounds__(64) mtf_walk(Batch bt, const int32_t *tlast, u
                         const int c = (int)((w >> (8 * kb)) & 255u);
                         if (c != front) {
                             const int p = (int)(base_p + cbase + li * 16 + d * 4 + kb);
-                            const int l = c & 63;
-                            int prev;
-                            switch (c >> 6) {
-                            case 0: prev = rdlane(k0, l); k0 = wrlane(p, l, k0); break;
-                            case 1: prev = rdlane(k1, l); k1 = wrlane(p, l, k1); break;
-                            case 2: prev = rdlane(k2, l); k2 = wrlane(p, l, k2); break;
-                            default: prev = rdlane(k3, l); k3 = wrlane(p, l, k3); break;
+                            const int l = c & 63, sel = c >> 6;
+                            const bool mine = lane == l;
+                            int prev = rdlane(k0, l);
+                            k0 = (mine && sel == 0) ? p : k0;
+                            if (NR > 1) {
+                                const int q1 = rdlane(k1, l);
+                                prev = sel == 1 ? q1 : prev;
+                                k1 = (mine && sel == 1) ? p : k1;
+                            }
+                            if (NR > 2) {
+                                const int q2 = rdlane(k2, l), q3 = rdlane(k3, l);
+                                prev = sel == 2 ? q2 : prev;
+                                prev = sel == 3 ? q3 : prev;
+                                k2 = (mine && sel == 2) ? p : k2;
+                                k3 = (mine && sel == 3) ? p : k3;
                             }
                             // c's own key is already p (> prev), every other key is unchanged:
                             // position = (keys above prev) - 1 for the symbol itself.
-                            uint32_t cnt = (uint32_t)__popcll(__ballot(k0 > prev)) + (uint32_t)__popcll(__ballot(k1 > prev)) +
-                                           (uint32_t)__popcll(__ballot(k2 > prev)) + (uint32_t)__popcll(__ballot(k3 > prev)) - 1u;
+                            uint32_t cnt = (uint32_t)__popcll(__ballot(k0 > prev)) - 1u;
+                            if (NR > 1) cnt += (uint32_t)__popcll(__ballot(k1 > prev));
+                            if (NR > 2) cnt += (uint32_t)__popcll(__ballot(k2 > prev)) + (uint32_t)__popcll(__ballot(k3 > prev));
                             ow |= cnt << (8 * kb);
                             front = c;
                         }
                     }
                 }
-                if (d == 0) o0 = wrlane((int)ow, (int)li, o0);
-                else if (d == 1) o1 = wrlane((int)ow, (int)li, o1);
-                else if (d == 2) o2 = wrlane((int)ow, (int)li, o2);
-                else o3 = wrlane((int)ow, (int)li, o3);
+                if (d == 0) o0 = me ? (int)ow : o0;
+                else if (d == 1) o1 = me ? (int)ow : o1;
+                else if (d == 2) o2 = me ? (int)ow : o2;
+                else o3 = me ? (int)ow : o3;
             }
         }
         if ((uint32_t)lane < nl) *reinterpret_cast<uint4 *>(o + cbase + lane * 16) = make_uint4(o0, o1, o2, o3);
     }
+}
+
+__global__ void __launch_bounds__(64) mtf_walk(Batch bt, const int32_t *tlast, uint32_t MT)
+{
+    const uint32_t b = blockIdx.y, tile = blockIdx.x;
+    const uint32_t n = bt.n[b];
+    const uint32_t base_p = tile * MTF_TILE;
+    if (base_p >= n) return;
+    const int lane = threadIdx.x;
+    __shared__ uint8_t names[256];
+    __shared__ uint32_t ls[4];
+    const uint32_t num_names = build_names(bt.hasbyte + (size_t)b * 256, names, ls);
+    const int32_t *keys = tlast + ((size_t)b * MT + tile) * 256;
+    const uint8_t *s = bt.bwt + (size_t)b * bt.S + base_p;
+    uint8_t *o = bt.mtfpos + (size_t)b * bt.S + base_p;
+    const uint32_t remain = n - base_p;
+    const uint32_t tile_len = remain < MTF_TILE ? remain : MTF_TILE;
+    if (num_names <= 64)
+        walk_tile<1>(s, o, keys, names, base_p, tile_len, lane);
+    else if (num_names <= 128)
+        walk_tile<2>(s, o, keys, names, base_p, tile_len, lane);
+    else
+        walk_tile<4>(s, o, keys, names, base_p, tile_len, lane);
 }
 
 // ---- RLE2 --------------------------------------------------------------------------------------------
@@ -201,8 +253,9 @@ __global__ void __launch_bounds__(RLE_THREADS) rle_tiles(Batch bt, RleTile *rt)
     uint32_t v[4];
     const uint32_t valid = rle_load(r, q0, n, v);
     int tfirst = INT32_MAX, tlastnz = -1;
-    for (uint32_t k = 0; k < valid; k++) {
-        if ((v[k >> 2] >> ((k & 3) * 8)) & 255u) {
+#pragma unroll
+    for (int k = 0; k < RLE_ITEMS; k++) {
+        if ((uint32_t)k < valid && ((v[k >> 2] >> ((k & 3) * 8)) & 255u)) {
             if (tfirst == INT32_MAX) tfirst = (int)(q0 + k);
             tlastnz = (int)(q0 + k);
         }
@@ -214,8 +267,9 @@ __global__ void __launch_bounds__(RLE_THREADS) rle_tiles(Batch bt, RleTile *rt)
     __syncthreads();
     int cur = threadIdx.x ? ex[threadIdx.x - 1] : -1;
     uint32_t cnt = 0;
-    for (uint32_t k = 0; k < valid; k++) {
-        if ((v[k >> 2] >> ((k & 3) * 8)) & 255u) {
+#pragma unroll
+    for (int k = 0; k < RLE_ITEMS; k++) {
+        if ((uint32_t)k < valid && ((v[k >> 2] >> ((k & 3) * 8)) & 255u)) {
             const int p = (int)(q0 + k);
             cnt += 1 + (cur >= 0 ? run_digits((uint32_t)(p - 1 - cur)) : 0u);
             cur = p;
@@ -302,8 +356,9 @@ __global__ void __launch_bounds__(RLE_THREADS) rle_emit(Batch bt, const RleTile 
     uint32_t v[4];
     const uint32_t valid = rle_load(r, q0, n, v);
     int tlastnz = -1;
-    for (uint32_t k = 0; k < valid; k++)
-        if ((v[k >> 2] >> ((k & 3) * 8)) & 255u) tlastnz = (int)(q0 + k);
+#pragma unroll
+    for (int k = 0; k < RLE_ITEMS; k++)
+        if ((uint32_t)k < valid && ((v[k >> 2] >> ((k & 3) * 8)) & 255u)) tlastnz = (int)(q0 + k);
 
     __shared__ int lm[RLE_THREADS / 64];
     __shared__ int ex[RLE_THREADS];
@@ -315,8 +370,9 @@ __global__ void __launch_bounds__(RLE_THREADS) rle_emit(Batch bt, const RleTile 
     const int cur0 = max(me.last_nz, threadIdx.x ? ex[threadIdx.x - 1] : -1);
     int cur = cur0;
     uint32_t cnt = 0;
-    for (uint32_t k = 0; k < valid; k++) {
-        if ((v[k >> 2] >> ((k & 3) * 8)) & 255u) {
+#pragma unroll
+    for (int k = 0; k < RLE_ITEMS; k++) {
+        if ((uint32_t)k < valid && ((v[k >> 2] >> ((k & 3) * 8)) & 255u)) {
             const int p = (int)(q0 + k);
             cnt += 1 + run_digits((uint32_t)(p - 1 - cur));
             cur = p;
@@ -328,8 +384,9 @@ __global__ void __launch_bounds__(RLE_THREADS) rle_emit(Batch bt, const RleTile 
     uint16_t *out = bt.syms + (size_t)b * (bt.S + 64);
     cur = cur0;
     uint32_t fa = 0, fb = 0;
-    for (uint32_t k = 0; k < valid; k++) {
-        const uint32_t pos = (v[k >> 2] >> ((k & 3) * 8)) & 255u;
+#pragma unroll
+    for (int k = 0; k < RLE_ITEMS; k++) {
+        const uint32_t pos = (uint32_t)k < valid ? ((v[k >> 2] >> ((k & 3) * 8)) & 255u) : 0u;
         if (pos) {
             const int p = (int)(q0 + k);
             const uint32_t z = (uint32_t)(p - 1 - cur);

@@ -408,10 +408,19 @@ struct EmitArgs {
     const uint32_t *first;
 };
 
-// One workgroup = one 4096-byte input tile of one block.  Every input byte yields at most one
-// literal and one count byte; the tile's output is one contiguous byte range (<= 5/4 of the tile),
-// staged in LDS and written out as aligned 32-bit words (ragged edges byte by byte: neighbouring
-// tiles own the other bytes of those words).
+// One workgroup = one 4096-byte input tile of one block.  Nothing is looked up per run: the
+// canonical output offset C and the covering run's start at the tile's first byte come from the
+// plan tables (one lookup per tile); inside the tile, run starts are a max-scan of the start flags
+// and output offsets an add-scan of the per-byte emission counts (0, 1 or 2).  The block's first
+// run (chunking restarted at in_off) uses the closed form instead.  The tile's output is one
+// contiguous byte range (<= 5/4 of the tile), staged in LDS and written as aligned 32-bit words
+// (ragged edges byte by byte: neighbouring tiles own the other bytes of those words).
+__device__ __forceinline__ uint32_t emitted_before(uint32_t d) // canonical bytes of d bytes of a run
+{
+    const uint32_t c = d / 255u, k = d - c * 255u;
+    return 5u * c + (k < 4u ? k : 4u);
+}
+
 __global__ void __launch_bounds__(RL_THREADS) rle1_emit_kernel(EmitArgs ea, Batch bt)
 {
     const uint32_t b = blockIdx.y;
@@ -425,69 +434,106 @@ __global__ void __launch_bounds__(RL_THREADS) rle1_emit_kernel(EmitArgs ea, Batc
         bt.n[b] = d.rle_len;
         bt.desc[b] = d;
     }
+    __shared__ uint32_t ls[RL_THREADS / 64 + 2];
+    __shared__ int lm[RL_THREADS / 64];
+    __shared__ int exm[RL_THREADS];
+    __shared__ uint8_t stage[RL_TILE + RL_TILE / 4 + 16];
+    __shared__ uint32_t oend_s, rst_s;
+    __shared__ uint64_t tc_s;
+
     uint32_t valid, v[4];
     const uint32_t mask = start_mask(ea.in, ea.n, p0, valid, v);
-    __shared__ uint32_t ls[RL_THREADS / 64 + 2];
-    __shared__ uint8_t stage[RL_TILE + RL_TILE / 4 + 16];
-    __shared__ uint32_t obase_s;
-    uint32_t tot;
-    // run index of the byte BEFORE this thread's first byte
-    uint32_t j = ea.tbase[tile] + block_excl_add(__popc(mask), ls, &tot) - 1u;
+    // byte after this thread's 16 (to tell whether its last byte ends a run)
+    uint32_t nextb = 0x100u;
+    if (valid == RL_ITEMS && p0 + RL_ITEMS < ea.n) nextb = ea.in[p0 + RL_ITEMS];
 
+    // block constants and tile carries (one thread, a handful of table reads)
     const uint32_t jf = ea.first[b];
-    const uint64_t pof = ea.po[jf + 1];
-    const uint32_t A = canon_len((uint32_t)(ea.rs[jf + 1] - d.in_off));
-    // first / last input position of this tile that belongs to the block
-    const uint64_t pfirst = tile0 > d.in_off ? tile0 : d.in_off;
-
-    uint32_t curj = 0xFFFFFFFFu, rend = 0, origin = 0, base = 0;
-    uint32_t offs[RL_ITEMS]; // block-relative output offset of the byte's chunk
-    uint32_t kks[RL_ITEMS];  // position inside the chunk | 0x100 if it also emits the count byte
-    uint32_t inblk = 0;
-    uint32_t lastend = 0; // output offset just past everything this thread emits
-    for (uint32_t k = 0; k < valid; k++) {
-        if (mask & (1u << k)) j++;
-        const uint64_t p = p0 + k;
-        offs[k] = 0;
-        kks[k] = 0;
-        if (p < d.in_off || p >= in_end) continue;
-        if (j != curj) {
-            curj = j;
-            const uint32_t rstart = ea.rs[j];
-            rend = ea.rs[j + 1];
-            if (rstart <= d.in_off) { // the run the block starts in: chunking restarts at in_off
-                origin = (uint32_t)d.in_off;
-                base = 0;
-            } else {
-                origin = rstart;
-                base = A + (uint32_t)(ea.po[j] - pof);
-            }
-        }
-        const uint32_t dd = (uint32_t)p - origin;
-        const uint32_t c = dd / 255u, kk = dd - c * 255u;
-        const bool cnt_byte = kk >= 3u && (kk == 254u || p + 1 == rend); // lib/rle.rs:212-226
-        offs[k] = base + 5u * c;
-        kks[k] = kk | (cnt_byte ? 0x100u : 0u);
-        inblk |= 1u << k;
-        if (p == pfirst) obase_s = offs[k] + (kk < 4u ? kk : 4u); // first byte this tile emits
-        const uint32_t e = offs[k] + (cnt_byte ? 5u : (kk < 4u ? kk + 1u : 0u));
-        lastend = e > lastend ? e : lastend;
+    const uint32_t e_first = ea.rs[jf + 1];                      // end of the run the block starts in
+    const uint32_t A = canon_len(e_first - (uint32_t)d.in_off);   // its RLE1 bytes after the restart
+    const uint64_t Ce = ea.po[jf + 1];                            // canonical offset at e_first
+    if (threadIdx.x == 0) {
+        const bool starts = mask & 1u;                            // tile's first byte starts a run
+        const uint32_t j0 = ea.tbase[tile] - (starts ? 0u : 1u);
+        const uint32_t rs0 = ea.rs[j0];
+        rst_s = rs0;
+        tc_s = ea.po[j0] + emitted_before((uint32_t)tile0 - rs0);
+        oend_s = 0;
     }
-    __shared__ uint32_t oend_s;
-    if (threadIdx.x == 0) oend_s = 0;
+    // run start of every byte: max-scan of start positions, carried in from the covering run
+    int tl = mask ? (int)(threadIdx.x * RL_ITEMS) + (31 - __clz((int)mask)) : -1;
+    exm[threadIdx.x] = block_incl_max(tl, lm);
     __syncthreads();
+    const uint32_t rst = rst_s;
+    const int carry = threadIdx.x ? exm[threadIdx.x - 1] : -1; // tile-relative start of the open run, -1 = rst
+    // canonical emission count per byte (2 bits) + "ends its run" (1 bit), packed 4 bits per byte
+    const uint32_t rs_in = carry >= 0 ? (uint32_t)tile0 + (uint32_t)carry : rst;
+    uint32_t cur_rs = rs_in;
+    unsigned long long em = 0;
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int k = 0; k < RL_ITEMS; k++) {
+        if ((uint32_t)k < valid) {
+            const uint32_t p = (uint32_t)p0 + k;
+            if (mask & (1u << k)) cur_rs = p;
+            const uint32_t byte = (v[k >> 2] >> ((k & 3) * 8)) & 255u;
+            const uint32_t nb = ((uint32_t)k + 1 < valid) ? ((v[((k + 1) & 15) >> 2] >> (((k + 1) & 3) * 8)) & 255u) : nextb;
+            const bool is_last = nb != byte;
+            const uint32_t kk = (p - cur_rs) % 255u;
+            const uint32_t can = (kk < 4u ? 1u : 0u) + ((kk >= 3u && (kk == 254u || is_last)) ? 1u : 0u);
+            em |= (unsigned long long)(can | (is_last ? 4u : 0u)) << (4 * k);
+            tsum += can;
+        }
+    }
+    uint32_t tot;
+    uint32_t ps = block_excl_add(tsum, ls, &tot); // canonical bytes of the tile before this thread
+    const uint64_t tc = tc_s;
+    // offset of the first byte this tile can emit (uniform): its first in-block position
+    const uint32_t in_off32 = (uint32_t)d.in_off;
+    uint32_t obase;
+    if (tile0 <= d.in_off)
+        obase = 0; // the block starts in this tile
+    else if (rst <= in_off32)
+        obase = emitted_before((uint32_t)tile0 - in_off32); // still inside the block's first run
+    else
+        obase = A + (uint32_t)(tc - Ce);
+
+    uint32_t lastend = 0;
+    cur_rs = rs_in;
+#pragma unroll
+    for (int k = 0; k < RL_ITEMS; k++) {
+        if ((uint32_t)k < valid) {
+            const uint32_t p = (uint32_t)p0 + k;
+            if (mask & (1u << k)) cur_rs = p;
+            const uint32_t e4 = (uint32_t)(em >> (4 * k)) & 15u;
+            const uint32_t can = e4 & 3u;
+            const bool is_last = e4 & 4u;
+            if (p0 + k >= d.in_off && p0 + k < in_end) {
+                uint32_t off, lit, cnt, kk;
+                if (cur_rs <= in_off32) { // the block's first run: chunking restarts at in_off
+                    const uint32_t dd = p - in_off32;
+                    kk = dd % 255u;
+                    off = emitted_before(dd);
+                    lit = kk < 4u;
+                    cnt = kk >= 3u && (kk == 254u || is_last); // lib/rle.rs:212-226
+                } else {
+                    kk = (p - cur_rs) % 255u;
+                    off = A + (uint32_t)(tc + ps - Ce);
+                    lit = kk < 4u;
+                    cnt = can - lit;
+                }
+                const uint32_t o = off - obase;
+                if (lit) stage[o] = (uint8_t)((v[k >> 2] >> ((k & 3) * 8)) & 255u);
+                if (cnt) stage[o + lit] = (uint8_t)(kk - 3u);
+                const uint32_t e = off + lit + cnt;
+                lastend = e > lastend ? e : lastend;
+            }
+            ps += can;
+        }
+    }
     atomicMax(&oend_s, lastend);
     __syncthreads();
-    const uint32_t obase = obase_s;
     const uint32_t nout = oend_s > obase ? oend_s - obase : 0;
-    for (uint32_t k = 0; k < valid; k++) {
-        if (!(inblk & (1u << k))) continue;
-        const uint32_t kk = kks[k] & 0xFFu;
-        const uint32_t byte = (v[k >> 2] >> ((k & 3) * 8)) & 255u;
-        if (kk < 4u) stage[offs[k] + kk - obase] = (uint8_t)byte;
-        if (kks[k] & 0x100u) stage[offs[k] + 4u - obase] = (uint8_t)(kk - 3u);
-    }
-    __syncthreads();
     uint8_t *out = bt.rle + (size_t)b * bt.S + obase;
     // head bytes up to the first 4-byte aligned address, aligned words, tail bytes
     const uint32_t mis = (uint32_t)((uintptr_t)out & 3u);
