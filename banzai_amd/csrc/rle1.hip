@@ -11,38 +11,61 @@
 //     except that the 4th literal of a chunk is only taken when its count byte fits too
 //     (bound checks at :136-151, :179-182, :193-203); so a block may end at M-1 bytes.
 //
-// Plan (whole input, parallel):  run-start flags -> per-tile counts -> scan -> run table RS[],
-// canonical output length per run -> scan -> PO[].  Splitting (one wavefront, sequential over
-// blocks, 64-ary searches in PO) yields every block's (in_off, in_len, rle_len, first run).
-// CRC-32/BZIP2 per block: per-thread table CRC of 32-byte pieces, shifted by x^(8*bytes_after)
-// with GF(2) multiplies, XOR-reduced (CRC is linear), init/xorout folded in at the end.
-// Emit (per batch): one thread per input byte places its literal and, at chunk ends, the count.
+// Plan (whole input, parallel, two sweeps of the input, no per-run tables): per 64-byte granule
+//   rsg  = start of the run covering the granule's first byte   (prefix max of run starts)
+//   nrsg = first run start at or after the granule              (suffix min of run starts)
+//   cg   = canonical RLE1 bytes emitted before the granule, relative to its 4096-byte tile,
+//          plus tc[tile] = canonical bytes before the tile      (prefix sums of emission counts)
+// Splitting (one wavefront, sequential over blocks: block k+1 starts where k ended): 64-ary
+// searches in tc / cg find the granule where the budget runs out, the 64 lanes evaluate that
+// granule byte-parallel (run starts by max-scan, emission prefix by add-scan) and the closed form
+// cuts inside the run.  CRC-32/BZIP2 per block: per-thread table CRC of 32-byte pieces, shifted
+// by x^(8*bytes_after) with GF(2) multiplies, XOR-reduced (CRC is linear), init/xorout folded in.
+// Emit (per batch): one thread per 16 input bytes, offsets by in-tile scans, output staged in LDS.
 #include "common.h"
 
 constexpr int RL_THREADS = 256;
 constexpr int RL_ITEMS = 16;
 constexpr uint32_t RL_TILE = RL_THREADS * RL_ITEMS; // 4096 input bytes per workgroup
+constexpr uint32_t GRAN = 64;                       // bytes per granule = one wavefront of the splitter
+constexpr uint32_t GRAN_PER_TILE = RL_TILE / GRAN;  // 64
+constexpr uint32_t NONE32 = 0xFFFFFFFFu;
+
+struct BlockAux { // per planned block: what the emit kernel needs about the run the block starts in
+    uint64_t Ce;      // canonical offset at the end of that run
+    uint32_t A;       // RLE1 bytes of that run's remainder (chunking restarted at in_off)
+    uint32_t e_first; // end of that run
+};
 
 struct PlanArrays {
     const uint8_t *in;
     uint64_t n;
-    uint32_t ntiles;   // input tiles
-    uint32_t *tbase;   // [ntiles+1] run starts before each tile (exclusive scan of counts)
-    uint32_t *rs;      // [J+1] run start positions, rs[J] = n
-    uint64_t *po;      // [J+1] canonical output offset of each run, po[J] = total
-    uint64_t *rtsum;   // [run tiles + 1] scan scratch
-    uint32_t *nruns;   // [1] J
-    BlockDesc *blocks; // [maxblocks]
-    uint32_t *first;   // [maxblocks] index of the run containing in_off
-    uint32_t *nblocks; // [1]
-    uint32_t maxblocks;
+    uint32_t ntiles;
+    uint32_t ngran;
     uint32_t M;
+    uint32_t maxblocks;
+    uint32_t *lrs;     // [ntiles]   last run start inside the tile (NONE32 if none); then exclusive prefix max
+    uint32_t *frs;     // [ntiles+1] first run start inside the tile; then suffix min (frs[ntiles] = n)
+    uint32_t *csum;    // [ntiles]   canonical bytes emitted by the tile
+    uint64_t *tc;      // [ntiles+1] exclusive scan of csum
+    uint32_t *cg;      // [ngran]
+    uint32_t *rsg;     // [ngran]
+    uint32_t *nrsg;    // [ngran+1]  nrsg[ngran] = n
+    BlockDesc *blocks; // [maxblocks]
+    BlockAux *aux;     // [maxblocks]
+    uint32_t *nblocks; // [1]
 };
 
 __device__ __forceinline__ uint32_t canon_len(uint32_t L) // RLE1 bytes of a run of L equal bytes
 {
     const uint32_t q = L / 255u, r = L - q * 255u;
     return 5u * q + (r < 4u ? r : 5u);
+}
+
+__device__ __forceinline__ uint32_t emitted_before(uint32_t d) // canonical bytes of the first d bytes of a run
+{
+    const uint32_t c = d / 255u, k = d - c * 255u;
+    return 5u * c + (k < 4u ? k : 4u);
 }
 
 // 16 input bytes at p0 (p0 and `in` 16-byte aligned); the ragged tail is read byte by byte so
@@ -80,45 +103,151 @@ __device__ __forceinline__ uint32_t start_mask(const uint8_t *in, uint64_t n, ui
     return mask;
 }
 
-__global__ void __launch_bounds__(RL_THREADS) plan_count(PlanArrays pa)
+// ---- plan sweep 1: first / last run start of every tile ------------------------------------------------
+__global__ void __launch_bounds__(RL_THREADS) plan_starts(PlanArrays pa)
 {
     const uint32_t tile = blockIdx.x;
     const uint64_t p0 = (uint64_t)tile * RL_TILE + threadIdx.x * RL_ITEMS;
     uint32_t valid, v[4];
-    const uint32_t cnt = __popc(start_mask(pa.in, pa.n, p0, valid, v));
-    __shared__ uint32_t ls[RL_THREADS / 64 + 2];
-    uint32_t tot;
-    (void)block_excl_add(cnt, ls, &tot);
-    if (threadIdx.x == 0) pa.tbase[tile] = tot;
+    const uint32_t mask = start_mask(pa.in, pa.n, p0, valid, v);
+    int last = mask ? (int)((uint32_t)p0 + 31u - (uint32_t)__clz((int)mask)) : -1;
+    uint32_t first = mask ? (uint32_t)p0 + (uint32_t)__ffs((int)mask) - 1u : NONE32;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        last = max(last, __shfl_xor(last, d, 64));
+        first = min(first, (uint32_t)__shfl_xor((int)first, d, 64));
+    }
+    __shared__ int sl[RL_THREADS / 64];
+    __shared__ uint32_t sf[RL_THREADS / 64];
+    if ((threadIdx.x & 63) == 0) {
+        sl[threadIdx.x >> 6] = last;
+        sf[threadIdx.x >> 6] = first;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < RL_THREADS / 64; w++) {
+            last = max(last, sl[w]);
+            first = min(first, sf[w]);
+        }
+        pa.lrs[tile] = last < 0 ? NONE32 : (uint32_t)last;
+        pa.frs[tile] = first;
+    }
 }
 
-// Single workgroup: exclusive scan of 32-bit counts (in place), total to out[count] and *total.
-__global__ void __launch_bounds__(1024) scan_u32(uint32_t *v, uint32_t count, uint32_t *total)
+// Single workgroup: lrs -> exclusive prefix max (run start covering each tile's first byte, unless
+// that byte starts a run itself); frs -> suffix min (first run start at or after each tile).
+__global__ void __launch_bounds__(1024) plan_carries(PlanArrays pa)
 {
-    __shared__ uint32_t ls[20];
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < count; base += 1024) {
-        const uint32_t e = base + threadIdx.x;
-        const uint32_t x = e < count ? v[e] : 0;
-        uint32_t tot;
-        const uint32_t ex = block_excl_add(x, ls, &tot);
-        if (e < count) v[e] = carry + ex;
-        carry += tot;
+    __shared__ uint32_t sh[1024];
+    const uint32_t t = threadIdx.x, NT = pa.ntiles;
+    // prefix max; NONE32 means "no start yet" -> treat as 0 candidates via +1 encoding
+    uint32_t carry = 0; // encoded value = position + 1, 0 = none
+    for (uint32_t base = 0; base < NT; base += 1024) {
+        const uint32_t e = base + t;
+        const uint32_t raw = e < NT ? pa.lrs[e] : NONE32;
+        sh[t] = raw == NONE32 ? 0u : raw + 1u;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1) {
+            const uint32_t x = t >= d ? sh[t - d] : 0u;
+            __syncthreads();
+            sh[t] = max(sh[t], x);
+            __syncthreads();
+        }
+        const uint32_t excl = max(carry, t ? sh[t - 1] : 0u);
+        if (e < NT) pa.lrs[e] = excl ? excl - 1u : NONE32;
+        const uint32_t tot = sh[1023];
+        __syncthreads();
+        carry = max(carry, tot);
+    }
+    // suffix min over frs, frs[NT] = n
+    uint32_t scarry = (uint32_t)pa.n;
+    if (t == 0) pa.frs[NT] = (uint32_t)pa.n;
+    const uint32_t nchunks = (NT + 1023) / 1024;
+    for (uint32_t c = nchunks; c-- > 0;) {
+        const uint32_t e = c * 1024 + t;
+        sh[t] = e < NT ? pa.frs[e] : NONE32;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1) {
+            const uint32_t x = t + d < 1024 ? sh[t + d] : NONE32;
+            __syncthreads();
+            sh[t] = min(sh[t], x);
+            __syncthreads();
+        }
+        if (e < NT) pa.frs[e] = min(sh[t], scarry);
+        const uint32_t tot = sh[0];
+        __syncthreads();
+        scarry = min(scarry, tot);
+    }
+}
+
+// ---- plan sweep 2: per-granule tables and per-tile canonical byte counts -----------------------------------
+__global__ void __launch_bounds__(RL_THREADS) plan_granules(PlanArrays pa)
+{
+    const uint32_t tile = blockIdx.x;
+    const uint64_t tile0 = (uint64_t)tile * RL_TILE;
+    const uint64_t p0 = tile0 + threadIdx.x * RL_ITEMS;
+    uint32_t valid, v[4];
+    const uint32_t mask = start_mask(pa.in, pa.n, p0, valid, v);
+    uint32_t nextb = 0x100u;
+    if (valid == RL_ITEMS && p0 + RL_ITEMS < pa.n) nextb = pa.in[p0 + RL_ITEMS];
+    __shared__ uint32_t ls[RL_THREADS / 64 + 2];
+    __shared__ int lm[RL_THREADS / 64];
+    __shared__ int exm[RL_THREADS];
+    __shared__ uint32_t sfirst[RL_THREADS];
+    // run start covering each thread's first byte
+    int tl = mask ? (int)(threadIdx.x * RL_ITEMS) + (31 - __clz((int)mask)) : -1;
+    exm[threadIdx.x] = block_incl_max(tl, lm);
+    sfirst[threadIdx.x] = mask ? (uint32_t)p0 + (uint32_t)__ffs((int)mask) - 1u : NONE32;
+    __syncthreads();
+    const uint32_t rst = pa.lrs[tile]; // exclusive prefix max (NONE32 only for tile 0, whose byte 0 starts a run)
+    const int carry = threadIdx.x ? exm[threadIdx.x - 1] : -1;
+    const uint32_t rs_in = carry >= 0 ? (uint32_t)tile0 + (uint32_t)carry : rst;
+    uint32_t cur_rs = rs_in, tsum = 0;
+#pragma unroll
+    for (int k = 0; k < RL_ITEMS; k++) {
+        if ((uint32_t)k < valid) {
+            const uint32_t p = (uint32_t)p0 + k;
+            if (mask & (1u << k)) cur_rs = p;
+            const uint32_t byte = (v[k >> 2] >> ((k & 3) * 8)) & 255u;
+            const uint32_t nb = ((uint32_t)k + 1 < valid) ? ((v[((k + 1) & 15) >> 2] >> (((k + 1) & 3) * 8)) & 255u) : nextb;
+            const uint32_t kk = (p - cur_rs) % 255u;
+            tsum += (kk < 4u ? 1u : 0u) + ((kk >= 3u && (kk == 254u || nb != byte)) ? 1u : 0u);
+        }
+    }
+    uint32_t tot;
+    const uint32_t ps = block_excl_add(tsum, ls, &tot);
+    // suffix min of first run starts over the threads of the tile (Hillis-Steele, 8 steps)
+    for (uint32_t dd = 1; dd < RL_THREADS; dd <<= 1) {
+        const uint32_t x = threadIdx.x + dd < RL_THREADS ? sfirst[threadIdx.x + dd] : NONE32;
+        __syncthreads();
+        sfirst[threadIdx.x] = min(sfirst[threadIdx.x], x);
+        __syncthreads();
+    }
+    if ((threadIdx.x & 3u) == 0) {
+        const size_t g = (size_t)tile * GRAN_PER_TILE + (threadIdx.x >> 2);
+        if (p0 < pa.n) {
+            pa.cg[g] = ps;
+            pa.rsg[g] = (mask & 1u) ? (uint32_t)p0 : rs_in;
+            pa.nrsg[g] = min(sfirst[threadIdx.x], pa.frs[tile + 1]);
+        } else {
+            pa.nrsg[g] = (uint32_t)pa.n; // granule past the end of the input
+        }
     }
     if (threadIdx.x == 0) {
-        v[count] = carry;
-        if (total) *total = carry;
+        pa.csum[tile] = tot;
+        if (tile == 0) pa.nrsg[pa.ngran] = (uint32_t)pa.n;
     }
 }
 
-__global__ void __launch_bounds__(1024) scan_u64(uint64_t *v, uint32_t count)
+// Single workgroup: tc = exclusive scan of csum (64-bit), tc[ntiles] = total.
+__global__ void __launch_bounds__(1024) plan_tc(PlanArrays pa)
 {
     __shared__ uint64_t sh[1024];
     uint64_t carry = 0;
-    const uint32_t t = threadIdx.x;
-    for (uint32_t base = 0; base < count; base += 1024) {
+    const uint32_t t = threadIdx.x, NT = pa.ntiles;
+    for (uint32_t base = 0; base < NT; base += 1024) {
         const uint32_t e = base + t;
-        sh[t] = e < count ? v[e] : 0;
+        sh[t] = e < NT ? pa.csum[e] : 0;
         __syncthreads();
         for (uint32_t d = 1; d < 1024; d <<= 1) {
             const uint64_t x = t >= d ? sh[t - d] : 0;
@@ -126,66 +255,12 @@ __global__ void __launch_bounds__(1024) scan_u64(uint64_t *v, uint32_t count)
             sh[t] += x;
             __syncthreads();
         }
-        if (e < count) v[e] = carry + (t ? sh[t - 1] : 0);
+        if (e < NT) pa.tc[e] = carry + (t ? sh[t - 1] : 0);
         const uint64_t tot = sh[1023];
         __syncthreads();
         carry += tot;
     }
-    if (t == 0) v[count] = carry;
-}
-
-__global__ void __launch_bounds__(RL_THREADS) plan_runs(PlanArrays pa)
-{
-    const uint32_t tile = blockIdx.x;
-    const uint64_t p0 = (uint64_t)tile * RL_TILE + threadIdx.x * RL_ITEMS;
-    uint32_t valid, v[4];
-    const uint32_t mask = start_mask(pa.in, pa.n, p0, valid, v);
-    __shared__ uint32_t ls[RL_THREADS / 64 + 2];
-    uint32_t tot;
-    uint32_t j = pa.tbase[tile] + block_excl_add(__popc(mask), ls, &tot);
-    for (uint32_t m = mask; m; m &= m - 1) pa.rs[j++] = (uint32_t)(p0 + (uint32_t)__ffs(m) - 1u);
-    if (tile == 0 && threadIdx.x == 0) pa.rs[pa.tbase[pa.ntiles]] = (uint32_t)pa.n;
-}
-
-// Canonical output length per run, tile sums (phase 0) / offsets (phase 1) over tiles of 4096 runs.
-__global__ void __launch_bounds__(RL_THREADS) plan_outlen(PlanArrays pa, int phase)
-{
-    const uint32_t J = *pa.nruns;
-    const uint32_t j0 = blockIdx.x * RL_TILE + threadIdx.x * RL_ITEMS;
-    if (blockIdx.x * RL_TILE >= J) return;
-    uint32_t ol[RL_ITEMS];
-    uint32_t sum = 0;
-    if (j0 < J) {
-        uint32_t prev = pa.rs[j0];
-#pragma unroll
-        for (int k = 0; k < RL_ITEMS; k++) {
-            ol[k] = 0;
-            if (j0 + k < J) {
-                const uint32_t nx = pa.rs[j0 + k + 1];
-                ol[k] = canon_len(nx - prev);
-                prev = nx;
-            }
-            sum += ol[k];
-        }
-    }
-    __shared__ uint32_t ls[RL_THREADS / 64 + 2];
-    uint32_t tot;
-    const uint32_t ex = block_excl_add(sum, ls, &tot);
-    if (phase == 0) {
-        if (threadIdx.x == 0) pa.rtsum[blockIdx.x] = tot;
-        return;
-    }
-    if (j0 < J) {
-        uint64_t off = pa.rtsum[blockIdx.x] + ex;
-#pragma unroll
-        for (int k = 0; k < RL_ITEMS; k++) {
-            if (j0 + k < J) {
-                pa.po[j0 + k] = off;
-                off += ol[k];
-            }
-        }
-        if (j0 + RL_ITEMS >= J) pa.po[J] = off; // the thread holding the last run
-    }
+    if (t == 0) pa.tc[NT] = carry;
 }
 
 // ---- block splitting: one wavefront, sequential over blocks ----------------------------------------------
@@ -198,58 +273,132 @@ __device__ __forceinline__ void cut_in_run(uint32_t Lr, uint32_t R, uint32_t &k,
     t = ell >= 4u ? (rho < 3u ? rho : 3u) : rho;
 }
 
+struct Gran { // one 64-byte granule seen by the wavefront, lane l = byte g*64+l
+    uint32_t pos;  // byte position of this lane
+    bool valid;    // pos < n
+    bool start;    // this byte starts a run
+    uint64_t cpos; // canonical RLE1 bytes emitted before this byte
+};
+
+__device__ __forceinline__ Gran gran_eval(const PlanArrays &pa, uint32_t g, uint32_t lane)
+{
+    Gran r;
+    const uint32_t n = (uint32_t)pa.n;
+    r.pos = g * GRAN + lane;
+    r.valid = r.pos < n;
+    const uint32_t byte = r.valid ? pa.in[r.pos] : 0x100u;
+    uint32_t prevb = (uint32_t)__shfl_up((int)byte, 1, 64);
+    if (lane == 0) prevb = r.pos ? pa.in[r.pos - 1] : 0x200u;
+    uint32_t nextb = (uint32_t)__shfl_down((int)byte, 1, 64);
+    if (lane == 63) nextb = r.pos + 1 < n ? pa.in[r.pos + 1] : 0x100u;
+    r.start = r.valid && byte != prevb;
+    const bool is_last = nextb != byte;
+    const int own = r.start ? (int)lane : -1;
+    const int ms = wave_incl_max(own, (int)lane);
+    const uint32_t rs = ms >= 0 ? g * GRAN + (uint32_t)ms : pa.rsg[g];
+    const uint32_t kk = (r.pos - rs) % 255u;
+    const uint32_t em = r.valid ? ((kk < 4u ? 1u : 0u) + ((kk >= 3u && (kk == 254u || is_last)) ? 1u : 0u)) : 0u;
+    const uint32_t inc = wave_incl_add(em, (int)lane);
+    r.cpos = pa.tc[g / GRAN_PER_TILE] + pa.cg[g] + (inc - em);
+    return r;
+}
+
+// First run start at a position > s (n if there is none).
+__device__ __forceinline__ uint32_t next_start_after(const PlanArrays &pa, uint32_t s, uint32_t lane)
+{
+    const uint32_t g = s / GRAN;
+    const uint32_t pos = g * GRAN + lane;
+    const uint32_t n = (uint32_t)pa.n;
+    const uint32_t byte = pos < n ? pa.in[pos] : 0x100u;
+    uint32_t prevb = (uint32_t)__shfl_up((int)byte, 1, 64);
+    if (lane == 0) prevb = pos ? pa.in[pos - 1] : 0x200u;
+    const unsigned long long m = __ballot(pos < n && pos > s && byte != prevb);
+    if (m) return g * GRAN + (uint32_t)__ffsll((long long)m) - 1u;
+    return pa.nrsg[g + 1 <= pa.ngran ? g + 1 : pa.ngran];
+}
+
 __global__ void __launch_bounds__(64) plan_split(PlanArrays pa)
 {
     const uint32_t lane = threadIdx.x;
-    const uint32_t J = *pa.nruns;
-    const uint64_t N = pa.n;
-    const uint32_t M = pa.M;
-    uint64_t s = 0;
-    uint32_t j0 = 0, nb = 0;
+    const uint32_t N = (uint32_t)pa.n, M = pa.M, NT = pa.ntiles;
+    const uint64_t total = pa.tc[NT];
+    uint32_t s = 0, nb = 0;
     while (s < N && nb < pa.maxblocks) {
-        const uint32_t Lr = (uint32_t)(pa.rs[j0 + 1] - s);
+        const uint32_t e_first = next_start_after(pa, s, lane);
+        const uint32_t Lr = e_first - s;
         const uint32_t A = canon_len(Lr);
-        uint64_t consumed;
-        uint32_t out, nj0;
-        uint64_t ns;
-        if (A > M) {
+        uint32_t consumed, out;
+        uint64_t Ce = 0;
+        if (A > M) { // the budget runs out inside the run the block starts in
             uint32_t k, t;
             cut_in_run(Lr, M, k, t);
-            consumed = 255ull * k + t;
+            consumed = 255u * k + t;
             out = 5u * k + t;
-            ns = s + consumed;
-            nj0 = j0;
         } else {
-            const uint64_t pj = pa.po[j0 + 1];
-            const uint64_t lim = (uint64_t)(M - A) + pj;
-            // largest x in [j0+1, J] with po[x] <= lim (po strictly increasing), 64-ary search
-            uint32_t lo = j0 + 1, hi = J;
-            while (lo < hi) {
-                const uint32_t span = hi - lo;
-                const uint32_t step = (span + 63u) / 64u;
-                const uint64_t x = (uint64_t)lo + (uint64_t)(lane + 1) * step;
-                const bool ok = x <= hi && pa.po[x] <= lim;
-                const uint32_t c = (uint32_t)__popcll(__ballot(ok));
-                lo += c * step;
-                const uint64_t nh = (uint64_t)lo + step - 1;
-                if (nh < hi) hi = (uint32_t)nh;
-            }
-            const uint32_t x = lo;
-            const uint32_t cum = A + (uint32_t)(pa.po[x] - pj);
-            if (x == J) {
-                consumed = N - s;
-                out = cum;
-                ns = N;
-                nj0 = J;
+            if (e_first >= N) {
+                Ce = total;
             } else {
-                const uint32_t rsx = pa.rs[x];
-                const uint32_t Lx = pa.rs[x + 1] - rsx;
+                const Gran ge = gran_eval(pa, e_first / GRAN, lane);
+                Ce = __shfl(ge.cpos, (int)(e_first % GRAN), 64);
+            }
+            const uint64_t lim = (uint64_t)(M - A) + Ce; // largest canonical offset that still fits
+            if (total <= lim) { // everything to the end of the input fits
+                consumed = N - s;
+                out = A + (uint32_t)(total - Ce);
+            } else {
+                // last tile with tc <= lim: probe 64 tiles around the literal-text guess, else 64-ary search
+                uint32_t lo = e_first / RL_TILE, hi = NT - 1; // tc[lo] <= Ce <= lim
+                {
+                    long long guess = (long long)lo + (long long)((lim - Ce) / RL_TILE) - 40;
+                    if (guess < (long long)lo) guess = lo;
+                    if (guess > (long long)hi) guess = hi;
+                    const uint32_t w0 = (uint32_t)guess; // lo <= w0 <= hi
+                    const uint32_t x = w0 + lane;
+                    const bool ok = x <= hi && pa.tc[x] <= lim;
+                    const unsigned long long m = __ballot(ok); // tc is nondecreasing: a prefix of the window
+                    if (m & 1ull) {
+                        const uint32_t c = (uint32_t)__popcll(m);
+                        lo = w0 + c - 1;
+                        if (c < 64) hi = lo; // tc[lo+1] > lim or lo is the last tile
+                    } else {
+                        hi = w0 - 1; // tc[w0] > lim, and w0 > lo because tc[lo] <= lim
+                    }
+                }
+                while (lo < hi) {
+                    const uint32_t span = hi - lo;
+                    const uint32_t step = (span + 63u) / 64u;
+                    const uint64_t x = (uint64_t)lo + (uint64_t)(lane + 1) * step;
+                    const bool ok = x <= hi && pa.tc[x] <= lim;
+                    const uint32_t c = (uint32_t)__popcll(__ballot(ok));
+                    lo += c * step;
+                    const uint64_t nh = (uint64_t)lo + step - 1;
+                    if (nh < hi) hi = (uint32_t)nh;
+                }
+                const uint32_t tl = lo;
+                // last granule of that tile whose start offset is <= lim
+                const uint32_t gb = tl * GRAN_PER_TILE;
+                const uint32_t gidx = gb + lane;
+                const bool gok = (uint64_t)gidx * GRAN < pa.n && pa.tc[tl] + pa.cg[gidx] <= lim;
+                const uint32_t gx = gb + (uint32_t)__popcll(__ballot(gok)) - 1u; // lane 0 always ok
+                const Gran gr = gran_eval(pa, gx, lane);
+                // last run start in the granule that still fits, else the run covering the granule
+                const unsigned long long fit = __ballot(gr.start && gr.cpos <= lim);
+                uint32_t x;
+                uint64_t Cx;
+                if (fit) {
+                    const int l = 63 - __clzll((long long)fit);
+                    x = gx * GRAN + (uint32_t)l;
+                    Cx = __shfl(gr.cpos, l, 64);
+                } else {
+                    x = pa.rsg[gx];
+                    Cx = __shfl(gr.cpos, 0, 64) - emitted_before(gx * GRAN - x);
+                }
+                const uint32_t R = (uint32_t)(lim - Cx); // budget left for the run starting at x
+                const uint32_t Lx = next_start_after(pa, x, lane) - x;
                 uint32_t k, t;
-                cut_in_run(Lx, M - cum, k, t);
-                consumed = (uint64_t)rsx - s + 255ull * k + t;
-                out = cum + 5u * k + t;
-                ns = (uint64_t)rsx + 255ull * k + t;
-                nj0 = x;
+                cut_in_run(Lx, R, k, t);
+                consumed = x - s + 255u * k + t;
+                out = M - R + 5u * k + t;
             }
         }
         if (lane == 0) {
@@ -259,11 +408,14 @@ __global__ void __launch_bounds__(64) plan_split(PlanArrays pa)
             d.rle_len = out;
             d.crc = 0;
             pa.blocks[nb] = d;
-            pa.first[nb] = j0;
+            BlockAux ax;
+            ax.Ce = Ce;
+            ax.A = A;
+            ax.e_first = e_first;
+            pa.aux[nb] = ax;
         }
         nb++;
-        s = ns;
-        j0 = nj0;
+        s += consumed;
     }
     if (lane == 0) *pa.nblocks = (s < N) ? 0xFFFFFFFFu : nb; // overflow marker
 }
@@ -401,26 +553,19 @@ static int crc_tables(bzh_ctx *ctx, const CrcTables **out)
 struct EmitArgs {
     const uint8_t *in;
     uint64_t n;
-    const uint32_t *tbase;
-    const uint32_t *rs;
-    const uint64_t *po;
+    const uint32_t *rsg;
+    const uint64_t *tc;
     const BlockDesc *blocks; // plan blocks, already offset to the batch's first block
-    const uint32_t *first;
+    const BlockAux *aux;
 };
 
 // One workgroup = one 4096-byte input tile of one block.  Nothing is looked up per run: the
-// canonical output offset C and the covering run's start at the tile's first byte come from the
-// plan tables (one lookup per tile); inside the tile, run starts are a max-scan of the start flags
-// and output offsets an add-scan of the per-byte emission counts (0, 1 or 2).  The block's first
-// run (chunking restarted at in_off) uses the closed form instead.  The tile's output is one
-// contiguous byte range (<= 5/4 of the tile), staged in LDS and written as aligned 32-bit words
-// (ragged edges byte by byte: neighbouring tiles own the other bytes of those words).
-__device__ __forceinline__ uint32_t emitted_before(uint32_t d) // canonical bytes of d bytes of a run
-{
-    const uint32_t c = d / 255u, k = d - c * 255u;
-    return 5u * c + (k < 4u ? k : 4u);
-}
-
+// canonical output offset and the covering run's start at the tile's first byte come from the plan
+// tables (one lookup per tile); inside the tile, run starts are a max-scan of the start flags and
+// output offsets an add-scan of the per-byte emission counts (0, 1 or 2).  The block's first run
+// (chunking restarted at in_off) uses the closed form instead.  The tile's output is one contiguous
+// byte range (<= 5/4 of the tile), staged in LDS and written as aligned 32-bit words (ragged edges
+// byte by byte: neighbouring tiles own the other bytes of those words).
 __global__ void __launch_bounds__(RL_THREADS) rle1_emit_kernel(EmitArgs ea, Batch bt)
 {
     const uint32_t b = blockIdx.y;
@@ -448,16 +593,12 @@ __global__ void __launch_bounds__(RL_THREADS) rle1_emit_kernel(EmitArgs ea, Batc
     if (valid == RL_ITEMS && p0 + RL_ITEMS < ea.n) nextb = ea.in[p0 + RL_ITEMS];
 
     // block constants and tile carries (one thread, a handful of table reads)
-    const uint32_t jf = ea.first[b];
-    const uint32_t e_first = ea.rs[jf + 1];                      // end of the run the block starts in
-    const uint32_t A = canon_len(e_first - (uint32_t)d.in_off);   // its RLE1 bytes after the restart
-    const uint64_t Ce = ea.po[jf + 1];                            // canonical offset at e_first
+    const BlockAux ax = ea.aux[b];
+    const uint32_t A = ax.A;   // RLE1 bytes of the run the block starts in, after the restart
+    const uint64_t Ce = ax.Ce; // canonical offset at that run's end
     if (threadIdx.x == 0) {
-        const bool starts = mask & 1u;                            // tile's first byte starts a run
-        const uint32_t j0 = ea.tbase[tile] - (starts ? 0u : 1u);
-        const uint32_t rs0 = ea.rs[j0];
-        rst_s = rs0;
-        tc_s = ea.po[j0] + emitted_before((uint32_t)tile0 - rs0);
+        rst_s = ea.rsg[(size_t)tile * GRAN_PER_TILE]; // start of the run covering the tile's first byte
+        tc_s = ea.tc[tile];                           // canonical RLE1 bytes before the tile
         oend_s = 0;
     }
     // run start of every byte: max-scan of start positions, carried in from the covering run
@@ -563,8 +704,7 @@ static PlanWs plan_layout(uint8_t *base, uint64_t n, uint32_t M)
 {
     PlanWs w{};
     const uint64_t ntiles = (n + RL_TILE - 1) / RL_TILE;
-    const uint64_t maxruns = n;
-    const uint64_t rtiles = (maxruns + RL_TILE - 1) / RL_TILE;
+    const uint64_t ngran = ntiles * GRAN_PER_TILE;
     const uint64_t maxblocks = n / ((uint64_t)(M - 1) * 4 / 5) + 4;
     uint8_t *p = base;
     auto take = [&](size_t bytes) {
@@ -575,21 +715,24 @@ static PlanWs plan_layout(uint8_t *base, uint64_t n, uint32_t M)
     w.pa.n = n;
     w.pa.M = M;
     w.pa.ntiles = (uint32_t)ntiles;
+    w.pa.ngran = (uint32_t)ngran;
     w.pa.maxblocks = (uint32_t)maxblocks;
-    w.pa.tbase = (uint32_t *)take((ntiles + 2) * 4);
-    w.pa.rs = (uint32_t *)take((maxruns + 2) * 4);
-    w.pa.po = (uint64_t *)take((maxruns + 2) * 8);
-    w.pa.rtsum = (uint64_t *)take((rtiles + 2) * 8);
-    w.pa.nruns = (uint32_t *)take(256);
+    w.pa.lrs = (uint32_t *)take((ntiles + 2) * 4);
+    w.pa.frs = (uint32_t *)take((ntiles + 2) * 4);
+    w.pa.csum = (uint32_t *)take((ntiles + 2) * 4);
+    w.pa.tc = (uint64_t *)take((ntiles + 2) * 8);
+    w.pa.cg = (uint32_t *)take((ngran + 2) * 4);
+    w.pa.rsg = (uint32_t *)take((ngran + 2) * 4);
+    w.pa.nrsg = (uint32_t *)take((ngran + 2) * 4);
     w.pa.blocks = (BlockDesc *)take(maxblocks * sizeof(BlockDesc));
-    w.pa.first = (uint32_t *)take(maxblocks * 4);
+    w.pa.aux = (BlockAux *)take(maxblocks * sizeof(BlockAux));
     w.pa.nblocks = (uint32_t *)take(256);
     w.crcacc = (uint32_t *)take(maxblocks * 4);
     w.bytes = (size_t)(p - base);
     return w;
 }
 
-// Plan over d_in[0..n): d_in must be readable up to the next multiple of 16 bytes.
+// Plan over d_in[0..n): d_in must be 16-byte aligned.
 int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n)
 {
     hipStream_t st = ctx->stream;
@@ -616,16 +759,10 @@ int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n)
     PlanArrays &pa = w.pa;
     pa.in = d_in;
 
-    plan_count<<<dim3(pa.ntiles), RL_THREADS, 0, st>>>(pa);
-    scan_u32<<<dim3(1), 1024, 0, st>>>(pa.tbase, pa.ntiles, pa.nruns);
-    plan_runs<<<dim3(pa.ntiles), RL_THREADS, 0, st>>>(pa);
-    uint32_t J = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&J, pa.nruns, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-    const uint32_t rtiles = (J + RL_TILE - 1) / RL_TILE;
-    plan_outlen<<<dim3(rtiles), RL_THREADS, 0, st>>>(pa, 0);
-    scan_u64<<<dim3(1), 1024, 0, st>>>(pa.rtsum, rtiles);
-    plan_outlen<<<dim3(rtiles), RL_THREADS, 0, st>>>(pa, 1);
+    plan_starts<<<dim3(pa.ntiles), RL_THREADS, 0, st>>>(pa);
+    plan_carries<<<dim3(1), 1024, 0, st>>>(pa);
+    plan_granules<<<dim3(pa.ntiles), RL_THREADS, 0, st>>>(pa);
+    plan_tc<<<dim3(1), 1024, 0, st>>>(pa);
     plan_split<<<dim3(1), 64, 0, st>>>(pa);
     uint32_t nb = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&nb, pa.nblocks, 4, hipMemcpyDeviceToHost, st));
@@ -670,11 +807,10 @@ int rle1_emit(bzh_ctx *ctx, size_t b0, uint32_t B)
     EmitArgs ea{};
     ea.in = ctx->plan_in;
     ea.n = ctx->plan_n;
-    ea.tbase = w.pa.tbase;
-    ea.rs = w.pa.rs;
-    ea.po = w.pa.po;
+    ea.rsg = w.pa.rsg;
+    ea.tc = w.pa.tc;
     ea.blocks = w.pa.blocks + b0;
-    ea.first = w.pa.first + b0;
+    ea.aux = w.pa.aux + b0;
     uint64_t maxspan = 0;
     for (uint32_t b = 0; b < B; b++) {
         const bzh_block &pb = ctx->plan_blocks[b0 + b];
