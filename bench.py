@@ -151,6 +151,16 @@ def main():
                              f"1 thread of {os.cpu_count()} host cores"}
         # roofline of the dominant kernel (radix_scatter): algorithmic bytes / HIP-event time, per launch
         achieved = (SORT_BYTES_PER_ELEM * sort_elems / (sort_ms * 1e-3) / 1e9) if sort_ms > 0 else None
+        # HBM bytes per launch from the committed PMC passes of this same command (FETCH_SIZE / WRITE_SIZE in
+        # separate rocprofv3 runs, corrected as MI355X_MICROARCH.md prescribes); null if not collected
+        traffic = None
+        try:
+            pmc = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_pmc_traffic.json"))
+            if pmc and world == 1 and seg_bytes == SEGMENT:
+                with open(os.path.join(ROOT, "profiles", pmc[-1])) as f:
+                    traffic = round(json.load(f)["radix_scatter_all"]["hbm_bytes_per_launch"])
+        except Exception:
+            traffic = None
         result = {
             "metric": "encode MB/s (input) at level 9, enwik8, 1/2/4/8 MI355X; bit-exact vs CPU",
             "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -162,7 +172,7 @@ def main():
                        "parallelism": f"block-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": "radix_scatter", "achieved": round(achieved, 1) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
                          "launches": int(sort_launches), "avg_launch_us": round(sort_ms * 1e3 / max(1, sort_launches), 2),
                          "alg_bytes_per_launch": round(SORT_BYTES_PER_ELEM * sort_elems / max(1, sort_launches))},
             "cpu_baseline": cpu,
