@@ -134,6 +134,13 @@ def main():
             import bz2
             ref_in = d_in[:total].cpu().numpy().tobytes()
             checks["libbz2_roundtrip"] = bool(bz2.decompress(stream_bytes) == ref_in)
+        if world > 1:
+            # the sharded stream must equal what one GPU produces for the whole input (untimed)
+            d_mono = torch.zeros(out_cap, dtype=torch.uint8, device=dev)
+            ctx.set_profiling(False)
+            mlen = ctx.encode_device(d_in.data_ptr(), total, d_mono.data_ptr(), out_cap)
+            checks["sharded_equals_single_gpu"] = bool(mlen == out_len and torch.equal(d_mono[:mlen], d_out[:out_len]))
+            del d_mono
         cpu = None
         if not args.no_cpu:
             from oracle import pyoracle as po

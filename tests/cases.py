@@ -35,7 +35,8 @@ def gen(n, mode, seed):
 MODES = ["random", "lowalpha", "shortruns", "longruns", "text", "same", "periodic"]
 
 # sizes around the level-1 block boundary (M = 99,999) and tiny / ragged inputs
-SIZES_L1 = [0, 1, 2, 3, 4, 5, 49, 50, 51, 255, 256, 257, 4095, 4096, 4097, 99998, 99999, 100000, 100001, 250000]
+SIZES_L1 = [0, 1, 2, 3, 4, 5, 49, 50, 51, 63, 64, 65, 127, 128, 129, 255, 256, 257, 4095, 4096, 4097, 8191, 8192,
+            99998, 99999, 100000, 100001, 250000]
 SIZES_L9 = [1, 1000, 899999, 900000, 1800001]
 
 
@@ -51,3 +52,19 @@ def boundary_cases(M=99999):
             tail = rng.integers(1, 200, 3000, dtype=np.uint8)
             out.append(body.tobytes() + bytes([250]) * runlen + tail.tobytes())
     return out
+
+
+def repeats(n, seed, copies=6):
+    """text with verbatim repeated passages: long pair-groups that live in the BWT's TAIL rounds"""
+    rng = np.random.default_rng(seed)
+    words = [bytes(rng.integers(97, 123, rng.integers(2, 9)).astype(np.uint8)) for _ in range(500)]
+    out = bytearray()
+    while len(out) < n:
+        out += words[int(rng.integers(0, 500))] + b" "
+    out = bytearray(out[:n])
+    for _ in range(copies):
+        ln = int(rng.integers(50, max(51, n // 8)))
+        a = int(rng.integers(0, max(1, n - 2 * ln)))
+        b = int(rng.integers(a + ln, max(a + ln + 1, n - ln)))
+        out[b:b + ln] = out[a:a + ln]
+    return bytes(out)

@@ -176,6 +176,44 @@ def test_stream_bit_exact_level9(oracle, ctx9, mode):
         assert g == oracle.encode(d, 9), (mode, n)
 
 
+def test_fuzz_streams(oracle, ctx1):
+    """the reference's fuzz target (fuzz/fuzz_targets/round_trip.rs: level 1, arbitrary bytes), here
+    with the oracle as the bit-exact judge: random lengths, alphabets and run structures"""
+    import random
+    rng = random.Random(20260)
+    for it in range(150):
+        n = rng.choice([rng.randrange(0, 300), rng.randrange(300, 5000), rng.randrange(5000, 130000)])
+        kind = rng.randrange(5)
+        if kind == 0:
+            d = bytes(rng.randrange(256) for _ in range(n))
+        elif kind == 1:
+            d = bytes(rng.randrange(rng.choice([1, 2, 3, 5])) for _ in range(n))
+        elif kind == 2:
+            d = bytearray()
+            while len(d) < n:
+                d += bytes([rng.randrange(256)]) * rng.choice([1, 1, 2, 3, 4, 5, 6, 250, 255, 256, 260, 1000])
+            d = bytes(d[:n])
+        elif kind == 3:
+            w = bytes(rng.randrange(256) for _ in range(rng.randrange(1, 40)))
+            d = (w * (n // len(w) + 1))[:n]
+        else:
+            d = cases.repeats(n, it) if n > 200 else bytes(n)
+        g = ctx1.encode(d)
+        assert g == oracle.encode(d, 1), (it, kind, n)
+
+
+def test_tail_rounds_long_repeats(oracle, ctx9):
+    """verbatim repeats of up to n/8 bytes: thousands of two-member groups resolved in TAIL rounds,
+    block boundaries in the middle of repeats; plus exact and near periodicity at full block size"""
+    for n, seed in ((400_000, 1), (899_999, 2), (2_000_000, 3)):
+        d = cases.repeats(n, seed, copies=10)
+        assert ctx9.encode(d) == oracle.encode(d, 9), (n, seed)
+    per = cases.gen(899_999, "periodic", 4)
+    b, ptr, hb = ctx9.bwt(per)
+    ob = oracle.bwt(per)
+    assert (b, ptr) == (ob[0], ob[1])
+
+
 def test_other_levels(oracle, native):
     d = cases.gen(1_234_567, "text", 2) + cases.gen(300_000, "longruns", 2)
     for level in (2, 5, 8):
