@@ -1,0 +1,163 @@
+// bnz_main.cpp -- `bnzhip`: command-line front end over libbzhip.so with the interface of the
+// reference's `bnz` (reference bnz/src/main.rs:32-59 usage, :173-257 argument grammar, :259-285 I/O
+// plumbing, :292-309 keep/remove policy, :11-14 exit codes).  SURVEY.md section 8(f) row f1.
+// No compression logic lives here: one bzh_encode call on the whole input.
+#include <cstdio>
+#include <cstdlib>
+#include <cerrno>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bzhip.h"
+
+namespace {
+const int SUCCESS = 0, ERR_ARGS = 1, ERR_FILESYSTEM = 2, ERR_OUTPUT = 3; // bnz/src/main.rs:11-14
+
+const char *TAGLINE = "bnzhip: bzip2 encoder with banzai's output, computed on an AMD MI355X";
+const char *VERSION = "version alpha 0.3.1-hip";
+
+[[noreturn]] void die(int code, const std::string &msg)
+{
+    fprintf(stderr, "%s\n", msg.c_str());
+    exit(code);
+}
+
+[[noreturn]] void usage(bool full)
+{
+    fprintf(stderr, "%s\n", TAGLINE);
+    if (!full) {
+        fprintf(stderr, "   run 'bnzhip --help' for a full list of options\n");
+        fprintf(stderr, "   run 'bnzhip --info' for information about this software\n%s\n", VERSION);
+        exit(ERR_ARGS);
+    }
+    fprintf(stderr,
+            "\n  usage: bnzhip [options] <input_path>\n\n"
+            "  options:\n"
+            "     --output <path.bz2>    write the stream to this file\n"
+            "     --stdout    or   -c    write the stream to standard out\n"
+            "     --keep      or   -k    keep the input file\n"
+            "     --remove    or   -r    remove the input file\n\n"
+            "     -1 to -9               block size in 100 kB units (default -9)\n"
+            "     --fast                 same as -1\n"
+            "     --best                 same as -9\n\n"
+            "     --verbose   or   -v    accepted for compatibility\n\n"
+            "  commands:\n"
+            "     --help  --info  --version\n\n"
+            "  notes:\n"
+            "     '-' as input path reads standard in.  Without --output / --stdout the file\n"
+            "     '<input_path>.bz2' is written and the input removed; with an explicit output the\n"
+            "     input is kept unless --remove is given.  GPU: $BZHIP_DEVICE (default 0).\n\n%s\n",
+            VERSION);
+    exit(SUCCESS);
+}
+
+bool read_all(FILE *f, std::vector<uint8_t> &buf)
+{
+    uint8_t tmp[1 << 16];
+    size_t k;
+    while ((k = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + k);
+    return !ferror(f);
+}
+} // namespace
+
+int main(int argc, char **argv)
+{
+    if (argc <= 1) usage(false);
+    enum { ANY, NOARGS, OUTPATH } expect = ANY;
+    std::string in_path, out_path;
+    bool have_in = false, in_stdin = false, out_stdout = false, have_out = false;
+    int keep = -1, level = 9;
+    auto set_input = [&](const std::string &p, bool is_stdin) {
+        if (have_in) die(ERR_ARGS, "Only one input may be specified");
+        have_in = true;
+        in_stdin = is_stdin;
+        in_path = p;
+    };
+    auto set_output = [&](const std::string &p, bool is_stdout) {
+        if (have_out && !(out_stdout && is_stdout)) die(ERR_ARGS, "Only one output may be specified");
+        have_out = true;
+        out_stdout = is_stdout;
+        out_path = p;
+    };
+    for (int k = 1; k < argc; k++) {
+        const std::string a = argv[k];
+        if (expect == OUTPATH) {
+            if (!a.empty() && a[0] == '-') die(ERR_ARGS, "Argument '--output' requires a file path");
+            set_output(a, false);
+            expect = ANY;
+        } else if (expect == ANY && a.rfind("--", 0) == 0) {
+            if (a == "--help") usage(true);
+            else if (a == "--version") die(SUCCESS, VERSION);
+            else if (a == "--info")
+                die(SUCCESS, std::string(TAGLINE) +
+                                 "\n\nBlocks are suffix-sorted by prefix doubling with radix sorts, move-to-front\n"
+                                 "coded and Huffman coded by HIP kernels (libbzhip.so); the stream is bit-identical\n"
+                                 "to banzai 0.3.1's.\n\n" + VERSION);
+            else if (a == "--verbose") {}
+            else if (a == "--keep") keep = 1;
+            else if (a == "--remove") keep = 0;
+            else if (a == "--fast") level = 1;
+            else if (a == "--best") level = 9;
+            else if (a == "--output") expect = OUTPATH;
+            else if (a == "--stdout") set_output("", true);
+            else if (a == "--") expect = NOARGS;
+            else die(ERR_ARGS, "Unrecognised argument " + a);
+        } else if (expect == ANY && !a.empty() && a[0] == '-') {
+            if (a == "-") {
+                set_input("", true);
+            } else {
+                for (size_t c = 1; c < a.size(); c++) {
+                    const char f = a[c];
+                    if (f == 'c') set_output("", true);
+                    else if (f == 'k') keep = 1;
+                    else if (f == 'r') keep = 0;
+                    else if (f == 'v') {}
+                    else if (f >= '1' && f <= '9') level = f - '0';
+                    else die(ERR_ARGS, std::string("Flag '") + f + "' is not valid");
+                }
+            }
+        } else {
+            set_input(a, false);
+        }
+    }
+    if (!have_in) die(ERR_ARGS, "An input must be specified");
+
+    std::vector<uint8_t> data;
+    FILE *inf = in_stdin ? stdin : fopen(in_path.c_str(), "rb");
+    if (!inf) die(ERR_FILESYSTEM, "[filesystem error] cannot open " + in_path + ": " + strerror(errno));
+    if (!read_all(inf, data)) die(ERR_OUTPUT, "error during compression: read failed");
+    if (!in_stdin) fclose(inf);
+
+    FILE *outf = stdout;
+    if (have_out && !out_stdout) {
+        outf = fopen(out_path.c_str(), "wb");
+        if (!outf) die(ERR_FILESYSTEM, "[filesystem error] cannot create " + out_path + ": " + strerror(errno));
+    } else if (!have_out && !in_stdin) {
+        const std::string p = in_path + ".bz2";
+        outf = fopen(p.c_str(), "wb");
+        if (!outf) die(ERR_FILESYSTEM, "[filesystem error] cannot create " + p + ": " + strerror(errno));
+    }
+
+    const char *devs = getenv("BZHIP_DEVICE");
+    bzh_ctx *ctx = nullptr;
+    int st = bzh_create(&ctx, devs ? atoi(devs) : 0, level, 0);
+    if (st != BZH_OK) die(ERR_OUTPUT, std::string("error during compression: ") + bzh_strerror(st));
+    const size_t cap = data.size() + data.size() / 4 + (data.size() / 70000 + 2) * 4096 + 65536;
+    std::vector<uint8_t> out(cap);
+    size_t out_len = 0, consumed = 0;
+    st = bzh_encode(ctx, data.data(), data.size(), out.data(), cap, &out_len, &consumed);
+    if (st != BZH_OK) {
+        const std::string msg = std::string("error during compression: ") + bzh_strerror(st) + ": " + bzh_last_error(ctx);
+        bzh_destroy(ctx);
+        die(ERR_OUTPUT, msg);
+    }
+    bzh_destroy(ctx);
+    if (fwrite(out.data(), 1, out_len, outf) != out_len || fflush(outf) != 0) die(ERR_OUTPUT, "error during compression: write failed");
+    if (outf != stdout) fclose(outf);
+
+    const bool keep_input = keep >= 0 ? keep == 1 : have_out; // bnz/src/main.rs:292-300
+    if (!keep_input && !in_stdin && remove(in_path.c_str()) != 0)
+        die(ERR_OUTPUT, "error deleting input file: " + std::string(strerror(errno)));
+    return SUCCESS;
+}
