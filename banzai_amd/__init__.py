@@ -17,6 +17,7 @@ Context = _native.Context
 BzhError = _native.BzhError
 
 _ctx_cache = {}
+READ_CHUNK = 16 << 20
 
 
 def _ctx(level, device=0):
@@ -32,16 +33,25 @@ def encode(reader, writer, level, device=0):
     Same contract as banzai::encode: `level` in 1..=9 is the block size in 100 kB units
     (anything else raises, the reference asserts at lib/lib.rs:89); returns the number of input
     bytes encoded; I/O errors of reader/writer propagate."""
-    if not isinstance(level, int) or not 1 <= level <= 9:
+    if isinstance(level, bool) or not isinstance(level, int) or not 1 <= level <= 9:
         raise ValueError("level must be in 1..=9")
-    data = reader.read()
-    if not isinstance(data, (bytes, bytearray, memoryview)):
-        raise TypeError("reader.read() must return bytes")
-    stream = _ctx(level, device).encode(bytes(data))
-    writer.write(stream)
+    ctx = _ctx(level, device)
+    # incremental ingestion (the reference pulls from fill_buf as it goes, lib/rle.rs:30-92): input is
+    # handed to the GPU in chunks, finished stream bytes are written as soon as they are final
+    ctx.stream_begin()
+    while True:
+        chunk = reader.read(READ_CHUNK)
+        if not isinstance(chunk, (bytes, bytearray, memoryview)):
+            raise TypeError("reader.read() must return bytes")
+        eof = len(chunk) == 0
+        out = ctx.stream_feed(chunk, eof)
+        if out:
+            writer.write(out)
+        if eof:
+            break
     if hasattr(writer, "flush"):
         writer.flush()
-    return len(data)
+    return ctx.stream_consumed()
 
 
 def encode_file(in_path, out_path, device=0):

@@ -51,6 +51,11 @@ SIGNATURES = {
     "bzh_encode": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_size_t, u8p, ctypes.c_size_t, szp, szp]),
     "bzh_encode_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                                          ctypes.c_size_t, szp, szp]),
+    "bzh_stream_begin": (ctypes.c_int, [ctypes.c_void_p]),
+    "bzh_stream_feed": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_size_t, ctypes.c_int, u8p, ctypes.c_size_t, szp]),
+    "bzh_stream_bound": (ctypes.c_size_t, [ctypes.c_void_p, ctypes.c_size_t]),
+    "bzh_stream_set_chunk": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
+    "bzh_stream_consumed": (ctypes.c_size_t, [ctypes.c_void_p]),
     "bzh_plan_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, szp]),
     "bzh_plan_blocks": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Block), ctypes.c_size_t]),
     "bzh_encode_range_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p,
@@ -270,3 +275,25 @@ class Context:
         self.check(lib().bzh_assemble_device(self._h, ptrs, ptr(bits, u64p), nseg, ptr(c, u32p), len(crcs),
                                              ctypes.c_void_p(d_out), cap, ctypes.byref(olen)))
         return int(olen.value)
+
+    # ---- streaming (bzh_stream_*) ----
+    def stream_begin(self, chunk_bytes=None):
+        if chunk_bytes is not None:
+            self.check(lib().bzh_stream_set_chunk(self._h, chunk_bytes))
+        self.check(lib().bzh_stream_begin(self._h))
+        self._sbuf = None
+
+    def stream_feed(self, data, eof=False):
+        """-> stream bytes that became final with this feed"""
+        n = len(data)
+        a = np.frombuffer(bytes(data), dtype=np.uint8) if n else np.zeros(1, np.uint8)
+        need = int(lib().bzh_stream_bound(self._h, n))
+        if self._sbuf is None or self._sbuf.size < need:
+            self._sbuf = np.empty(need, dtype=np.uint8)
+        got = ctypes.c_size_t(0)
+        self.check(lib().bzh_stream_feed(self._h, ptr(np.ascontiguousarray(a)), n, 1 if eof else 0, ptr(self._sbuf),
+                                         self._sbuf.size, ctypes.byref(got)))
+        return self._sbuf[:got.value].tobytes()
+
+    def stream_consumed(self):
+        return int(lib().bzh_stream_consumed(self._h))

@@ -154,6 +154,8 @@ extern "C" void bzh_destroy(bzh_ctx *ctx)
     if (ctx->d_stage_out) hipFree(ctx->d_stage_out);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
     if (ctx->d_crctab) hipFree(ctx->d_crctab);
+    for (int k = 0; k < 2; k++)
+        if (ctx->strm.d_buf[k]) hipFree(ctx->strm.d_buf[k]);
     delete ctx;
 }
 
@@ -399,7 +401,7 @@ static float span_ms(hipEvent_t a, hipEvent_t b)
 // Encodes plan blocks [b0, b1) into d_out starting at bit `bit_base`; words of d_out from
 // bit_base/32 on are zeroed here as needed (words before that are the caller's).
 static int encode_range(bzh_ctx *ctx, size_t b0, size_t b1, uint8_t *d_out, size_t cap, uint64_t bit_base,
-                        uint64_t *nbits)
+                        uint64_t *nbits, const uint32_t *seed_word = nullptr)
 {
     if (((uintptr_t)d_out & 3u) != 0) {
         bzh_set_error(ctx, "output buffer must be 4-byte aligned");
@@ -450,6 +452,8 @@ static int encode_range(bzh_ctx *ctx, size_t b0, size_t b1, uint8_t *d_out, size
         }
         if (need_upto > zeroed_upto) {
             HIP_TRY(ctx, hipMemsetAsync(d_out + zeroed_upto * 4, 0, (size_t)(need_upto - zeroed_upto) * 4, st));
+            if (seed_word && zeroed_upto == bit_base / 32) // bits already owed to the word the range starts in
+                HIP_TRY(ctx, hipMemcpyAsync(d_out + zeroed_upto * 4, seed_word, 4, hipMemcpyHostToDevice, st));
             zeroed_upto = need_upto;
         }
         BZH_TRY(huff_pack(ctx, B, mmax, d_out, bit_base + cur));
@@ -681,4 +685,202 @@ extern "C" int bzh_crc32(bzh_ctx *ctx, const uint8_t *in, size_t n, uint32_t *cr
     BZH_TRY(ensure_stage(ctx, ctx->d_stage_in, ctx->stage_in_size, n + 16));
     if (n) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage_in, in, n, hipMemcpyHostToDevice, ctx->stream));
     return crc_device(ctx, ctx->d_stage_in, n, crc);
+}
+
+
+// ================================================================================================
+// Streaming
+// ================================================================================================
+
+extern "C" int bzh_stream_begin(bzh_ctx *ctx)
+{
+    if (!ctx) return BZH_E_ARG;
+    auto &s = ctx->strm;
+    s.active = true;
+    s.header_done = false;
+    s.pend.clear();
+    s.cur = 0;
+    s.carry = 0;
+    s.bitpos = 0;
+    s.carry_word = 0;
+    s.stream_crc = 0;
+    s.consumed = 0;
+    return BZH_OK;
+}
+
+extern "C" size_t bzh_stream_bound(const bzh_ctx *ctx, size_t n)
+{
+    if (!ctx) return 0;
+    // everything pending may be released by this call: carried raw bytes (< 52 MB: one block of a
+    // maximal run) + what was held back below STREAM_MIN_FEED + n, at worst-case expansion, plus framing
+    const size_t raw = n + ctx->strm.min_feed + ((size_t)52 << 20);
+    return raw + raw / 4 + (raw / 70000 + 4) * 4096 + 65536;
+}
+
+extern "C" size_t bzh_stream_consumed(const bzh_ctx *ctx) { return ctx ? ctx->strm.consumed : 0; }
+
+extern "C" int bzh_stream_set_chunk(bzh_ctx *ctx, size_t bytes)
+{
+    if (!ctx || bytes == 0 || bytes > ((size_t)1 << 30)) return BZH_E_ARG;
+    ctx->strm.min_feed = bytes;
+    return BZH_OK;
+}
+
+static inline void put_be32(uint8_t *p, uint32_t v)
+{
+    p[0] = (uint8_t)(v >> 24);
+    p[1] = (uint8_t)(v >> 16);
+    p[2] = (uint8_t)(v >> 8);
+    p[3] = (uint8_t)v;
+}
+
+extern "C" int bzh_stream_feed(bzh_ctx *ctx, const uint8_t *in, size_t n, int eof, uint8_t *out, size_t cap,
+                               size_t *out_len)
+{
+    if (!ctx || (!in && n) || !out || !out_len) return BZH_E_ARG;
+    auto &s = ctx->strm;
+    if (!s.active) return BZH_E_STATE;
+    *out_len = 0;
+    const size_t PIECE = (size_t)256 << 20; // keeps every plan far inside 32-bit positions
+    if (n > PIECE) {
+        size_t done = 0, produced = 0;
+        while (done < n) {
+            const size_t k = n - done < PIECE ? n - done : PIECE;
+            size_t got = 0;
+            BZH_TRY(bzh_stream_feed(ctx, in + done, k, eof && done + k == n, out + produced, cap - produced, &got));
+            done += k;
+            produced += got;
+        }
+        *out_len = produced;
+        return BZH_OK;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    s.pend.insert(s.pend.end(), in, in + n);
+    if (!eof && s.pend.size() < s.min_feed) return BZH_OK;
+
+    size_t opos = 0;
+    auto need_cap = [&](size_t more) { return opos + more <= cap; };
+    if (!s.header_done) { // lib/lib.rs:18-22
+        if (!need_cap(4)) return BZH_E_CAP;
+        out[0] = 0x42;
+        out[1] = 0x5A;
+        out[2] = 0x68;
+        out[3] = (uint8_t)('0' + ctx->level);
+        opos = 4;
+        s.bitpos = 32;
+        s.header_done = true;
+    }
+
+    const size_t total = s.carry + s.pend.size();
+    if (total > 0) {
+        // carried bytes already sit at the start of d_buf[cur]; append the pending ones
+        if (total + 16 > s.cap[s.cur]) {
+            uint8_t *nb = nullptr;
+            const size_t want = align_up(total + total / 4 + (1 << 20), 4096);
+            if (hipMalloc((void **)&nb, want) != hipSuccess) {
+                bzh_set_error(ctx, "hipMalloc(%zu) failed", want);
+                return BZH_E_NOMEM;
+            }
+            if (s.carry) HIP_TRY(ctx, hipMemcpyAsync(nb, s.d_buf[s.cur], s.carry, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            if (s.d_buf[s.cur]) hipFree(s.d_buf[s.cur]);
+            s.d_buf[s.cur] = nb;
+            s.cap[s.cur] = want;
+        }
+        uint8_t *buf = s.d_buf[s.cur];
+        if (!s.pend.empty())
+            HIP_TRY(ctx, hipMemcpyAsync(buf + s.carry, s.pend.data(), s.pend.size(), hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        s.pend.clear();
+
+        BZH_TRY(rle1_plan(ctx, buf, total));
+        const size_t nb = ctx->plan_blocks.size();
+        size_t F = nb; // blocks that are final
+        if (!eof) {
+            F = 0;
+            while (F < nb && !ctx->plan_open[F]) F++;
+        }
+        size_t used = 0;
+        if (F > 0) {
+            used = F == nb ? total : (size_t)ctx->plan_blocks[F].in_off;
+            size_t raw = 0;
+            for (size_t k = 0; k < F; k++) raw += ctx->plan_blocks[k].in_len;
+            const size_t dcap = (raw + raw / 4 + (F + 2) * 4096 + 65536) & ~(size_t)3;
+            BZH_TRY(ensure_stage(ctx, ctx->d_stage_out, ctx->stage_out_size, dcap));
+            const uint32_t phase = (uint32_t)(s.bitpos & 31u);
+            uint8_t seed_be[4];
+            put_be32(seed_be, s.carry_word);
+            uint32_t seed;
+            memcpy(&seed, seed_be, 4);
+            uint64_t nbits = 0;
+            memset(&ctx->stats, 0, sizeof ctx->stats);
+            ctx->sort_spans.clear();
+            ctx->evnext = 0;
+            BZH_TRY(encode_range(ctx, 0, F, ctx->d_stage_out, ctx->stage_out_size & ~(size_t)3, phase, &nbits,
+                                 phase ? &seed : nullptr));
+            const uint64_t bits_in_buf = phase + nbits;
+            const size_t full_words = (size_t)(bits_in_buf / 32);
+            if (!need_cap(full_words * 4)) return BZH_E_CAP;
+            if (full_words)
+                HIP_TRY(ctx, hipMemcpyAsync(out + opos, ctx->d_stage_out, full_words * 4, hipMemcpyDeviceToHost, st));
+            uint8_t lastw[4] = {0, 0, 0, 0};
+            if (bits_in_buf & 31u)
+                HIP_TRY(ctx, hipMemcpyAsync(lastw, ctx->d_stage_out + full_words * 4, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            opos += full_words * 4;
+            s.carry_word = ((uint32_t)lastw[0] << 24) | ((uint32_t)lastw[1] << 16) | ((uint32_t)lastw[2] << 8) | lastw[3];
+            s.bitpos += nbits;
+            for (size_t k = 0; k < F; k++) // lib/lib.rs:107-108
+                s.stream_crc = ctx->plan_blocks[k].crc ^ ((s.stream_crc << 1) | (s.stream_crc >> 31));
+            s.consumed += used;
+        }
+        // carry the unconsumed tail to the other buffer (no overlapping copy)
+        const size_t left = total - used;
+        const int other = s.cur ^ 1;
+        if (left) {
+            if (left + 16 > s.cap[other]) {
+                if (s.d_buf[other]) hipFree(s.d_buf[other]);
+                s.d_buf[other] = nullptr;
+                s.cap[other] = 0;
+                const size_t want = align_up(left + s.min_feed + (1 << 20), 4096);
+                if (hipMalloc((void **)&s.d_buf[other], want) != hipSuccess) {
+                    bzh_set_error(ctx, "hipMalloc(%zu) failed", want);
+                    return BZH_E_NOMEM;
+                }
+                s.cap[other] = want;
+            }
+            HIP_TRY(ctx, hipMemcpyAsync(s.d_buf[other], buf + used, left, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            s.cur = other;
+        }
+        s.carry = left;
+    }
+
+    if (eof) { // footer + stream CRC (lib/lib.rs:66-70), zero padding to a byte (lib/out.rs:22-28)
+        const uint32_t phase = (uint32_t)(s.bitpos & 31u);
+        uint8_t tail[24];
+        memset(tail, 0, sizeof tail);
+        put_be32(tail, phase ? s.carry_word : 0u);
+        const uint8_t foot[10] = {0x17, 0x72, 0x45, 0x38, 0x50, 0x90, (uint8_t)(s.stream_crc >> 24),
+                                  (uint8_t)(s.stream_crc >> 16), (uint8_t)(s.stream_crc >> 8), (uint8_t)s.stream_crc};
+        for (uint32_t k = 0; k < 80; k++) {
+            const uint32_t bit = (foot[k >> 3] >> (7 - (k & 7))) & 1u;
+            const uint32_t pos = phase + k;
+            tail[pos >> 3] |= (uint8_t)(bit << (7 - (pos & 7)));
+        }
+        const size_t nbytes = (phase + 80 + 7) / 8;
+        if (!need_cap(nbytes)) return BZH_E_CAP;
+        memcpy(out + opos, tail, nbytes);
+        opos += nbytes;
+        s.bitpos += 80;
+        s.active = false;
+        for (int k = 0; k < 2; k++) {
+            if (s.d_buf[k]) hipFree(s.d_buf[k]);
+            s.d_buf[k] = nullptr;
+            s.cap[k] = 0;
+        }
+    }
+    *out_len = opos;
+    return BZH_OK;
 }

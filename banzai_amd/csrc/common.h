@@ -119,7 +119,7 @@ struct bzh_ctx {
     const uint8_t *plan_in = nullptr; // device
     size_t plan_n = 0;
     std::vector<bzh_block> plan_blocks;
-    std::vector<uint32_t> plan_restart; // per block: offset inside the first run where it (re)starts
+    std::vector<uint8_t> plan_open;     // per block: 1 = cut not final unless the input ends here
     void *plan_ws = nullptr;            // device scratch of the plan (run tables)
     size_t plan_ws_size = 0;
     // staging
@@ -129,6 +129,20 @@ struct bzh_ctx {
     size_t stage_out_size = 0;
     uint32_t *h_pinned = nullptr; // small pinned readback area
     void *d_crctab = nullptr;     // GF(2) tables of the block CRC (rle1.hip)
+    // streaming encode (bzh_stream_*)
+    struct Stream {
+        bool active = false, header_done = false;
+        std::vector<uint8_t> pend;      // host bytes not yet sent to the GPU
+        uint8_t *d_buf[2] = {nullptr, nullptr};
+        size_t cap[2] = {0, 0};
+        int cur = 0;
+        size_t carry = 0;               // bytes at the start of d_buf[cur] not yet encoded
+        uint64_t bitpos = 0;            // stream bits produced so far
+        uint32_t carry_word = 0;        // the bitpos % 32 bits not yet handed out (big-endian word)
+        uint32_t stream_crc = 0;
+        size_t consumed = 0;
+        size_t min_feed = (size_t)32 << 20; // pending bytes that trigger a GPU pass
+    } strm;
     bzh_stats stats{};
     std::vector<hipEvent_t> evpool;
     size_t evnext = 0;

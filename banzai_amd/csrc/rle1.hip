@@ -35,6 +35,8 @@ struct BlockAux { // per planned block: what the emit kernel needs about the run
     uint64_t Ce;      // canonical offset at the end of that run
     uint32_t A;       // RLE1 bytes of that run's remainder (chunking restarted at in_off)
     uint32_t e_first; // end of that run
+    uint32_t open;    // 1 = the cut could move if more input followed (streaming: not final yet)
+    uint32_t pad;
 };
 
 struct PlanArrays {
@@ -327,13 +329,16 @@ __global__ void __launch_bounds__(64) plan_split(PlanArrays pa)
         const uint32_t e_first = next_start_after(pa, s, lane);
         const uint32_t Lr = e_first - s;
         const uint32_t A = canon_len(Lr);
-        uint32_t consumed, out;
+        uint32_t consumed, out, open = 0;
         uint64_t Ce = 0;
+        // A cut inside the input's last run is final only if that run is known to hold at least one
+        // more full 255-byte chunk than the budget can take (then its true length cannot matter).
         if (A > M) { // the budget runs out inside the run the block starts in
             uint32_t k, t;
             cut_in_run(Lr, M, k, t);
             consumed = 255u * k + t;
             out = 5u * k + t;
+            open = e_first >= N && (uint64_t)Lr < 255ull * (M / 5u + 2u);
         } else {
             if (e_first >= N) {
                 Ce = total;
@@ -345,6 +350,7 @@ __global__ void __launch_bounds__(64) plan_split(PlanArrays pa)
             if (total <= lim) { // everything to the end of the input fits
                 consumed = N - s;
                 out = A + (uint32_t)(total - Ce);
+                open = 1;
             } else {
                 // last tile with tc <= lim: probe 64 tiles around the literal-text guess, else 64-ary search
                 uint32_t lo = e_first / RL_TILE, hi = NT - 1; // tc[lo] <= Ce <= lim
@@ -394,7 +400,9 @@ __global__ void __launch_bounds__(64) plan_split(PlanArrays pa)
                     Cx = __shfl(gr.cpos, 0, 64) - emitted_before(gx * GRAN - x);
                 }
                 const uint32_t R = (uint32_t)(lim - Cx); // budget left for the run starting at x
-                const uint32_t Lx = next_start_after(pa, x, lane) - x;
+                const uint32_t xe = next_start_after(pa, x, lane);
+                const uint32_t Lx = xe - x;
+                open = xe >= N && (uint64_t)Lx < 255ull * (R / 5u + 2u);
                 uint32_t k, t;
                 cut_in_run(Lx, R, k, t);
                 consumed = x - s + 255u * k + t;
@@ -412,6 +420,8 @@ __global__ void __launch_bounds__(64) plan_split(PlanArrays pa)
             ax.Ce = Ce;
             ax.A = A;
             ax.e_first = e_first;
+            ax.open = open;
+            ax.pad = 0;
             pa.aux[nb] = ax;
         }
         nb++;
@@ -789,6 +799,13 @@ int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n)
     HIP_TRY(ctx, hipMemcpyAsync(hb.data(), pa.blocks, nb * sizeof(BlockDesc), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     HIP_TRY(ctx, hipGetLastError());
+    {
+        std::vector<BlockAux> hax(nb);
+        HIP_TRY(ctx, hipMemcpyAsync(hax.data(), pa.aux, nb * sizeof(BlockAux), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        ctx->plan_open.resize(nb);
+        for (uint32_t b = 0; b < nb; b++) ctx->plan_open[b] = (uint8_t)hax[b].open;
+    }
     ctx->plan_blocks.resize(nb);
     for (uint32_t b = 0; b < nb; b++) {
         ctx->plan_blocks[b].in_off = hb[b].in_off;

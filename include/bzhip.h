@@ -84,6 +84,30 @@ BZH_API int bzh_encode(bzh_ctx *ctx, const uint8_t *in, size_t n, uint8_t *out, 
 BZH_API int bzh_encode_device(bzh_ctx *ctx, const void *d_in, size_t n, void *d_out, size_t cap, size_t *out_len,
                       size_t *consumed);
 
+/* ---- streaming: encode() fed by a reader that yields arbitrary chunks (lib/rle.rs:30-92) ------- */
+
+/* Starts a stream on the context.  Then call bzh_stream_feed any number of times; the bytes it
+ * returns, concatenated, are exactly the stream bzh_encode produces for the concatenated input,
+ * whatever the chunking (the reference's incremental InputStream + margin_call, without its T16
+ * truncation bug).  Memory stays bounded: input is buffered only until the blocks it completes
+ * are final (at most about one block's worth of raw bytes is carried between feeds). */
+BZH_API int bzh_stream_begin(bzh_ctx *ctx);
+
+/* Feeds n more input bytes; eof != 0 marks the end of the input (n may be 0) and completes the
+ * stream.  Writes the stream bytes that became final to out (cap >= bzh_stream_bound(ctx, n));
+ * *out_len receives their count.  BZH_E_CAP leaves the stream unusable. */
+BZH_API int bzh_stream_feed(bzh_ctx *ctx, const uint8_t *in, size_t n, int eof, uint8_t *out, size_t cap,
+                            size_t *out_len);
+
+/* Upper bound of the bytes one bzh_stream_feed(…, n, …) call can return. */
+BZH_API size_t bzh_stream_bound(const bzh_ctx *ctx, size_t n);
+
+/* Pending input that triggers a GPU pass (default 32 MiB; smaller = lower latency, more launches). */
+BZH_API int bzh_stream_set_chunk(bzh_ctx *ctx, size_t bytes);
+
+/* Input bytes encoded so far (after the eof feed: the total, encode()'s return value). */
+BZH_API size_t bzh_stream_consumed(const bzh_ctx *ctx);
+
 /* ---- block-sharded path (one rank per GPU) -------------------------- */
 
 /* Split d_in[0..n) into blocks: the sequential part of the loop at lib/lib.rs:101-126, i.e.

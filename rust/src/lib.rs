@@ -6,7 +6,7 @@ use std::convert;
 use std::ffi::CStr;
 use std::fs;
 use std::io;
-use std::io::{Read, Write};
+use std::io::Write;
 use std::os::raw::{c_char, c_int};
 use std::path;
 
@@ -20,15 +20,18 @@ extern "C" {
     fn bzh_destroy(ctx: *mut BzhCtx);
     fn bzh_strerror(status: c_int) -> *const c_char;
     fn bzh_last_error(ctx: *const BzhCtx) -> *const c_char;
-    fn bzh_encode(
+    fn bzh_stream_begin(ctx: *mut BzhCtx) -> c_int;
+    fn bzh_stream_bound(ctx: *const BzhCtx, n: usize) -> usize;
+    fn bzh_stream_feed(
         ctx: *mut BzhCtx,
         input: *const u8,
         n: usize,
+        eof: c_int,
         out: *mut u8,
         cap: usize,
         out_len: *mut usize,
-        consumed: *mut usize,
     ) -> c_int;
+    fn bzh_stream_consumed(ctx: *const BzhCtx) -> usize;
 }
 
 struct Ctx(*mut BzhCtx);
@@ -63,12 +66,6 @@ where
 {
     assert!(1 <= level && level <= 9);
 
-    // Blocks are cut by a sequential rule over the whole input, so the slice is gathered first
-    // (a reader that yields everything in one fill_buf is the case the reference handles without
-    // its truncation bug).
-    let mut raw = vec![];
-    reader.read_to_end(&mut raw)?;
-
     let device: c_int = std::env::var("BZHIP_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
     let mut handle: *mut BzhCtx = std::ptr::null_mut();
     let status = unsafe { bzh_create(&mut handle, device, level as c_int, 0) };
@@ -76,19 +73,39 @@ where
         return Err(to_io_error(std::ptr::null(), status));
     }
     let ctx = Ctx(handle);
-
-    let cap = raw.len() + raw.len() / 4 + (raw.len() / 70_000 + 2) * 4096 + 65_536;
-    let mut out: Vec<u8> = vec![0; cap];
-    let (mut out_len, mut consumed) = (0usize, 0usize);
-    let status =
-        unsafe { bzh_encode(ctx.0, raw.as_ptr(), raw.len(), out.as_mut_ptr(), cap, &mut out_len, &mut consumed) };
+    let status = unsafe { bzh_stream_begin(ctx.0) };
     if status != 0 {
         return Err(to_io_error(ctx.0, status));
     }
 
-    writer.write_all(&out[..out_len])?;
+    // Pull from the reader as the reference does (fill_buf / consume, lib/rle.rs:43-91); the library
+    // buffers what it must and returns stream bytes as soon as they are final.
+    let mut out: Vec<u8> = Vec::new();
+    loop {
+        let (len, eof) = {
+            let buf = reader.fill_buf()?;
+            let eof = buf.is_empty();
+            let cap = unsafe { bzh_stream_bound(ctx.0, buf.len()) };
+            if out.len() < cap {
+                out.resize(cap, 0);
+            }
+            let mut out_len = 0usize;
+            let status = unsafe {
+                bzh_stream_feed(ctx.0, buf.as_ptr(), buf.len(), eof as c_int, out.as_mut_ptr(), out.len(), &mut out_len)
+            };
+            if status != 0 {
+                return Err(to_io_error(ctx.0, status));
+            }
+            writer.write_all(&out[..out_len])?;
+            (buf.len(), eof)
+        };
+        reader.consume(len);
+        if eof {
+            break;
+        }
+    }
     writer.flush()?;
-    Ok(consumed)
+    Ok(unsafe { bzh_stream_consumed(ctx.0) })
 }
 
 /// bzip2 encode a file and write the output to another file (level 9)

@@ -311,3 +311,60 @@ def test_full_size_properties_config3(native):
     assert sum(b[1] for b in blocks) == n and all(0 < b[2] <= 899_999 for b in blocks)
     assert first[:4] == b"BZh9"
     assert bz2.decompress(first) == data.tobytes()
+
+
+# ---- streaming --------------------------------------------------------------------------
+def _stream(ctx, data, cuts, chunk_bytes):
+    ctx.stream_begin(chunk_bytes)
+    out, pos = [], 0
+    for c in cuts:
+        out.append(ctx.stream_feed(data[pos:pos + c]))
+        pos += c
+    out.append(ctx.stream_feed(data[pos:], eof=True))
+    assert ctx.stream_consumed() == len(data)
+    return b"".join(out)
+
+
+def test_streaming_equals_one_shot(oracle, ctx1):
+    """any chunking of the reader gives the same stream (the reference's BufRead contract), including
+    feeds that end inside runs, GPU passes whose last blocks are not final yet, and empty input"""
+    import random
+    rng = random.Random(5)
+    assert _stream(ctx1, b"", [], 1 << 20) == oracle.encode(b"", 1)
+    for mode in ("text", "longruns", "shortruns", "same", "random"):
+        d = cases.gen(700_001, mode, 21)
+        want = oracle.encode(d, 1)
+        for chunk_bytes in (150_000, 1 << 20):
+            cuts, left = [], len(d)
+            while left > 0 and len(cuts) < 40:
+                c = min(left, rng.choice([1, 7, 4096, 99_999, 100_000, 250_000, 333_333]))
+                cuts.append(c)
+                left -= c
+            assert _stream(ctx1, d, cuts, chunk_bytes) == want, (mode, chunk_bytes)
+    # a zero run far longer than a block: blocks inside it must be released before the run ends
+    d = b"\0" * 30_000_000 + b"tail"
+    ctx1.stream_begin(4 << 20)
+    pieces = [ctx1.stream_feed(d[k:k + (3 << 20)]) for k in range(0, len(d), 3 << 20)]
+    assert sum(len(p) for p in pieces) > 0  # output appeared before eof although the run was still open
+    pieces.append(ctx1.stream_feed(b"", eof=True))
+    assert b"".join(pieces) == oracle.encode(d, 1)
+
+
+def test_streaming_public_api_chunked_reader(oracle):
+    import banzai_amd
+
+    class Dribble(io.RawIOBase):  # a reader that hands out odd-sized pieces
+        def __init__(self, data):
+            self.d, self.p, self.k = data, 0, 0
+
+        def read(self, n=-1):
+            self.k += 1
+            take = min(n if n >= 0 else len(self.d), 1 + (self.k * 7919) % 300_000)
+            out = self.d[self.p:self.p + take]
+            self.p += len(out)
+            return out
+
+    d = cases.gen(2_000_003, "text", 4) + cases.gen(500_000, "longruns", 4)
+    w = io.BytesIO()
+    assert banzai_amd.encode(Dribble(d), w, 9) == len(d)
+    assert w.getvalue() == oracle.encode(d, 9)
