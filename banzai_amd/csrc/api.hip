@@ -356,17 +356,32 @@ __device__ __forceinline__ void or_word_be(uint32_t *out, uint64_t word_idx, uin
     if (v) atomicOr(out + word_idx, __builtin_bswap32(v));
 }
 
-// ORs nbits bits of src (MSB-first, from bit 0) into dst at bit position dst_bit.  dst zeroed.
+// Copies nbits bits of src (MSB-first, from bit 0) to bit position dst_bit of dst (zeroed before).
+// One thread per DESTINATION word: interior words are plain stores assembled from two source words
+// (funnel shift); only the first and last word, shared with the neighbouring segments, are ORed.
 __global__ void __launch_bounds__(256) concat_bits(uint32_t *dst, uint64_t dst_bit, const uint32_t *src, uint64_t nbits)
 {
-    const uint64_t nw = (nbits + 31) >> 5;
     const uint32_t sh = (uint32_t)(dst_bit & 31u);
     const uint64_t w0 = dst_bit >> 5;
-    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < nw; k += (uint64_t)gridDim.x * 256) {
-        uint32_t v = __builtin_bswap32(src[k]);
-        if (k == nw - 1 && (nbits & 31u)) v &= 0xFFFFFFFFu << (32 - (uint32_t)(nbits & 31u));
-        or_word_be(dst, w0 + k, v >> sh);
-        if (sh) or_word_be(dst, w0 + k + 1, v << (32 - sh));
+    const uint64_t nsw = (nbits + 31) >> 5;            // source words
+    const uint64_t ndw = (sh + nbits + 31) >> 5;       // destination words touched
+    const uint32_t tailbits = (uint32_t)(nbits & 31u);
+    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < ndw; k += (uint64_t)gridDim.x * 256) {
+        // destination word k holds source bits [32k - sh, 32k - sh + 32)
+        uint32_t hi = 0, lo = 0; // source words k-1 and k (big-endian values)
+        if (k >= 1 && k - 1 < nsw) {
+            hi = __builtin_bswap32(src[k - 1]);
+            if (k - 1 == nsw - 1 && tailbits) hi &= 0xFFFFFFFFu << (32 - tailbits);
+        }
+        if (k < nsw) {
+            lo = __builtin_bswap32(src[k]);
+            if (k == nsw - 1 && tailbits) lo &= 0xFFFFFFFFu << (32 - tailbits);
+        }
+        const uint32_t v = sh ? ((hi << (32 - sh)) | (lo >> sh)) : lo;
+        if (k == 0 || k == ndw - 1)
+            or_word_be(dst, w0 + k, v);
+        else
+            dst[w0 + k] = __builtin_bswap32(v);
     }
 }
 
@@ -559,8 +574,8 @@ extern "C" int bzh_assemble_device(bzh_ctx *ctx, const void *const *d_segs, cons
     for (size_t k = 0; k < nseg; k++) {
         if (seg_bits[k] == 0) continue;
         if (((uintptr_t)d_segs[k] & 3u) != 0) return BZH_E_ARG;
-        const uint64_t nw = (seg_bits[k] + 31) / 32;
-        uint32_t grid = (uint32_t)std::min<uint64_t>((nw + 255) / 256, 4096);
+        const uint64_t nw = (seg_bits[k] + 31) / 32 + 1;
+        uint32_t grid = (uint32_t)std::min<uint64_t>((nw + 255) / 256, 8192);
         concat_bits<<<dim3(grid), 256, 0, st>>>((uint32_t *)d_out, pos, (const uint32_t *)d_segs[k], seg_bits[k]);
         pos += seg_bits[k];
     }

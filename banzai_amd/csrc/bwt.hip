@@ -523,6 +523,7 @@ struct TailArgs {
 };
 
 // record: [resolved:1 @60][new rank:20 @40][SA position:20 @20][suffix:20 @0]
+template <bool QUAD>
 __global__ void __launch_bounds__(TAIL_THREADS) tail_sort(TailArgs a)
 {
     uint32_t b, tile;
@@ -540,6 +541,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) tail_sort(TailArgs a)
     u64 *buf = ((lenw & TAIL_BUF_B) ? a.bufB : a.bufA) + base;
     const uint32_t *rank = a.rank + base;
     __shared__ uint32_t A0[TAIL_W], A1[TAIL_W], A2[TAIL_W], A3[TAIL_W];
+    __shared__ uint32_t A4[QUAD ? TAIL_W : 1], A5[QUAD ? TAIL_W : 1]; // extra keys of the 4h form only
     __shared__ uint32_t ls[TAIL_THREADS / 64 + 2];
 
     // load by slot (coalesced); already-resolved suffixes (first tail round only) drop out
@@ -606,15 +608,27 @@ __global__ void __launch_bounds__(TAIL_THREADS) tail_sort(TailArgs a)
                 owned |= 1u << k;
                 if (A2[e] - fs >= (uint32_t)TAIL_G) bad = true; // span beyond the window guarantee
                 const uint32_t i = A1[e];
-                uint32_t k2;
+                uint32_t k2, k3 = 0, k4 = 0;
                 if (a.h < n) {
                     uint32_t i2 = i + a.h;
                     if (i2 >= n) i2 -= n;
                     k2 = rank[i2] & RANK_MASK;
+                    if (QUAD) { // two more h-blocks of the (cyclic) rotation
+                        uint32_t i3 = i2 + a.h;
+                        if (i3 >= n) i3 -= n;
+                        uint32_t i4 = i3 + a.h;
+                        if (i4 >= n) i4 -= n;
+                        k3 = rank[i3] & RANK_MASK;
+                        k4 = rank[i4] & RANK_MASK;
+                    }
                 } else {
                     k2 = n - 1 - i; // identical rotations: larger index first
                 }
                 A3[e] = k2;
+                if (QUAD) {
+                    A4[e] = k3;
+                    A5[e] = k4;
+                }
             }
         }
     }
@@ -624,13 +638,18 @@ __global__ void __launch_bounds__(TAIL_THREADS) tail_sort(TailArgs a)
     for (int k = 0; k < TAIL_PER; k++) {
         const uint32_t e = k * TAIL_THREADS + threadIdx.x;
         if (e < V && (owned & (1u << k))) {
-            const uint32_t r = A0[e], g = gstart[k], mykey = A3[e];
+            const uint32_t r = A0[e], g = gstart[k];
+            // lexicographic key (k2, k3, k4): two 64-bit words compare it
+            const uint32_t my_hi = A3[e];
+            const u64 my_lo = QUAD ? (((u64)A4[e] << 32) | A5[e]) : 0ull;
             uint32_t less = 0, eq_before = 0, eq = 0;
             for (uint32_t f = g; f < V && A0[f] == r; f++) {
-                const uint32_t kf = A3[f];
-                less += kf < mykey;
-                eq += kf == mykey;
-                eq_before += (kf == mykey) && (f < e);
+                const uint32_t f_hi = A3[f];
+                const u64 f_lo = QUAD ? (((u64)A4[f] << 32) | A5[f]) : 0ull;
+                const bool same = f_hi == my_hi && f_lo == my_lo;
+                less += (f_hi < my_hi) || (f_hi == my_hi && f_lo < my_lo);
+                eq += same;
+                eq_before += same && (f < e);
             }
             const uint32_t u = less + eq_before;
             const bool single = eq == 1;
@@ -937,6 +956,9 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
 
         a.h = h;
         a.gate = bt.gateR;
+        // with only TAIL blocks left a round may look three h-blocks ahead: depth 4h instead of 2h
+        // (three gathers per suffix: only once few suffixes are left, where rounds are latency-bound)
+        const bool quad = maxact == 0 && h < (1u << 28) && tot * 10 < ntotal;
         u64 *next_cur = cur, *next_oth = oth;
         if (!maxact) {
             // every unresolved block is in TAIL mode
@@ -984,7 +1006,10 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             ta.h = h;
             ta.T = (maxtail + TAIL_T - 1) / TAIL_T;
             ta.B = B;
-            tail_sort<<<dim3(xcd_grid(ta.T, B)), TAIL_THREADS, 0, st>>>(ta);
+            if (quad)
+                tail_sort<true><<<dim3(xcd_grid(ta.T, B)), TAIL_THREADS, 0, st>>>(ta);
+            else
+                tail_sort<false><<<dim3(xcd_grid(ta.T, B)), TAIL_THREADS, 0, st>>>(ta);
             tail_apply<<<dim3(xcd_grid(ta.T, B)), 256, 0, st>>>(ta);
             tail_scan<<<dim3(B), 512, 0, st>>>(ta);
             tail_compact<<<dim3(xcd_grid(ta.T, B)), 256, 0, st>>>(ta);
@@ -1005,7 +1030,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         }
         prevcnt = nact;
 
-        if (h < (1u << 30)) h <<= 1;
+        if (h < (1u << 30)) h <<= quad ? 2 : 1;
     }
     {
         uint32_t err = 0;

@@ -138,47 +138,77 @@ __global__ void __launch_bounds__(RL_THREADS) plan_starts(PlanArrays pa)
 
 // Single workgroup: lrs -> exclusive prefix max (run start covering each tile's first byte, unless
 // that byte starts a run itself); frs -> suffix min (first run start at or after each tile).
+// 16 tiles per thread per sweep.  Both are unsigned max-scans: a position p is encoded as p+1 for
+// the prefix max and as n-p for the suffix min (taken as a prefix max walking backwards); 0 = none.
+constexpr int PC_PER = 16;
+constexpr uint32_t PC_CHUNK = 1024 * PC_PER;
+
+__device__ __forceinline__ uint32_t block_incl_umax(uint32_t v, uint32_t *lds) // lds: blockDim/64 words
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t x = (uint32_t)__shfl_up((int)v, d, 64);
+        if (lane >= d) v = max(v, x);
+    }
+    if (lane == 63) lds[wave] = v;
+    __syncthreads();
+    uint32_t c = 0;
+    for (int w = 0; w < wave; w++) c = max(c, lds[w]);
+    v = max(v, c);
+    __syncthreads();
+    return v;
+}
+
 __global__ void __launch_bounds__(1024) plan_carries(PlanArrays pa)
 {
-    __shared__ uint32_t sh[1024];
-    const uint32_t t = threadIdx.x, NT = pa.ntiles;
-    // prefix max; NONE32 means "no start yet" -> treat as 0 candidates via +1 encoding
-    uint32_t carry = 0; // encoded value = position + 1, 0 = none
-    for (uint32_t base = 0; base < NT; base += 1024) {
-        const uint32_t e = base + t;
-        const uint32_t raw = e < NT ? pa.lrs[e] : NONE32;
-        sh[t] = raw == NONE32 ? 0u : raw + 1u;
-        __syncthreads();
-        for (uint32_t d = 1; d < 1024; d <<= 1) {
-            const uint32_t x = t >= d ? sh[t - d] : 0u;
-            __syncthreads();
-            sh[t] = max(sh[t], x);
-            __syncthreads();
+    __shared__ uint32_t lm[16];
+    __shared__ uint32_t tailv[1024];
+    const uint32_t t = threadIdx.x, NT = pa.ntiles, n32 = (uint32_t)pa.n;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < NT; base += PC_CHUNK) {
+        const uint32_t e0 = base + t * PC_PER;
+        uint32_t v[PC_PER], run = 0;
+#pragma unroll
+        for (int k = 0; k < PC_PER; k++) {
+            const uint32_t raw = e0 + k < NT ? pa.lrs[e0 + k] : NONE32;
+            v[k] = raw == NONE32 ? 0u : raw + 1u;
+            run = max(run, v[k]);
         }
-        const uint32_t excl = max(carry, t ? sh[t - 1] : 0u);
-        if (e < NT) pa.lrs[e] = excl ? excl - 1u : NONE32;
-        const uint32_t tot = sh[1023];
+        tailv[t] = block_incl_umax(run, lm);
         __syncthreads();
-        carry = max(carry, tot);
+        uint32_t ex = max(carry, t ? tailv[t - 1] : 0u);
+#pragma unroll
+        for (int k = 0; k < PC_PER; k++) {
+            if (e0 + k < NT) pa.lrs[e0 + k] = ex ? ex - 1u : NONE32; // exclusive
+            ex = max(ex, v[k]);
+        }
+        carry = max(carry, tailv[1023]);
+        __syncthreads();
     }
-    // suffix min over frs, frs[NT] = n
-    uint32_t scarry = (uint32_t)pa.n;
-    if (t == 0) pa.frs[NT] = (uint32_t)pa.n;
-    const uint32_t nchunks = (NT + 1023) / 1024;
-    for (uint32_t c = nchunks; c-- > 0;) {
-        const uint32_t e = c * 1024 + t;
-        sh[t] = e < NT ? pa.frs[e] : NONE32;
-        __syncthreads();
-        for (uint32_t d = 1; d < 1024; d <<= 1) {
-            const uint32_t x = t + d < 1024 ? sh[t + d] : NONE32;
-            __syncthreads();
-            sh[t] = min(sh[t], x);
-            __syncthreads();
+    if (t == 0) pa.frs[NT] = n32;
+    carry = 0;
+    for (uint32_t base = 0; base < NT; base += PC_CHUNK) { // base counts tiles from the END
+        const uint32_t r0 = base + t * PC_PER;
+        uint32_t v[PC_PER], run = 0;
+#pragma unroll
+        for (int k = 0; k < PC_PER; k++) {
+            const uint32_t r = r0 + k;
+            const uint32_t raw = r < NT ? pa.frs[NT - 1 - r] : NONE32;
+            v[k] = raw == NONE32 ? 0u : n32 - raw; // >= 1, larger = earlier position
+            run = max(run, v[k]);
         }
-        if (e < NT) pa.frs[e] = min(sh[t], scarry);
-        const uint32_t tot = sh[0];
+        tailv[t] = block_incl_umax(run, lm);
         __syncthreads();
-        scarry = min(scarry, tot);
+        uint32_t ex = max(carry, t ? tailv[t - 1] : 0u);
+#pragma unroll
+        for (int k = 0; k < PC_PER; k++) {
+            const uint32_t r = r0 + k;
+            ex = max(ex, v[k]); // inclusive: first run start at or after the tile's first byte
+            if (r < NT) pa.frs[NT - 1 - r] = ex ? n32 - ex : n32;
+        }
+        carry = max(carry, tailv[1023]);
+        __syncthreads();
     }
 }
 
@@ -241,25 +271,28 @@ __global__ void __launch_bounds__(RL_THREADS) plan_granules(PlanArrays pa)
     }
 }
 
-// Single workgroup: tc = exclusive scan of csum (64-bit), tc[ntiles] = total.
+// Single workgroup: tc = exclusive scan of csum (64-bit), tc[ntiles] = total.  16 tiles per thread:
+// a chunk of 16384 tiles emits < 2^27 bytes, so the in-chunk scan is 32-bit, the carry 64-bit.
 __global__ void __launch_bounds__(1024) plan_tc(PlanArrays pa)
 {
-    __shared__ uint64_t sh[1024];
+    __shared__ uint32_t ls[20];
     uint64_t carry = 0;
     const uint32_t t = threadIdx.x, NT = pa.ntiles;
-    for (uint32_t base = 0; base < NT; base += 1024) {
-        const uint32_t e = base + t;
-        sh[t] = e < NT ? pa.csum[e] : 0;
-        __syncthreads();
-        for (uint32_t d = 1; d < 1024; d <<= 1) {
-            const uint64_t x = t >= d ? sh[t - d] : 0;
-            __syncthreads();
-            sh[t] += x;
-            __syncthreads();
+    for (uint32_t base = 0; base < NT; base += PC_CHUNK) {
+        const uint32_t e0 = base + t * PC_PER;
+        uint32_t v[PC_PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PC_PER; k++) {
+            v[k] = e0 + k < NT ? pa.csum[e0 + k] : 0u;
+            sum += v[k];
         }
-        if (e < NT) pa.tc[e] = carry + (t ? sh[t - 1] : 0);
-        const uint64_t tot = sh[1023];
-        __syncthreads();
+        uint32_t tot;
+        uint32_t ex = block_excl_add(sum, ls, &tot);
+#pragma unroll
+        for (int k = 0; k < PC_PER; k++) {
+            if (e0 + k < NT) pa.tc[e0 + k] = carry + ex;
+            ex += v[k];
+        }
         carry += tot;
     }
     if (t == 0) pa.tc[NT] = carry;

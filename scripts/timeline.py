@@ -3,7 +3,7 @@ f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
 thr = float(sys.argv[2]) if len(sys.argv) > 2 else 100
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('plan_count')]
+idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('plan_starts')]
 seq = rows[idx[-1]:]
 t0 = int(seq[0]['Start_Timestamp'])
 tot = {}
