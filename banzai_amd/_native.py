@@ -47,6 +47,7 @@ SIGNATURES = {
     "bzh_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
     "bzh_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "bzh_set_profiling": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "bzh_set_lanes": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "bzh_get_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Stats)]),
     "bzh_encode": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_size_t, u8p, ctypes.c_size_t, szp, szp]),
     "bzh_encode_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
@@ -148,6 +149,9 @@ class Context:
 
     def set_profiling(self, on=True):
         self.check(lib().bzh_set_profiling(self._h, 1 if on else 0))
+
+    def set_lanes(self, lanes):
+        self.check(lib().bzh_set_lanes(self._h, lanes))
 
     def stats(self):
         s = Stats()

@@ -8,6 +8,9 @@
 //   assemble: "BZh9", stream CRC fold, footer
 #include <stdarg.h>
 #include <algorithm>
+#include <future>
+#include <memory>
+#include <thread>
 
 #include "common.h"
 
@@ -121,8 +124,10 @@ extern "C" int bzh_create(bzh_ctx **out, int device, int level, int max_batch)
     ctx->level = level;
     ctx->M = 100000u * (uint32_t)level - 1u; // lib/rle.rs:121
     ctx->max_batch = max_batch ? (uint32_t)max_batch : 128u;
-    Batch probe{};
+    Batch probe{}, probe2{};
     ctx->arena_size = layout_batch(probe, nullptr, ctx->max_batch, ctx->M);
+    // the same memory also serves as two half-batch arenas (lanes, see ensure_lanes)
+    ctx->arena_size = std::max(ctx->arena_size, 2 * layout_batch(probe2, nullptr, std::max<uint32_t>(1, ctx->max_batch / 2), ctx->M));
     if (probe.TPB > 1024 || ctx->max_batch > 1024) {
         delete ctx;
         return BZH_E_ARG;
@@ -148,6 +153,12 @@ extern "C" void bzh_destroy(bzh_ctx *ctx)
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
     for (hipEvent_t e : ctx->evpool) hipEventDestroy(e);
+    for (bzh_ctx *l : ctx->lanes) {
+        for (hipEvent_t e : l->evpool) hipEventDestroy(e);
+        if (l->stream) hipStreamDestroy(l->stream);
+        if (l->h_pinned) hipHostFree(l->h_pinned);
+        delete l;
+    }
     if (ctx->arena) hipFree(ctx->arena);
     if (ctx->plan_ws) hipFree(ctx->plan_ws);
     if (ctx->d_stage_in) hipFree(ctx->d_stage_in);
@@ -163,6 +174,13 @@ extern "C" int bzh_set_stream(bzh_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return BZH_E_ARG;
     ctx->stream = (hipStream_t)hip_stream;
+    return BZH_OK;
+}
+
+extern "C" int bzh_set_lanes(bzh_ctx *ctx, int lanes)
+{
+    if (!ctx || (lanes != 1 && lanes != 2)) return BZH_E_ARG;
+    ctx->nlanes = lanes;
     return BZH_OK;
 }
 
@@ -413,6 +431,68 @@ static float span_ms(hipEvent_t a, hipEvent_t b)
     return hipEventElapsedTime(&t, a, b) == hipSuccess ? t : 0.f;
 }
 
+// ---- lanes: two half-batch workers so that one half's latency-bound phases (tail rounds of the
+// suffix sort, the Huffman heap, per-round read-backs) overlap the other half's bandwidth-bound kernels
+static int ensure_lanes(bzh_ctx *ctx)
+{
+    if (!ctx->lanes.empty()) return BZH_OK;
+    const uint32_t lane_mb = std::max<uint32_t>(1, ctx->max_batch / 2);
+    Batch probe{};
+    const size_t half = layout_batch(probe, nullptr, lane_mb, ctx->M);
+    if (2 * half > ctx->arena_size) return BZH_E_NOMEM; // bzh_create sizes the arena for both views
+    for (int k = 0; k < 2; k++) {
+        bzh_ctx *l = new (std::nothrow) bzh_ctx();
+        if (!l) return BZH_E_NOMEM;
+        l->parent = ctx;
+        l->device = ctx->device;
+        l->level = ctx->level;
+        l->M = ctx->M;
+        l->max_batch = lane_mb;
+        layout_batch(l->bt, ctx->arena + (size_t)k * half, lane_mb, ctx->M);
+        l->S = l->bt.S;
+        if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess ||
+            hipHostMalloc((void **)&l->h_pinned, sizeof(uint32_t) * (lane_mb * 8 + 64)) != hipSuccess) {
+            delete l;
+            return BZH_E_NOMEM;
+        }
+        ctx->lanes.push_back(l);
+    }
+    return BZH_OK;
+}
+
+struct RangeJob {
+    size_t k0 = 0;
+    uint32_t B = 0, nmax = 0, mmax = 0;
+    uint64_t ntotal = 0, T = 0;
+    int status = BZH_OK;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::promise<void> ready, packed;
+};
+
+// Everything of a batch up to its bit total, on the lane's stream and arena.
+static int prepare_batch(bzh_ctx *lane, RangeJob &j)
+{
+    hipStream_t st = lane->stream;
+    auto mark = [&](int i) {
+        if (lane->profiling) {
+            j.ev[i] = bzh_event(lane);
+            hipEventRecord(j.ev[i], st);
+        }
+    };
+    mark(0);
+    BZH_TRY(rle1_emit(lane, j.k0, j.B));
+    mark(1);
+    BZH_TRY(bwt_run(lane, j.B, j.nmax, j.ntotal));
+    mark(2);
+    BZH_TRY(mtf_run(lane, j.B, j.nmax));
+    mark(3);
+    BZH_TRY(huff_prepare(lane, j.B, j.mmax));
+    mark(4);
+    HIP_TRY(lane, hipMemcpyAsync(&j.T, lane->bt.bitoff + j.B, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(lane, hipStreamSynchronize(st));
+    return BZH_OK;
+}
+
 // Encodes plan blocks [b0, b1) into d_out starting at bit `bit_base`; words of d_out from
 // bit_base/32 on are zeroed here as needed (words before that are the caller's).
 static int encode_range(bzh_ctx *ctx, size_t b0, size_t b1, uint8_t *d_out, size_t cap, uint64_t bit_base,
@@ -422,76 +502,139 @@ static int encode_range(bzh_ctx *ctx, size_t b0, size_t b1, uint8_t *d_out, size
         bzh_set_error(ctx, "output buffer must be 4-byte aligned");
         return BZH_E_ARG;
     }
-    hipStream_t st = ctx->stream;
-    Batch &bt = ctx->bt;
-    const uint64_t cap_words = cap / 4;
-    uint64_t zeroed_upto = bit_base / 32; // first word not yet known to be zero (exclusive bound of zeroed range)
-    uint64_t cur = 0;
-    struct Ev { hipEvent_t e[6]; };
-    std::vector<Ev> evs;
-    for (size_t k0 = b0; k0 < b1; k0 += ctx->max_batch) {
-        const uint32_t B = (uint32_t)std::min<size_t>(ctx->max_batch, b1 - k0);
-        uint32_t nmax = 0;
-        uint64_t ntotal = 0;
-        for (uint32_t b = 0; b < B; b++) {
-            nmax = std::max(nmax, ctx->plan_blocks[k0 + b].rle_len);
-            ntotal += ctx->plan_blocks[k0 + b].rle_len;
-            ctx->stats.rle_bytes += ctx->plan_blocks[k0 + b].rle_len;
-            ctx->stats.raw_bytes += ctx->plan_blocks[k0 + b].in_len;
+    // default: one lane = this context (whole arena, caller's stream, no extra threads)
+    std::vector<bzh_ctx *> lanes{ctx};
+    if (ctx->nlanes == 2) {
+        BZH_TRY(ensure_lanes(ctx));
+        lanes = ctx->lanes;
+    }
+    const size_t NL = lanes.size();
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // the plan and whatever produced the input
+    const size_t nb = b1 - b0;
+    const uint32_t lane_mb = lanes[0]->max_batch;
+    size_t njobs = (nb + lane_mb - 1) / lane_mb;
+    if (njobs < NL && nb >= NL) njobs = NL; // give every lane work
+    const size_t per = (nb + njobs - 1) / njobs;
+    std::vector<std::unique_ptr<RangeJob>> jobs;
+    for (size_t k0 = b0; k0 < b1; k0 += per) {
+        auto j = std::make_unique<RangeJob>();
+        j->k0 = k0;
+        j->B = (uint32_t)std::min<size_t>(per, b1 - k0);
+        for (uint32_t b = 0; b < j->B; b++) {
+            const bzh_block &pb = ctx->plan_blocks[k0 + b];
+            j->nmax = std::max(j->nmax, pb.rle_len);
+            j->ntotal += pb.rle_len;
+            ctx->stats.rle_bytes += pb.rle_len;
+            ctx->stats.raw_bytes += pb.in_len;
         }
-        ctx->stats.blocks += B;
-        Ev ev{};
-        auto mark = [&](int i) {
-            if (ctx->profiling) {
-                ev.e[i] = bzh_event(ctx);
-                hipEventRecord(ev.e[i], st);
-            }
-        };
-        mark(0);
-        BZH_TRY(rle1_emit(ctx, k0, B));
-        mark(1);
-        BZH_TRY(bwt_run(ctx, B, nmax, ntotal));
-        mark(2);
-        BZH_TRY(mtf_run(ctx, B, nmax));
-        mark(3);
-        const uint32_t mmax = nmax + 1; // m <= n + 1 (lib/mtf.rs:36)
-        BZH_TRY(huff_prepare(ctx, B, mmax));
-        mark(4);
-        uint64_t T = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&T, bt.bitoff + B, 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));
-        const uint64_t need_upto = (bit_base + cur + T + 31) / 32 + 1;
-        if (need_upto > cap_words) {
-            bzh_set_error(ctx, "output needs more than %zu bytes", cap);
-            return BZH_E_CAP;
-        }
-        if (need_upto > zeroed_upto) {
-            HIP_TRY(ctx, hipMemsetAsync(d_out + zeroed_upto * 4, 0, (size_t)(need_upto - zeroed_upto) * 4, st));
-            if (seed_word && zeroed_upto == bit_base / 32) // bits already owed to the word the range starts in
-                HIP_TRY(ctx, hipMemcpyAsync(d_out + zeroed_upto * 4, seed_word, 4, hipMemcpyHostToDevice, st));
-            zeroed_upto = need_upto;
-        }
-        BZH_TRY(huff_pack(ctx, B, mmax, d_out, bit_base + cur));
-        mark(5);
-        cur += T;
-        if (ctx->profiling) {
-            evs.push_back(ev);
-            std::vector<uint32_t> hm(B);
-            HIP_TRY(ctx, hipMemcpyAsync(hm.data(), bt.m, B * 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(ctx, hipStreamSynchronize(st));
-            for (uint32_t b = 0; b < B; b++) ctx->stats.mtf_syms += hm[b];
+        j->mmax = j->nmax + 1; // m <= n + 1 (lib/mtf.rs:36)
+        ctx->stats.blocks += j->B;
+        jobs.push_back(std::move(j));
+    }
+    bzh_stats keep = ctx->stats; // one-lane mode: the lane is ctx itself
+    for (bzh_ctx *l : lanes) {
+        l->profiling = ctx->profiling;
+        l->sort_spans.clear();
+        if (l != ctx) {
+            l->evnext = 0;
+            memset(&l->stats, 0, sizeof l->stats);
+            l->err[0] = 0;
+        } else {
+            ctx->stats.bwt_active_sum = 0;
+            ctx->stats.bwt_rounds = 0;
+            ctx->stats.bwt_sort_launches = 0;
+            ctx->stats.bwt_sort_elems = 0;
         }
     }
-    if (ctx->profiling) {
-        HIP_TRY(ctx, hipStreamSynchronize(st));
-        for (auto &ev : evs) {
-            ctx->stats.ms_rle1 += span_ms(ev.e[0], ev.e[1]);
-            ctx->stats.ms_bwt += span_ms(ev.e[1], ev.e[2]);
-            ctx->stats.ms_mtf += span_ms(ev.e[2], ev.e[3]);
-            ctx->stats.ms_huff += span_ms(ev.e[3], ev.e[4]);
-            ctx->stats.ms_pack += span_ms(ev.e[4], ev.e[5]);
+    (void)keep;
+    // lane k prepares jobs k, k+2, ...; it may reuse its arena only after the job was packed
+    auto worker = [&](int k) {
+        hipSetDevice(ctx->device);
+        bool dead = false;
+        for (size_t j = k; j < jobs.size(); j += NL) {
+            RangeJob &job = *jobs[j];
+            job.status = dead ? BZH_E_STATE : prepare_batch(lanes[k], job);
+            if (job.status != BZH_OK) dead = true;
+            job.ready.set_value();
+            job.packed.get_future().wait();
         }
-        stats_collect_sort(ctx);
+    };
+    std::vector<std::thread> threads;
+    if (NL > 1)
+        for (size_t k = 0; k < NL; k++) threads.emplace_back(worker, (int)k);
+
+    const uint64_t cap_words = cap / 4;
+    uint64_t zeroed_upto = bit_base / 32; // first word not yet known to be zero
+    uint64_t cur = 0;
+    int status = BZH_OK;
+    for (size_t j = 0; j < jobs.size(); j++) {
+        RangeJob &job = *jobs[j];
+        bzh_ctx *lane = lanes[j % NL];
+        if (NL == 1) { // no worker thread: prepare here
+            job.status = status == BZH_OK ? prepare_batch(lane, job) : BZH_E_STATE;
+            job.ready.set_value();
+        }
+        job.ready.get_future().wait();
+        if (status == BZH_OK && job.status != BZH_OK) {
+            status = job.status;
+            if (lane != ctx) bzh_set_error(ctx, "%s", lane->err);
+        }
+        if (status == BZH_OK) {
+            hipStream_t st = lane->stream;
+            const uint64_t need_upto = (bit_base + cur + job.T + 31) / 32 + 1;
+            hipError_t he = hipSuccess;
+            if (need_upto > cap_words) {
+                bzh_set_error(ctx, "output needs more than %zu bytes", cap);
+                status = BZH_E_CAP;
+            } else {
+                if (need_upto > zeroed_upto) {
+                    he = hipMemsetAsync(d_out + zeroed_upto * 4, 0, (size_t)(need_upto - zeroed_upto) * 4, st);
+                    if (he == hipSuccess && seed_word && zeroed_upto == bit_base / 32) // bits owed to the first word
+                        he = hipMemcpyAsync(d_out + zeroed_upto * 4, seed_word, 4, hipMemcpyHostToDevice, st);
+                    zeroed_upto = need_upto;
+                }
+                if (he == hipSuccess) status = huff_pack(lane, job.B, job.mmax, d_out, bit_base + cur);
+                if (lane->profiling && status == BZH_OK) {
+                    job.ev[5] = bzh_event(lane);
+                    hipEventRecord(job.ev[5], st);
+                    std::vector<uint32_t> hm(job.B);
+                    he = hipMemcpyAsync(hm.data(), lane->bt.m, job.B * 4, hipMemcpyDeviceToHost, st);
+                    if (he == hipSuccess) he = hipStreamSynchronize(st);
+                    for (uint32_t b = 0; b < job.B; b++) ctx->stats.mtf_syms += hm[b];
+                }
+                if (he == hipSuccess) he = hipStreamSynchronize(st); // the lane's arena is free again
+                if (he != hipSuccess) {
+                    bzh_set_error(ctx, "pack: %s", hipGetErrorString(he));
+                    status = BZH_E_HIP;
+                }
+                cur += job.T;
+            }
+        }
+        job.packed.set_value();
+    }
+    for (auto &t : threads) t.join();
+    if (status != BZH_OK) return status;
+    if (ctx->profiling) {
+        for (auto &jp : jobs) {
+            RangeJob &job = *jp;
+            ctx->stats.ms_rle1 += span_ms(job.ev[0], job.ev[1]);
+            ctx->stats.ms_bwt += span_ms(job.ev[1], job.ev[2]);
+            ctx->stats.ms_mtf += span_ms(job.ev[2], job.ev[3]);
+            ctx->stats.ms_huff += span_ms(job.ev[3], job.ev[4]);
+            ctx->stats.ms_pack += span_ms(job.ev[4], job.ev[5]);
+        }
+        for (bzh_ctx *l : lanes) {
+            stats_collect_sort(l);
+            if (l == ctx) continue;
+            ctx->stats.ms_bwt_sort += l->stats.ms_bwt_sort;
+            ctx->stats.bwt_sort_launches += l->stats.bwt_sort_launches;
+            ctx->stats.bwt_sort_elems += l->stats.bwt_sort_elems;
+        }
+    }
+    for (bzh_ctx *l : lanes) {
+        if (l == ctx) continue;
+        ctx->stats.bwt_active_sum += l->stats.bwt_active_sum;
+        ctx->stats.bwt_rounds = std::max(ctx->stats.bwt_rounds, l->stats.bwt_rounds);
     }
     ctx->stats.out_bits += cur;
     *nbits = cur;

@@ -103,6 +103,9 @@ struct Timer {
 };
 
 struct bzh_ctx {
+    bzh_ctx *parent = nullptr;        // lanes: the context that owns the plan and the arena
+    std::vector<bzh_ctx *> lanes;     // two half-batch workers (own stream, half of the arena each)
+    int nlanes = 1;                   // 1: batches run one after the other on this context; 2: on the lanes
     int device = 0;
     int level = 9;
     uint32_t M = 0;

@@ -853,17 +853,18 @@ int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n)
 int rle1_emit(bzh_ctx *ctx, size_t b0, uint32_t B)
 {
     if (B == 0) return BZH_OK;
-    PlanWs w = plan_layout((uint8_t *)ctx->plan_ws, ctx->plan_n, ctx->M);
+    const bzh_ctx *pc = ctx->parent ? ctx->parent : ctx; // lanes read the owner's plan
+    PlanWs w = plan_layout((uint8_t *)pc->plan_ws, pc->plan_n, pc->M);
     EmitArgs ea{};
-    ea.in = ctx->plan_in;
-    ea.n = ctx->plan_n;
+    ea.in = pc->plan_in;
+    ea.n = pc->plan_n;
     ea.rsg = w.pa.rsg;
     ea.tc = w.pa.tc;
     ea.blocks = w.pa.blocks + b0;
     ea.aux = w.pa.aux + b0;
     uint64_t maxspan = 0;
     for (uint32_t b = 0; b < B; b++) {
-        const bzh_block &pb = ctx->plan_blocks[b0 + b];
+        const bzh_block &pb = pc->plan_blocks[b0 + b];
         const uint64_t t0 = pb.in_off / RL_TILE, t1 = (pb.in_off + pb.in_len - 1) / RL_TILE;
         maxspan = std::max<uint64_t>(maxspan, t1 - t0 + 1);
     }

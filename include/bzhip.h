@@ -70,6 +70,10 @@ BZH_API const char *bzh_strerror(int status);
 BZH_API const char *bzh_last_error(const bzh_ctx *ctx); /* detail of the last failure on this ctx   */
 BZH_API int bzh_set_stream(bzh_ctx *ctx, void *hip_stream); /* hipStream_t to launch on (default 0) */
 BZH_API int bzh_set_profiling(bzh_ctx *ctx, int enabled);
+/* 1 (default): batches run one after the other on the context's stream.  2: two half-batch lanes on
+ * internal streams and host threads overlap latency-bound phases (+2-3 % throughput on MI355X, but
+ * concurrent kernels stretch each other's durations, so per-kernel timings no longer add up). */
+BZH_API int bzh_set_lanes(bzh_ctx *ctx, int lanes);
 BZH_API int bzh_get_stats(const bzh_ctx *ctx, bzh_stats *out);
 
 /* ---- whole path: replaces banzai::encode(reader, writer, level), lib/lib.rs:84-132 -------- */

@@ -275,6 +275,16 @@ def test_device_path_and_sharded_equals_monolithic(oracle, native):
         assert d_out[:ln2].cpu().numpy().tobytes() == want
 
 
+def test_two_lanes_same_bytes(oracle, native):
+    """bzh_set_lanes(2): half-batches prepared concurrently on two internal streams, packed in order"""
+    d = cases.gen(3_000_001, "text", 9) + cases.repeats(1_500_000, 9) + cases.gen(400_000, "longruns", 9)
+    with native.Context(0, 1, 8) as ctx:  # level 1: ~49 blocks -> 13 jobs over two lanes
+        ctx.set_lanes(2)
+        assert ctx.encode(d) == oracle.encode(d, 1)
+        ctx.set_lanes(1)
+        assert ctx.encode(d) == oracle.encode(d, 1)
+
+
 def test_output_capacity_error(native):
     import torch
     dev = torch.device("cuda", 0)
