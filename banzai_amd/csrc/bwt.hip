@@ -507,7 +507,6 @@ constexpr int TAIL_PER = TAIL_W / TAIL_THREADS; // 10 slots per thread
 constexpr u64 LIST_INVALID = ~0ull;
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 constexpr uint32_t TAIL_BUF_B = 0x80000000u; // gateT bit: the block's list lives in listB
-constexpr uint32_t TAIL_RECS = 0x40000000u;  // gateT bit: slots hold records of the previous tail round
 constexpr uint32_t TAIL_LEN = 0x3FFFFFFFu;
 
 struct TailArgs {
@@ -553,16 +552,15 @@ __global__ void __launch_bounds__(TAIL_THREADS) tail_sort(TailArgs a)
             const uint32_t sl = s_lo + w;
             const u64 x = buf[sl];
             if (x != LIST_INVALID) {
+                // Only the suffix index is taken from the slot.  The group rank must come from the rank
+                // array, which no one writes during this kernel: a neighbour that has already rewritten
+                // the slots of a group spanning into this window left NEW ranks in its records.
                 i = (uint32_t)(x & SUF_MASK);
-                if (lenw & TAIL_RECS) {
-                    r = (uint32_t)(x >> 40) & 0xFFFFFu; // compacted survivors carry their current rank
-                } else {
-                    const uint32_t rr = rank[i];
-                    if (!(rr & RANK_RESOLVED))
-                        r = rr;
-                    else if (sl >= r0 && sl < r1)
-                        buf[sl] = LIST_INVALID; // resolved before: a hole for tail_apply / tail_compact
-                }
+                const uint32_t rr = rank[i];
+                if (!(rr & RANK_RESOLVED))
+                    r = rr;
+                else if (sl >= r0 && sl < r1)
+                    buf[sl] = LIST_INVALID; // resolved before: a hole for tail_apply / tail_compact
             }
         }
         A0[w] = r;
@@ -919,7 +917,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
                 taillen[b] = hprev[b] | (cur == bufB ? TAIL_BUF_B : 0u);
             }
             if (tailmode[b] == 2) // compacted last round: the list moved to the other buffer
-                taillen[b] = hact[b] | ((taillen[b] & TAIL_BUF_B) ^ TAIL_BUF_B) | TAIL_RECS;
+                taillen[b] = hact[b] | ((taillen[b] & TAIL_BUF_B) ^ TAIL_BUF_B);
             if (tailmode[b]) {
                 tailmode[b] = 2;
                 hgR[b] = 0;
