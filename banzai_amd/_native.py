@@ -118,14 +118,15 @@ class Context:
     def __init__(self, device=0, level=9, max_batch=0):
         self._h = ctypes.c_void_p()
         self.level = level
+        self._destroy = lib().bzh_destroy  # kept so that close() still works during interpreter shutdown
         st = lib().bzh_create(ctypes.byref(self._h), device, level, max_batch)
         if st != 0:
             self._h = None
             raise BzhError(st, lib().bzh_strerror(st).decode())
 
     def close(self):
-        if self._h:
-            lib().bzh_destroy(self._h)
+        if getattr(self, "_h", None):
+            self._destroy(self._h)
             self._h = None
 
     __del__ = close
