@@ -7,10 +7,11 @@
 //
 // Method: cyclic prefix doubling, all bzip2 blocks of a batch at once.  Every sort element is one
 // 64-bit word
-//      init pass :  [ 4-byte cyclic prefix : 32 ][ 0 : 12 ][ suffix : 20 ]
+//      init pass :  [ 4 bytes of the cyclic prefix : 32 ][ 0 : 12 ][ suffix : 20 ]
 //      rounds    :  [ 0:4 ][ group rank r : 20 ][ key2 = rank[i+h] : 20 ][ suffix i : 20 ]
 // (n < 2^20 at every level).  rank = first SA position of the suffix's group, bit 31 = resolved.
-// Initial LSD radix sort on the prefix (4 passes x 8 bits).  A doubling round with depth h comes
+// Initial LSD radix sort on the 8-byte prefix (8 passes x 8 bits, key half swapped after pass 4).
+// A doubling round with depth h comes
 // in two forms, chosen per round from the unresolved fraction:
 //   SWEEP  (most suffixes unresolved): unresolved suffixes are ENUMERATED in SA order of suffix
 //          i+h (a coalesced sweep of SA + rank gathers) and stably sorted by r only -- 3 passes of
@@ -79,20 +80,26 @@ __device__ __forceinline__ bool wg_map(uint32_t T, uint32_t B, uint32_t &b, uint
 
 static inline uint32_t xcd_grid(uint32_t tiles, uint32_t B) { return 8u * ((B + 7u) / 8u) * tiles; }
 
+// 4 bytes of the cyclic text starting at position i (big-endian), i < n.
+__device__ __forceinline__ uint32_t text4(const uint8_t *s, uint32_t i, uint32_t n)
+{
+    uint32_t i1 = i + 1, i2 = i + 2, i3 = i + 3;
+    if (i3 >= n) { // cyclic wrap (n may be smaller than 4)
+        i1 %= n;
+        i2 %= n;
+        i3 %= n;
+    }
+    return ((uint32_t)s[i] << 24) | ((uint32_t)s[i1] << 16) | ((uint32_t)s[i2] << 8) | (uint32_t)s[i3];
+}
+
 // WANT_K2 = false for histogram passes that only look at the r digits.
 template <int MODE, bool WANT_K2>
 __device__ __forceinline__ bool gen_elem(const SortArgs &a, uint32_t b, uint32_t e, uint32_t n, u64 &v)
 {
     const size_t base = (size_t)b * a.S;
     if (MODE == GEN_BYTES4) {
-        const uint8_t *s = a.blk + base;
-        uint32_t i1 = e + 1, i2 = e + 2, i3 = e + 3;
-        if (i3 >= n) { // cyclic wrap (n may be smaller than 4)
-            i1 %= n;
-            i2 %= n;
-            i3 %= n;
-        }
-        const uint32_t key = ((uint32_t)s[e] << 24) | ((uint32_t)s[i1] << 16) | ((uint32_t)s[i2] << 8) | (uint32_t)s[i3];
+        // a.h = byte offset of the key inside the rotation (4 for the low half of the 8-byte prefix)
+        const uint32_t key = text4(a.blk + base, (e + a.h) % n, n);
         v = ((u64)key << 32) | e;
         return true;
     } else if (MODE == GEN_SWEEP) {
@@ -158,11 +165,13 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_hist(SortArgs a)
     for (int k = threadIdx.x; k < NB; k += SORT_THREADS) out[(size_t)k * a.TPB + tile] = h[k];
 }
 
-// One workgroup per bzip2 block: exclusive scan of hist over (digit major, tile minor).
+// One workgroup per bzip2 block: exclusive scan of hist over (digit major, tile minor), 16 entries
+// per thread and sweep.
 template <int BITS>
 __global__ void __launch_bounds__(1024) radix_scan(SortArgs a)
 {
     constexpr int NB = 1 << BITS;
+    constexpr int PER = 16;
     const uint32_t b = blockIdx.x;
     if (a.gate[b] == 0) return;
     const uint32_t cnt = a.cnt[b];
@@ -171,22 +180,39 @@ __global__ void __launch_bounds__(1024) radix_scan(SortArgs a)
     uint32_t *hist = a.hist + (size_t)b * NBMAX * a.TPB;
     __shared__ uint32_t lds[20];
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < total; base += 1024) {
-        const uint32_t e = base + threadIdx.x;
-        uint32_t addr = 0, v = 0;
-        if (e < total) {
-            const uint32_t bin = e / ntile, t = e - bin * ntile;
-            addr = bin * a.TPB + t;
-            v = hist[addr];
+    for (uint32_t base = 0; base < total; base += 1024 * PER) {
+        const uint32_t e0 = base + threadIdx.x * PER;
+        uint32_t v[PER], addr[PER], sum = 0;
+        // entry e -> (bin = e / ntile, tile = e % ntile); consecutive entries advance the tile
+        uint32_t bin = e0 < total ? e0 / ntile : 0, t = e0 < total ? e0 - bin * ntile : 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            v[k] = 0;
+            addr[k] = 0;
+            if (e0 + k < total) {
+                addr[k] = bin * a.TPB + t;
+                v[k] = hist[addr[k]];
+                if (++t == ntile) {
+                    t = 0;
+                    bin++;
+                }
+            }
+            sum += v[k];
         }
         uint32_t tot;
-        const uint32_t ex = block_excl_add(v, lds, &tot);
-        if (e < total) hist[addr] = carry + ex;
+        uint32_t ex = carry + block_excl_add(sum, lds, &tot);
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            if (e0 + k < total) hist[addr[k]] = ex;
+            ex += v[k];
+        }
         carry += tot;
     }
 }
 
-template <int BITS, int MODE>
+// REKEY: the element leaves with the key of the NEXT key half (bytes i..i+3 of the rotation) --
+// used by the last pass over the low half of the 8-byte prefix.
+template <int BITS, int MODE, bool REKEY = false>
 __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
 {
     constexpr int NB = 1 << BITS;
@@ -264,8 +290,12 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
     __syncthreads();
     u64 *dst = a.dst + (size_t)b * a.S;
     for (uint32_t e = threadIdx.x; e < tile_total; e += SORT_THREADS) {
-        const u64 x = stage[e];
+        u64 x = stage[e];
         const uint32_t d = (uint32_t)(x >> a.shift) & (NB - 1);
+        if (REKEY) {
+            const uint32_t i = (uint32_t)(x & SUF_MASK);
+            x = ((u64)text4(a.blk + (size_t)b * a.S, i, n) << 32) | i;
+        }
         dst[goff[d] + (e - binstart[d])] = x;
     }
 }
@@ -275,6 +305,7 @@ struct RefineArgs {
     const uint32_t *n;   // [B]
     const uint32_t *cnt; // [B] list length (n for the init pass, unresolved count in rounds)
     const u64 *list;     // [B][S] sorted elements
+    const uint8_t *blk;  // [B][S] the text (init pass: low half of the 8-byte prefix is compared from it)
     uint32_t *rank;      // [B][S]
     uint32_t *sa;        // [B][S]
     uint32_t *headp;     // [B][S]
@@ -303,11 +334,13 @@ __device__ __forceinline__ void stage_tile(const u64 *list, uint32_t tile0, uint
     }
 }
 
-__device__ __forceinline__ void elem_flags(const RefineArgs &a, uint32_t q, u64 cur, u64 prev, bool &gs, bool &bd)
+// lo/plo: bytes 4..7 of the rotations of cur / prev (init pass only)
+__device__ __forceinline__ void elem_flags(const RefineArgs &a, uint32_t q, u64 cur, u64 prev, uint32_t lo, uint32_t plo,
+                                           bool &gs, bool &bd)
 {
     if (a.init) {
         gs = (q == 0);
-        bd = gs || (cur >> 32) != (prev >> 32);
+        bd = gs || (cur >> 32) != (prev >> 32) || lo != plo;
     } else {
         gs = (q == 0) || (cur >> 40) != (prev >> 40);
         bd = gs || (cur >> 20) != (prev >> 20);
@@ -334,13 +367,20 @@ __global__ void __launch_bounds__(SORT_THREADS) flag_tiles(RefineArgs a)
     int lastgs = -1, lastbd = -1;
     if (q0 < cnt) {
         u64 prev = e0 ? lds[slot_of(e0 - 1)] : (q0 ? list[q0 - 1] : 0ull);
+        const uint32_t n = a.n[b];
+        const uint8_t *txt = a.blk + base;
+        uint32_t plo = 0;
+        if (a.init && q0) plo = text4(txt, ((uint32_t)(prev & SUF_MASK) + 4u) % n, n);
 #pragma unroll
         for (int k = 0; k < SORT_ITEMS; k++) {
             const uint32_t q = q0 + k;
             if (q < cnt) {
                 const u64 cur = lds[slot_of(e0 + k)];
+                uint32_t lo = 0;
+                if (a.init) lo = text4(txt, ((uint32_t)(cur & SUF_MASK) + 4u) % n, n);
                 bool gs, bd;
-                elem_flags(a, q, cur, prev, gs, bd);
+                elem_flags(a, q, cur, prev, lo, plo, gs, bd);
+                plo = lo;
                 if (gs) lastgs = (int)q;
                 if (bd) lastbd = (int)q;
                 packed[k >> 2] |= ((gs ? 1u : 0u) | (bd ? 2u : 0u)) << ((k & 3) * 8);
@@ -802,6 +842,29 @@ static void launch_pass(bzh_ctx *ctx, SortArgs &a, uint32_t B, uint32_t maxcnt, 
     }
 }
 
+static void launch_rekey_pass(bzh_ctx *ctx, SortArgs &a, uint32_t B, uint32_t maxcnt, uint64_t elems)
+{
+    const uint32_t tiles = (maxcnt + SORT_TILE - 1) / SORT_TILE;
+    if (tiles == 0) return;
+    a.T = tiles;
+    a.B = B;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    radix_hist<8, GEN_LIST><<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(a);
+    radix_scan<8><<<dim3(B), 1024, 0, ctx->stream>>>(a);
+    if (ctx->profiling) {
+        e0 = bzh_event(ctx);
+        hipEventRecord(e0, ctx->stream);
+    }
+    radix_scatter<8, GEN_LIST, true><<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(a);
+    if (ctx->profiling) {
+        e1 = bzh_event(ctx);
+        hipEventRecord(e1, ctx->stream);
+        ctx->sort_spans.push_back({e0, e1});
+        ctx->stats.bwt_sort_launches += 1;
+        ctx->stats.bwt_sort_elems += elems;
+    }
+}
+
 static void launch_refine(bzh_ctx *ctx, RefineArgs &r, uint32_t B, uint32_t maxcnt)
 {
     const uint32_t tiles = (maxcnt + SORT_TILE - 1) / SORT_TILE;
@@ -833,23 +896,31 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     a.TPB = bt.TPB;
     a.h = 0;
 
-    // ---- initial sort on the 4-byte cyclic prefix: 4 passes of 8 bits over bits 32..63 ---------
+    // ---- initial sort on the 8-byte cyclic prefix: LSD, 8 passes of 8 bits.  Passes 0-3 order by
+    // bytes 4..7 of the rotation (the key field holds them), the scatter of pass 3 swaps in bytes 0..3,
+    // passes 4-7 order by those.  A plain pass over every suffix costs far less than a doubling round
+    // does per suffix, so this replaces "4-byte sort + refine + first doubling round".
     a.cnt = bt.n;
     a.gate = bt.n;
     a.shift = 32;
+    a.h = 4; // key offset for GEN_BYTES4
     a.src = nullptr;
     a.dst = bufA;
     launch_pass<8, GEN_BYTES4>(ctx, a, B, nmax, ntotal);
     u64 *cur = bufA, *oth = bufB;
-    for (int p = 1; p < 4; p++) {
-        a.shift = 32 + 8 * p;
+    for (int p = 1; p < 8; p++) {
+        a.shift = 32 + 8 * (p & 3);
         a.src = cur;
         a.dst = oth;
-        launch_pass<8, GEN_LIST>(ctx, a, B, nmax, ntotal);
+        if (p == 3)
+            launch_rekey_pass(ctx, a, B, nmax, ntotal);
+        else
+            launch_pass<8, GEN_LIST>(ctx, a, B, nmax, ntotal);
         u64 *t = cur;
         cur = oth;
         oth = t;
     }
+    a.h = 0;
 
     // three rotating count arrays: length of the list in `cur` (prevcnt), unresolved counts of the
     // round being sorted (nact), counts that round's refine accumulates (nact_next)
@@ -864,6 +935,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     r.n = bt.n;
     r.cnt = bt.n;
     r.list = cur;
+    r.blk = bt.rle;
     r.rank = bt.rank;
     r.sa = bt.sa;
     r.headp = bt.headp;
@@ -887,7 +959,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     std::vector<uint8_t> tailmode(B, 0);
     bool active_mode = false, have_n = false;
     const uint32_t *prevcnt = bt.n; // device: length of the list `cur` per block (radix blocks)
-    uint32_t h = 4;
+    uint32_t h = 8; // the initial sort ordered the rotations by their first 8 bytes
     TailArgs ta{};
     ta.n = bt.n;
     ta.len = bt.gateT;
