@@ -83,13 +83,22 @@ static inline uint32_t xcd_grid(uint32_t tiles, uint32_t B) { return 8u * ((B + 
 // 4 bytes of the cyclic text starting at position i (big-endian), i < n.
 __device__ __forceinline__ uint32_t text4(const uint8_t *s, uint32_t i, uint32_t n)
 {
-    uint32_t i1 = i + 1, i2 = i + 2, i3 = i + 3;
-    if (i3 >= n) { // cyclic wrap (n may be smaller than 4)
-        i1 %= n;
-        i2 %= n;
-        i3 %= n;
+    if (i + 3 < n) { // one (possibly unaligned) dword load; gfx950 global loads need no alignment
+        uint32_t w;
+        __builtin_memcpy(&w, s + i, 4);
+        return __builtin_bswap32(w);
     }
+    // cyclic wrap (n may be smaller than 4)
+    const uint32_t i1 = (i + 1) % n, i2 = (i + 2) % n, i3 = (i + 3) % n;
     return ((uint32_t)s[i] << 24) | ((uint32_t)s[i1] << 16) | ((uint32_t)s[i2] << 8) | (uint32_t)s[i3];
+}
+
+// (suffix of x + 4) mod n
+__device__ __forceinline__ uint32_t wrap_add(u64 x, uint32_t n)
+{
+    uint32_t i = (uint32_t)(x & SUF_MASK) + 4u;
+    if (i >= n) i = n > 4 ? i - n : i % n;
+    return i;
 }
 
 // WANT_K2 = false for histogram passes that only look at the r digits.
@@ -99,7 +108,9 @@ __device__ __forceinline__ bool gen_elem(const SortArgs &a, uint32_t b, uint32_t
     const size_t base = (size_t)b * a.S;
     if (MODE == GEN_BYTES4) {
         // a.h = byte offset of the key inside the rotation (4 for the low half of the 8-byte prefix)
-        const uint32_t key = text4(a.blk + base, (e + a.h) % n, n);
+        uint32_t i = e + a.h;
+        if (i >= n) i = n > 4 ? i - n : i % n;
+        const uint32_t key = text4(a.blk + base, i, n);
         v = ((u64)key << 32) | e;
         return true;
     } else if (MODE == GEN_SWEEP) {
@@ -370,14 +381,14 @@ __global__ void __launch_bounds__(SORT_THREADS) flag_tiles(RefineArgs a)
         const uint32_t n = a.n[b];
         const uint8_t *txt = a.blk + base;
         uint32_t plo = 0;
-        if (a.init && q0) plo = text4(txt, ((uint32_t)(prev & SUF_MASK) + 4u) % n, n);
+        if (a.init && q0) plo = text4(txt, wrap_add(prev, n), n);
 #pragma unroll
         for (int k = 0; k < SORT_ITEMS; k++) {
             const uint32_t q = q0 + k;
             if (q < cnt) {
                 const u64 cur = lds[slot_of(e0 + k)];
                 uint32_t lo = 0;
-                if (a.init) lo = text4(txt, ((uint32_t)(cur & SUF_MASK) + 4u) % n, n);
+                if (a.init) lo = text4(txt, wrap_add(cur, n), n);
                 bool gs, bd;
                 elem_flags(a, q, cur, prev, lo, plo, gs, bd);
                 plo = lo;
