@@ -29,10 +29,22 @@ def oracle_split(oracle, data, level):
 # ---- stage seams -----------------------------------------------------------------------------------
 @pytest.mark.parametrize("mode", cases.MODES)
 def test_bwt_seam(oracle, ctx9, mode):
-    for n in (1, 2, 3, 5, 63, 64, 65, 257, 4095, 4096, 4097, 10000, 70000):
+    for n in (1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 16, 17, 63, 64, 65, 257, 4095, 4096, 4097, 10000, 70000):
         d = cases.gen(n, mode, 2)
         g, o = ctx9.bwt(d), oracle.bwt(d)
         assert g[0] == o[0] and g[1] == o[1] and np.array_equal(g[2], o[2]), (mode, n)
+
+
+def test_bwt_all_short_binary_strings(oracle, ctx9):
+    """every string over {a, b} of length 1..9 (all periods, all wrap-arounds of the 8-byte initial
+    sort key, every tie pattern of T6), in batches through bzh_bwt_batch"""
+    blocks = [bytes(97 + ((v >> k) & 1) for k in range(n)) for n in range(1, 10) for v in range(1 << n)]
+    step = 8  # the fixture context is created with max_batch = 8
+    for k in range(0, len(blocks), step):
+        part = blocks[k:k + step]
+        for blk, r in zip(part, ctx9.bwt_batch(part)):
+            o = oracle.bwt(blk)
+            assert r[0] == o[0] and r[1] == o[1], blk
 
 
 def test_bwt_golden_vectors(ctx9):
