@@ -35,6 +35,8 @@
 #include <vector>
 
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
 
 typedef unsigned long long u64;
 
@@ -61,9 +63,11 @@ struct SortArgs {
     uint32_t *hist;       // [B][NBMAX*TPB]
     uint32_t S, TPB, h, shift;
     uint32_t T, B; // launch geometry: tiles per block in this launch, blocks
+    uint32_t recrank; // GEN_ACTIVE: src records carry the suffix's current group rank (refine wrote it back)
 };
 
 constexpr int NBMAX = 256;
+constexpr u64 LIST_INVALID = ~0ull; // list slot without an unresolved suffix
 
 // XCD-aware workgroup -> (bzip2 block, tile) map.  Workgroups are dealt round-robin over the 8
 // XCDs (observed dispatch behaviour, used for speed only): ids congruent mod 8 share an XCD and
@@ -130,9 +134,16 @@ __device__ __forceinline__ bool gen_elem(const SortArgs &a, uint32_t b, uint32_t
         v = ((u64)r << 40) | ((u64)e << 20) | i;
         return true;
     } else if (MODE == GEN_ACTIVE) {
-        const uint32_t i = (uint32_t)(a.src[base + e] & SUF_MASK);
-        const uint32_t r = a.rank[base + i];
-        if (r & RANK_RESOLVED) return false;
+        const u64 x = a.src[base + e];
+        const uint32_t i = (uint32_t)(x & SUF_MASK);
+        uint32_t r;
+        if (a.recrank) { // the last refine left [new rank][.][i], or LIST_INVALID for resolved suffixes
+            if (x == LIST_INVALID) return false;
+            r = (uint32_t)(x >> 40) & 0xFFFFFu;
+        } else {
+            r = a.rank[base + i];
+            if (r & RANK_RESOLVED) return false;
+        }
         uint32_t k2;
         if (a.h < n) {
             uint32_t i2 = i + a.h;
@@ -315,13 +326,14 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
 struct RefineArgs {
     const uint32_t *n;   // [B]
     const uint32_t *cnt; // [B] list length (n for the init pass, unresolved count in rounds)
-    const u64 *list;     // [B][S] sorted elements
+    u64 *list;           // [B][S] sorted elements (rewritten in place when writeback is set)
     const uint8_t *blk;  // [B][S] the text (init pass: low half of the 8-byte prefix is compared from it)
     uint32_t *rank;      // [B][S]
     uint32_t *sa;        // [B][S]
     uint32_t *headp;     // [B][S]
     uint8_t *flg;        // [B][S]
     int2 *tagg;          // [B][TPB]
+    uint32_t writeback;  // leave [new rank:20 @40][0][suffix] / LIST_INVALID (resolved) in the list
     uint32_t *nact_next; // [B]
     uint32_t *maxgrp;    // [B] largest refined group (members), atomicMax
     const uint32_t *gate; // [B] skip block when 0 (nullptr = no gating)
@@ -512,7 +524,7 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
                 const uint32_t head = gbase + (uint32_t)cd;
                 const bool single = (f & 2u) && ((q + 1 == cnt) || (fn & 2u));
                 rank[i] = single ? (head | RANK_RESOLVED) : head;
-                outv[k] = ((u64)pos << 40) | ((u64)head << 20) | i;
+                outv[k] = ((u64)(single ? 1u : 0u) << 60) | ((u64)pos << 40) | ((u64)head << 20) | i;
                 unresolved += single ? 0u : 1u;
                 if ((q + 1 == cnt) || (fn & 2u)) biggest = max(biggest, q - (uint32_t)cd + 1u); // last of its group
             }
@@ -525,11 +537,16 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; k++) {
-        const u64 x = lds[slot_of(k * SORT_THREADS + threadIdx.x)];
+        const uint32_t e = k * SORT_THREADS + threadIdx.x;
+        const u64 x = lds[slot_of(e)];
         if (x != ~0ull) {
-            const uint32_t pos = (uint32_t)(x >> 40);
+            const uint32_t pos = (uint32_t)(x >> 40) & 0xFFFFFu;
+            const uint32_t head = (uint32_t)(x >> 20) & 0xFFFFFu;
             sa[pos] = (uint32_t)(x & SUF_MASK);
-            headp[pos] = (uint32_t)(x >> 20) & 0xFFFFFu;
+            headp[pos] = head;
+            // the next round re-keys this list (ACTIVE) or sorts it in place (TAIL): leave the new
+            // group rank in the record so that neither has to gather rank[i]
+            if (a.writeback) a.list[base + tile0 + e] = ((x >> 60) & 1ull) ? LIST_INVALID : (((u64)head << 40) | (x & SUF_MASK));
         }
     }
     unresolved = wave_reduce_add(unresolved);
@@ -546,16 +563,16 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
 // members.  The block's unresolved suffixes sit, grouped and in SA order, in `len` slots of one list
 // buffer.  tail_sort: a workgroup owns the groups whose first member lies in its range of TAIL_T
 // slots and sees TAIL_G slots either side, so every owned group is complete in its window; it ranks
-// the members of each group by key2 and writes a record into the slot of the u-th member (in
-// place).  A neighbour may be rewriting the slots of ITS groups while this workgroup reads them:
-// it then sees a permutation of the same group's members (8-byte stores are single transactions)
-// and reaches the same ownership verdict.  tail_sort reads only OLD ranks; tail_apply stores the new
-// ranks / SA entries (the kernel boundary keeps rank reads consistent) and counts survivors per
-// tile; tail_scan + tail_compact move the still-unresolved records, order preserved, to the other
-// buffer, so the next round touches only what is left.
-constexpr int TAIL_T = 2048, TAIL_G = 256, TAIL_W = TAIL_T + 2 * TAIL_G, TAIL_THREADS = 256;
-constexpr int TAIL_PER = TAIL_W / TAIL_THREADS; // 10 slots per thread
-constexpr u64 LIST_INVALID = ~0ull;
+// the members of each group by key2 and writes a record for the slot of the u-th member into the
+// block's OTHER list buffer (same slot numbering), so the input stays untouched during the kernel
+// and its records can be trusted: each carries the suffix and its current group rank (written by
+// refine, or by the previous tail round), so nothing has to be gathered but key2.  tail_sort reads
+// only OLD ranks; tail_apply stores the new ranks / SA entries (the kernel boundary keeps rank reads
+// consistent) and counts survivors per tile; tail_scan + tail_compact move the still-unresolved
+// records, order preserved, back to the block's own buffer, so the next round touches only what is
+// left.
+constexpr int TAIL_T = 2048, TAIL_G = 256, TAIL_W = TAIL_T + 2 * TAIL_G, TAIL_THREADS = 512;
+constexpr int TAIL_PER = TAIL_W / TAIL_THREADS; // 5 slots per thread
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 constexpr uint32_t TAIL_BUF_B = 0x80000000u; // gateT bit: the block's list lives in listB
 constexpr uint32_t TAIL_LEN = 0x3FFFFFFFu;
@@ -563,6 +580,7 @@ constexpr uint32_t TAIL_LEN = 0x3FFFFFFFu;
 struct TailArgs {
     const uint32_t *n;   // [B]
     const uint32_t *len; // [B] slot count | TAIL_BUF_B, 0 = block not in tail mode this round
+    uint32_t recrank;    // records carry the current group rank (always, except right after the initial sort)
     u64 *bufA, *bufB;    // [B][S]
     uint32_t *rank;      // [B][S]
     uint32_t *sa;        // [B][S]
@@ -588,7 +606,8 @@ __global__ void __launch_bounds__(TAIL_THREADS) tail_sort(TailArgs a)
     const uint32_t nwin = s_hi - s_lo;
     const uint32_t n = a.n[b];
     const size_t base = (size_t)b * a.S;
-    u64 *buf = ((lenw & TAIL_BUF_B) ? a.bufB : a.bufA) + base;
+    const u64 *buf = ((lenw & TAIL_BUF_B) ? a.bufB : a.bufA) + base; // read only during this kernel
+    u64 *out = ((lenw & TAIL_BUF_B) ? a.bufA : a.bufB) + base;       // records, same slot numbering
     const uint32_t *rank = a.rank + base;
     __shared__ uint32_t A0[TAIL_W], A1[TAIL_W], A2[TAIL_W], A3[TAIL_W];
     __shared__ uint32_t A4[QUAD ? TAIL_W : 1], A5[QUAD ? TAIL_W : 1]; // extra keys of the 4h form only
@@ -603,16 +622,16 @@ __global__ void __launch_bounds__(TAIL_THREADS) tail_sort(TailArgs a)
             const uint32_t sl = s_lo + w;
             const u64 x = buf[sl];
             if (x != LIST_INVALID) {
-                // Only the suffix index is taken from the slot.  The group rank must come from the rank
-                // array, which no one writes during this kernel: a neighbour that has already rewritten
-                // the slots of a group spanning into this window left NEW ranks in its records.
                 i = (uint32_t)(x & SUF_MASK);
-                const uint32_t rr = rank[i];
-                if (!(rr & RANK_RESOLVED))
-                    r = rr;
-                else if (sl >= r0 && sl < r1)
-                    buf[sl] = LIST_INVALID; // resolved before: a hole for tail_apply / tail_compact
+                if (a.recrank) { // refine / the last tail round left the group rank in the record
+                    r = (uint32_t)(x >> 40) & 0xFFFFFu;
+                } else { // list straight from the initial sort: rank and resolvedness from the array
+                    const uint32_t rr = rank[i];
+                    if (!(rr & RANK_RESOLVED)) r = rr;
+                }
             }
+            // no unresolved suffix here: a hole for tail_apply / tail_compact
+            if (r == NONE32 && sl >= r0 && sl < r1) out[sl] = LIST_INVALID;
         }
         A0[w] = r;
         A1[w] = i;
@@ -704,7 +723,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) tail_sort(TailArgs a)
             const bool single = eq == 1;
             unresolved += single ? 0u : 1u;
             const u64 rec = ((u64)(single ? 1u : 0u) << 60) | ((u64)(r + less) << 40) | ((u64)(r + u) << 20) | A1[e];
-            buf[A2[g + u]] = rec; // the u-th smallest member takes the slot of the u-th member
+            out[A2[g + u]] = rec; // the u-th smallest member takes the slot of the u-th member
         }
     }
     unresolved = wave_reduce_add(unresolved);
@@ -722,7 +741,7 @@ __global__ void __launch_bounds__(256) tail_apply(TailArgs a)
     const uint32_t r0 = tile * TAIL_T;
     if (r0 >= len) return;
     const size_t base = (size_t)b * a.S;
-    const u64 *rec = ((lenw & TAIL_BUF_B) ? a.bufB : a.bufA) + base;
+    const u64 *rec = ((lenw & TAIL_BUF_B) ? a.bufA : a.bufB) + base; // tail_sort's output
     uint32_t *rank = a.rank + base;
     uint32_t *sa = a.sa + base;
     uint32_t alive = 0;
@@ -772,8 +791,8 @@ __global__ void __launch_bounds__(256) tail_compact(TailArgs a)
     const uint32_t r0 = tile * TAIL_T;
     if (r0 >= len) return;
     const size_t base = (size_t)b * a.S;
-    const u64 *src = ((lenw & TAIL_BUF_B) ? a.bufB : a.bufA) + base;
-    u64 *dst = ((lenw & TAIL_BUF_B) ? a.bufA : a.bufB) + base;
+    const u64 *src = ((lenw & TAIL_BUF_B) ? a.bufA : a.bufB) + base; // tail_sort's output
+    u64 *dst = ((lenw & TAIL_BUF_B) ? a.bufB : a.bufA) + base;       // back home, compacted
     constexpr int PER = TAIL_T / 256;
     const uint32_t s0 = r0 + threadIdx.x * PER;
     u64 x[PER];
@@ -999,8 +1018,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
                 // the sorted list in `cur` keeps this many slots, in this buffer, from now on
                 taillen[b] = hprev[b] | (cur == bufB ? TAIL_BUF_B : 0u);
             }
-            if (tailmode[b] == 2) // compacted last round: the list moved to the other buffer
-                taillen[b] = hact[b] | ((taillen[b] & TAIL_BUF_B) ^ TAIL_BUF_B);
+            if (tailmode[b] == 2) // compacted last round (back into its own buffer)
+                taillen[b] = hact[b] | (taillen[b] & TAIL_BUF_B);
             if (tailmode[b]) {
                 tailmode[b] = 2;
                 hgR[b] = 0;
@@ -1019,6 +1038,23 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             }
         }
         if (tot == 0) break;
+        static const bool trace = getenv("BZH_TRACE_ROUNDS") != nullptr;
+        if (trace) { // diagnostic: group-size picture of the round about to run
+            uint32_t nrad = 0, ntail = 0, le512 = 0, le1k = 0, le4k = 0;
+            for (uint32_t b = 0; b < B; b++) {
+                if (!hact[b]) continue;
+                if (tailmode[b]) {
+                    ntail++;
+                    continue;
+                }
+                nrad++;
+                le512 += hmax[b] <= 512;
+                le1k += hmax[b] <= 1024;
+                le4k += hmax[b] <= 4096;
+            }
+            fprintf(stderr, "[bzhip] round %d h=%u unresolved=%llu radix blocks=%u (maxgrp<=512:%u <=1k:%u <=4k:%u) tail blocks=%u\n",
+                    round, h, (unsigned long long)tot, nrad, le512, le1k, le4k, ntail);
+        }
         ctx->stats.bwt_active_sum += tot;
         ctx->stats.bwt_rounds = (uint64_t)(round + 1) > ctx->stats.bwt_rounds ? (uint64_t)(round + 1) : ctx->stats.bwt_rounds;
         { // rotate: this round's counts stay readable next round as the length of `cur`
@@ -1036,6 +1072,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         if (!active_mode && nsum && sum * 3 < nsum) active_mode = true;
 
         a.h = h;
+        a.recrank = round > 0; // every refine after the initial one writes ranks back into the list
         a.gate = bt.gateR;
         // with only TAIL blocks left a round may look three h-blocks ahead: depth 4h instead of 2h
         // (three gathers per suffix: only once few suffixes are left, where rounds are latency-bound)
@@ -1085,6 +1122,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         if (maxtail) { // blocks in TAIL mode: in place in their own buffer, independent of cur/oth
             ta.nact_next = nact_next;
             ta.h = h;
+            ta.recrank = round > 0;
             ta.T = (maxtail + TAIL_T - 1) / TAIL_T;
             ta.B = B;
             if (quad)
@@ -1106,6 +1144,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             r.nact_next = nact_next;
             r.maxgrp = nact_next + mb;
             r.init = 0;
+            r.writeback = 1;
             r.gate = bt.gateR;
             launch_refine(ctx, r, B, maxact);
         }
