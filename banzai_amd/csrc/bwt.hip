@@ -552,9 +552,24 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
     unresolved = wave_reduce_add(unresolved);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) biggest = max(biggest, (uint32_t)__shfl_xor((int)biggest, d, 64));
-    if ((threadIdx.x & 63) == 0 && unresolved) {
-        atomicAdd(&a.nact_next[b], unresolved);
-        atomicMax(&a.maxgrp[b], biggest);
+    // one atomic pair per workgroup: all tiles of a block hit the same two counters
+    __shared__ uint32_t wsum[SORT_THREADS / 64], wmax[SORT_THREADS / 64];
+    if ((threadIdx.x & 63) == 0) {
+        wsum[threadIdx.x >> 6] = unresolved;
+        wmax[threadIdx.x >> 6] = biggest;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t su = 0, mx = 0;
+#pragma unroll
+        for (int w = 0; w < SORT_THREADS / 64; w++) {
+            su += wsum[w];
+            mx = max(mx, wmax[w]);
+        }
+        if (su) {
+            atomicAdd(&a.nact_next[b], su);
+            atomicMax(&a.maxgrp[b], mx);
+        }
     }
 }
 
@@ -609,11 +624,15 @@ __global__ void __launch_bounds__(TAIL_THREADS) tail_sort(TailArgs a)
     const u64 *buf = ((lenw & TAIL_BUF_B) ? a.bufB : a.bufA) + base; // read only during this kernel
     u64 *out = ((lenw & TAIL_BUF_B) ? a.bufA : a.bufB) + base;       // records, same slot numbering
     const uint32_t *rank = a.rank + base;
-    __shared__ uint32_t A0[TAIL_W], A1[TAIL_W], A2[TAIL_W], A3[TAIL_W];
+    // A0 group rank, A1 suffix | window offset of the slot << 20, A3 (A4, A5) keys, GE group end (at the head)
+    __shared__ uint32_t A0[TAIL_W], A1[TAIL_W], A3[TAIL_W];
     __shared__ uint32_t A4[QUAD ? TAIL_W : 1], A5[QUAD ? TAIL_W : 1]; // extra keys of the 4h form only
+    __shared__ uint16_t GE[TAIL_W];
     __shared__ uint32_t ls[TAIL_THREADS / 64 + 2];
+    __shared__ int lm[TAIL_THREADS / 64];
+    __shared__ int exh[TAIL_THREADS];
 
-    // load by slot (coalesced); already-resolved suffixes (first tail round only) drop out
+    // load by slot (coalesced); slots without an unresolved suffix drop out
 #pragma unroll
     for (int k = 0; k < TAIL_PER; k++) {
         const uint32_t w = k * TAIL_THREADS + threadIdx.x;
@@ -637,45 +656,67 @@ __global__ void __launch_bounds__(TAIL_THREADS) tail_sort(TailArgs a)
         A1[w] = i;
     }
     __syncthreads();
-    // order-preserving compaction: thread owns TAIL_PER consecutive slots
+    // order-preserving compaction: a thread owns TAIL_PER consecutive slots and, afterwards, the
+    // (consecutive) compacted elements they hold
     const uint32_t w0 = threadIdx.x * TAIL_PER;
-    uint32_t rr[TAIL_PER], ii[TAIL_PER], cnt = 0;
+    uint32_t cr[TAIL_PER], ci[TAIL_PER], cnt = 0;
 #pragma unroll
     for (int k = 0; k < TAIL_PER; k++) {
-        rr[k] = A0[w0 + k];
-        ii[k] = A1[w0 + k];
-        cnt += rr[k] != NONE32;
+        const uint32_t r = A0[w0 + k], i = A1[w0 + k];
+        // keep registers dense: element j of this thread is its j-th unresolved slot
+#pragma unroll
+        for (int j = 0; j < TAIL_PER; j++) {
+            if (r != NONE32 && (uint32_t)j == cnt) {
+                cr[j] = r;
+                ci[j] = i | ((w0 + k) << 20);
+            }
+        }
+        cnt += r != NONE32;
     }
     uint32_t V;
-    uint32_t idx = block_excl_add(cnt, ls, &V);
+    const uint32_t idx0 = block_excl_add(cnt, ls, &V);
 #pragma unroll
-    for (int k = 0; k < TAIL_PER; k++) {
-        if (rr[k] != NONE32) {
-            A0[idx] = rr[k];         // group rank
-            A1[idx] = ii[k];         // suffix
-            A2[idx] = s_lo + w0 + k; // slot
-            idx++;
+    for (int j = 0; j < TAIL_PER; j++) {
+        if ((uint32_t)j < cnt) {
+            A0[idx0 + j] = cr[j];
+            A1[idx0 + j] = ci[j];
         }
     }
     __syncthreads();
-    // group start of every compacted element, ownership, key2 of owned elements
+    // group structure by scan: start of every element's group, end of the group stored at its head
+    const uint32_t prevr = (cnt && idx0 > 0) ? A0[idx0 - 1] : NONE32;
+    const uint32_t nextr = (cnt && idx0 + cnt < V) ? A0[idx0 + cnt] : NONE32;
+    int lasthead = -1;
+#pragma unroll
+    for (int j = 0; j < TAIL_PER; j++)
+        if ((uint32_t)j < cnt && cr[j] != (j ? cr[j - 1] : prevr)) lasthead = (int)(idx0 + j);
+    const int inc = block_incl_max(lasthead, lm);
+    exh[threadIdx.x] = inc;
+    __syncthreads();
+    int run = threadIdx.x ? exh[threadIdx.x - 1] : -1;
     uint32_t gstart[TAIL_PER];
+#pragma unroll
+    for (int j = 0; j < TAIL_PER; j++) {
+        gstart[j] = 0;
+        if ((uint32_t)j < cnt) {
+            if (cr[j] != (j ? cr[j - 1] : prevr)) run = (int)(idx0 + j);
+            gstart[j] = (uint32_t)run;
+            const uint32_t nx = ((uint32_t)(j + 1) < cnt) ? cr[(j + 1 < TAIL_PER) ? j + 1 : j] : nextr;
+            if (nx != cr[j]) GE[run] = (uint16_t)(idx0 + j + 1);
+        }
+    }
+    // ownership and the keys of owned elements
     uint32_t owned = 0;
     bool bad = false;
 #pragma unroll
-    for (int k = 0; k < TAIL_PER; k++) {
-        const uint32_t e = k * TAIL_THREADS + threadIdx.x;
-        gstart[k] = 0;
-        if (e < V) {
-            const uint32_t r = A0[e];
-            uint32_t g = e;
-            while (g > 0 && A0[g - 1] == r) g--;
-            gstart[k] = g;
-            const uint32_t fs = A2[g];
+    for (int j = 0; j < TAIL_PER; j++) {
+        if ((uint32_t)j < cnt) {
+            const uint32_t e = idx0 + j;
+            const uint32_t fs = s_lo + (A1[gstart[j]] >> 20);
             if (fs >= r0 && fs < r1) {
-                owned |= 1u << k;
-                if (A2[e] - fs >= (uint32_t)TAIL_G) bad = true; // span beyond the window guarantee
-                const uint32_t i = A1[e];
+                owned |= 1u << j;
+                if (s_lo + (ci[j] >> 20) - fs >= (uint32_t)TAIL_G) bad = true; // span beyond the window guarantee
+                const uint32_t i = ci[j] & (uint32_t)SUF_MASK;
                 uint32_t k2, k3 = 0, k4 = 0;
                 if (a.h < n) {
                     uint32_t i2 = i + a.h;
@@ -701,17 +742,17 @@ __global__ void __launch_bounds__(TAIL_THREADS) tail_sort(TailArgs a)
         }
     }
     __syncthreads();
-    uint32_t unresolved = 0;
 #pragma unroll
-    for (int k = 0; k < TAIL_PER; k++) {
-        const uint32_t e = k * TAIL_THREADS + threadIdx.x;
-        if (e < V && (owned & (1u << k))) {
-            const uint32_t r = A0[e], g = gstart[k];
+    for (int j = 0; j < TAIL_PER; j++) {
+        if ((uint32_t)j < cnt && (owned & (1u << j))) {
+            const uint32_t e = idx0 + j, r = cr[j], g = gstart[j];
+            const uint32_t ge = GE[g];
             // lexicographic key (k2, k3, k4): two 64-bit words compare it
             const uint32_t my_hi = A3[e];
             const u64 my_lo = QUAD ? (((u64)A4[e] << 32) | A5[e]) : 0ull;
             uint32_t less = 0, eq_before = 0, eq = 0;
-            for (uint32_t f = g; f < V && A0[f] == r; f++) {
+#pragma unroll 4
+            for (uint32_t f = g; f < ge; f++) { // bounds known up front: the LDS reads pipeline
                 const uint32_t f_hi = A3[f];
                 const u64 f_lo = QUAD ? (((u64)A4[f] << 32) | A5[f]) : 0ull;
                 const bool same = f_hi == my_hi && f_lo == my_lo;
@@ -721,13 +762,13 @@ __global__ void __launch_bounds__(TAIL_THREADS) tail_sort(TailArgs a)
             }
             const uint32_t u = less + eq_before;
             const bool single = eq == 1;
-            unresolved += single ? 0u : 1u;
-            const u64 rec = ((u64)(single ? 1u : 0u) << 60) | ((u64)(r + less) << 40) | ((u64)(r + u) << 20) | A1[e];
-            out[A2[g + u]] = rec; // the u-th smallest member takes the slot of the u-th member
+            const u64 rec = ((u64)(single ? 1u : 0u) << 60) | ((u64)(r + less) << 40) | ((u64)(r + u) << 20) |
+                            (ci[j] & (uint32_t)SUF_MASK);
+            out[s_lo + (A1[g + u] >> 20)] = rec; // the u-th smallest member takes the slot of the u-th member
         }
     }
-    unresolved = wave_reduce_add(unresolved);
-    if ((threadIdx.x & 63) == 0 && unresolved) atomicAdd(&a.nact_next[b], unresolved);
+    // (the block's survivor count is produced by tail_apply + tail_scan: per-wave atomics onto one
+    // counter per block cost more than the rest of this kernel)
     if (bad) atomicOr(a.err, 1u);
 }
 
@@ -779,6 +820,7 @@ __global__ void __launch_bounds__(512) tail_scan(TailArgs a)
     uint32_t tot;
     const uint32_t ex = block_excl_add(v, ls, &tot);
     if (threadIdx.x < ntile) tc[threadIdx.x] = ex;
+    if (threadIdx.x == 0) a.nact_next[b] = tot; // unresolved suffixes of the block after this round
 }
 
 // Moves the surviving records of a tile to the other buffer, order preserved.
