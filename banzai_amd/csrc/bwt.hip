@@ -184,51 +184,62 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_hist(SortArgs a)
     }
     __syncthreads();
     uint32_t *out = a.hist + (size_t)b * NBMAX * a.TPB;
-    for (int k = threadIdx.x; k < NB; k += SORT_THREADS) out[(size_t)k * a.TPB + tile] = h[k];
+    for (int k = threadIdx.x; k < NB; k += SORT_THREADS) out[(size_t)tile * NBMAX + k] = h[k]; // tile-major rows
 }
 
-// One workgroup per bzip2 block: exclusive scan of hist over (digit major, tile minor), 16 entries
-// per thread and sweep.
+// One workgroup per bzip2 block: exclusive scan of hist in (digit major, tile minor) order.  The
+// table is stored tile-major (one row of NB counts per tile), so thread (segment, digit) walks a
+// contiguous range of tiles down its digit's column and a wavefront always touches 64 consecutive
+// counts: sum the column segment, scan the 1024 segment sums in (digit, segment) order, walk again.
 template <int BITS>
 __global__ void __launch_bounds__(1024) radix_scan(SortArgs a)
 {
     constexpr int NB = 1 << BITS;
-    constexpr int PER = 16;
+    constexpr int SEG = 1024 / NB; // column segments per digit
     const uint32_t b = blockIdx.x;
     if (a.gate[b] == 0) return;
     const uint32_t cnt = a.cnt[b];
     const uint32_t ntile = (cnt + SORT_TILE - 1) / SORT_TILE;
-    const uint32_t total = NB * ntile;
     uint32_t *hist = a.hist + (size_t)b * NBMAX * a.TPB;
+    const uint32_t seg = threadIdx.x / NB, bin = threadIdx.x % NB;
+    const uint32_t per = (ntile + SEG - 1) / SEG;
+    const uint32_t t0 = min(ntile, seg * per), t1 = min(ntile, t0 + per);
+    uint32_t *col = hist + bin;
+    uint32_t sum = 0;
+    uint32_t t = t0;
+    for (; t + 8 <= t1; t += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = col[(size_t)(t + k) * NBMAX];
+#pragma unroll
+        for (int k = 0; k < 8; k++) sum += v[k];
+    }
+    for (; t < t1; t++) sum += col[(size_t)t * NBMAX];
+    __shared__ uint32_t ord[1024];
     __shared__ uint32_t lds[20];
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < total; base += 1024 * PER) {
-        const uint32_t e0 = base + threadIdx.x * PER;
-        uint32_t v[PER], addr[PER], sum = 0;
-        // entry e -> (bin = e / ntile, tile = e % ntile); consecutive entries advance the tile
-        uint32_t bin = e0 < total ? e0 / ntile : 0, t = e0 < total ? e0 - bin * ntile : 0;
+    ord[bin * SEG + seg] = sum;
+    __syncthreads();
+    uint32_t tot;
+    const uint32_t mine = ord[threadIdx.x];
+    const uint32_t ex = block_excl_add(mine, lds, &tot);
+    ord[threadIdx.x] = ex;
+    __syncthreads();
+    uint32_t run = ord[bin * SEG + seg];
+    t = t0;
+    for (; t + 8 <= t1; t += 8) {
+        uint32_t v[8];
 #pragma unroll
-        for (int k = 0; k < PER; k++) {
-            v[k] = 0;
-            addr[k] = 0;
-            if (e0 + k < total) {
-                addr[k] = bin * a.TPB + t;
-                v[k] = hist[addr[k]];
-                if (++t == ntile) {
-                    t = 0;
-                    bin++;
-                }
-            }
-            sum += v[k];
-        }
-        uint32_t tot;
-        uint32_t ex = carry + block_excl_add(sum, lds, &tot);
+        for (int k = 0; k < 8; k++) v[k] = col[(size_t)(t + k) * NBMAX];
 #pragma unroll
-        for (int k = 0; k < PER; k++) {
-            if (e0 + k < total) hist[addr[k]] = ex;
-            ex += v[k];
+        for (int k = 0; k < 8; k++) {
+            col[(size_t)(t + k) * NBMAX] = run;
+            run += v[k];
         }
-        carry += tot;
+    }
+    for (; t < t1; t++) {
+        const uint32_t v = col[(size_t)t * NBMAX];
+        col[(size_t)t * NBMAX] = run;
+        run += v;
     }
 }
 
@@ -279,7 +290,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
     if (threadIdx.x < NB) {
         const uint32_t bin = threadIdx.x;
         binstart[bin] = ex;
-        goff[bin] = a.hist[(size_t)b * NBMAX * a.TPB + (size_t)bin * a.TPB + tile];
+        goff[bin] = a.hist[(size_t)b * NBMAX * a.TPB + (size_t)tile * NBMAX + bin];
         uint32_t g = ex;
 #pragma unroll
         for (int w = 0; w < NW; w++) {

@@ -1,5 +1,5 @@
-import csv, glob, sys
-f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
+import csv, glob, os, sys
+f = max(glob.glob(sys.argv[1] + '/*/*kernel_trace.csv'), key=os.path.getmtime)  # newest trace
 thr = float(sys.argv[2]) if len(sys.argv) > 2 else 100
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
