@@ -64,6 +64,11 @@ struct SortArgs {
     uint32_t S, TPB, h, shift;
     uint32_t T, B; // launch geometry: tiles per block in this launch, blocks
     uint32_t recrank; // GEN_ACTIVE: src records carry the suffix's current group rank (refine wrote it back)
+    // single-pass (look-back) scatter of the initial sort only:
+    u64 *look;             // [B][TPB][256] tile status words  [pass:32][state:2][count:30]
+    const uint32_t *dbase; // [B][256] exclusive scan of the block's byte counts = first slot of every digit
+    uint32_t *err;         // bit 1: a look-back gave up (internal error, never a hang)
+    uint32_t pass;         // id of this pass in the status words (stale words read as "not there yet")
 };
 
 constexpr int NBMAX = 256;
@@ -243,9 +248,56 @@ __global__ void __launch_bounds__(1024) radix_scan(SortArgs a)
     }
 }
 
+// Digit bases of the initial sort.  Every one of its 8 passes keys on one byte of the CYCLIC
+// rotation, so each pass's digit histogram is the block's byte histogram: one workgroup per block
+// counts the bytes once (per-wave private counters) and leaves the exclusive scan.
+__global__ void __launch_bounds__(1024) byte_base(const uint8_t *blk, const uint32_t *nn, uint32_t *dbase, uint32_t S)
+{
+    const uint32_t b = blockIdx.x, n = nn[b];
+    const uint8_t *s = blk + (size_t)b * S;
+    __shared__ uint32_t h[16][256];
+    __shared__ uint32_t ls[20];
+    for (int k = threadIdx.x; k < 16 * 256; k += 1024) (&h[0][0])[k] = 0;
+    __syncthreads();
+    uint32_t *mine = h[threadIdx.x >> 6];
+    for (uint32_t i = threadIdx.x * 4; i < n; i += 4096) {
+        if (i + 4 <= n) {
+            uint32_t w;
+            __builtin_memcpy(&w, s + i, 4);
+            atomicAdd(&mine[w & 255u], 1u);
+            atomicAdd(&mine[(w >> 8) & 255u], 1u);
+            atomicAdd(&mine[(w >> 16) & 255u], 1u);
+            atomicAdd(&mine[w >> 24], 1u);
+        } else {
+            for (uint32_t j = i; j < n; j++) atomicAdd(&mine[s[j]], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t c = 0;
+    if (threadIdx.x < 256) {
+#pragma unroll
+        for (int w = 0; w < 16; w++) c += h[w][threadIdx.x];
+    }
+    uint32_t tot;
+    const uint32_t ex = block_excl_add(c, ls, &tot);
+    if (threadIdx.x < 256) dbase[(size_t)b * 256 + threadIdx.x] = ex;
+}
+
+constexpr uint32_t LOOK_LOCAL = 1u, LOOK_GLOBAL = 2u;
+__device__ __forceinline__ u64 look_word(uint32_t pass, uint32_t state, uint32_t count)
+{
+    return ((u64)pass << 32) | ((u64)state << 30) | count;
+}
+
 // REKEY: the element leaves with the key of the NEXT key half (bytes i..i+3 of the rotation) --
 // used by the last pass over the low half of the 8-byte prefix.
-template <int BITS, int MODE, bool REKEY = false>
+// OSW ("one sweep"): no histogram / scan launches before this kernel.  The tile publishes its digit
+// counts, then each digit's thread looks back over the earlier tiles of the block (decoupled
+// look-back: a predecessor offers either its own counts or, once known, its inclusive prefix) for
+// the tile's first slot; digit bases come from a.dbase.  A status word is one 64-bit atomic, so no
+// fences are needed; tiles only ever wait for LOWER workgroup ids, which the dispatcher starts
+// first; waits are bounded (a.err) so that a logic error cannot hang the device.
+template <int BITS, int MODE, bool REKEY = false, bool OSW = false>
 __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
 {
     constexpr int NB = 1 << BITS;
@@ -290,7 +342,11 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
     if (threadIdx.x < NB) {
         const uint32_t bin = threadIdx.x;
         binstart[bin] = ex;
-        goff[bin] = a.hist[(size_t)b * NBMAX * a.TPB + (size_t)tile * NBMAX + bin];
+        if (OSW)
+            __hip_atomic_store(a.look + ((size_t)b * a.TPB + tile) * NBMAX + bin, look_word(a.pass, LOOK_LOCAL, mytot),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+            goff[bin] = a.hist[(size_t)b * NBMAX * a.TPB + (size_t)tile * NBMAX + bin];
         uint32_t g = ex;
 #pragma unroll
         for (int w = 0; w < NW; w++) {
@@ -319,6 +375,30 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
             if (off == 0) mycur[d] = basepos + __popcll(m); // lowest lane of the digit group advances
             stage[basepos + off] = v[k];
         }
+    }
+    if (OSW && threadIdx.x < NB) { // look back for the counts of digit `bin` in tiles 0 .. tile-1
+        const uint32_t bin = threadIdx.x;
+        u64 *col = a.look + (size_t)b * a.TPB * NBMAX + bin;
+        uint32_t acc = 0, spins = 0;
+        int t = (int)tile - 1;
+        while (t >= 0) {
+            const u64 w = __hip_atomic_load(col + (size_t)t * NBMAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t state = (uint32_t)(w >> 30) & 3u;
+            if ((uint32_t)(w >> 32) != a.pass || state == 0) { // predecessor has not published yet
+                if (++spins > (1u << 22)) {
+                    atomicOr(a.err, 2u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                continue;
+            }
+            acc += (uint32_t)w & 0x3FFFFFFFu;
+            if (state == LOOK_GLOBAL) break;
+            t--;
+        }
+        __hip_atomic_store(col + (size_t)tile * NBMAX, look_word(a.pass, LOOK_GLOBAL, acc + mytot), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        goff[bin] = a.dbase[(size_t)b * 256 + bin] + acc;
     }
     __syncthreads();
     u64 *dst = a.dst + (size_t)b * a.S;
@@ -925,20 +1005,21 @@ static void launch_pass(bzh_ctx *ctx, SortArgs &a, uint32_t B, uint32_t maxcnt, 
     }
 }
 
-static void launch_rekey_pass(bzh_ctx *ctx, SortArgs &a, uint32_t B, uint32_t maxcnt, uint64_t elems)
+// one pass of the initial sort: single kernel (look-back scatter)
+template <int MODE, bool REKEY>
+static void launch_osw_pass(bzh_ctx *ctx, SortArgs &a, uint32_t B, uint32_t maxcnt, uint64_t elems)
 {
     const uint32_t tiles = (maxcnt + SORT_TILE - 1) / SORT_TILE;
     if (tiles == 0) return;
     a.T = tiles;
     a.B = B;
+    a.pass++;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    radix_hist<8, GEN_LIST><<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(a);
-    radix_scan<8><<<dim3(B), 1024, 0, ctx->stream>>>(a);
     if (ctx->profiling) {
         e0 = bzh_event(ctx);
         hipEventRecord(e0, ctx->stream);
     }
-    radix_scatter<8, GEN_LIST, true><<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(a);
+    radix_scatter<8, MODE, REKEY, true><<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(a);
     if (ctx->profiling) {
         e1 = bzh_event(ctx);
         hipEventRecord(e1, ctx->stream);
@@ -983,22 +1064,32 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     // bytes 4..7 of the rotation (the key field holds them), the scatter of pass 3 swaps in bytes 0..3,
     // passes 4-7 order by those.  A plain pass over every suffix costs far less than a doubling round
     // does per suffix, so this replaces "4-byte sort + refine + first doubling round".
+    // The passes run as single look-back kernels (no histogram / scan launches): their digit bases
+    // are the block's byte counts.  Status words and bases live in sa / headp, which nothing uses
+    // before the first refine.
     a.cnt = bt.n;
     a.gate = bt.n;
     a.shift = 32;
     a.h = 4; // key offset for GEN_BYTES4
     a.src = nullptr;
     a.dst = bufA;
-    launch_pass<8, GEN_BYTES4>(ctx, a, B, nmax, ntotal);
+    a.look = reinterpret_cast<u64 *>(bt.sa);
+    a.dbase = bt.headp;
+    a.err = bt.errflag;
+    a.pass = 0;
+    HIP_TRY(ctx, hipMemsetAsync(bt.errflag, 0, sizeof(uint32_t), st));
+    HIP_TRY(ctx, hipMemsetAsync(a.look, 0, (size_t)B * bt.TPB * NBMAX * sizeof(u64), st));
+    byte_base<<<dim3(B), 1024, 0, st>>>(bt.rle, bt.n, bt.headp, bt.S);
+    launch_osw_pass<GEN_BYTES4, false>(ctx, a, B, nmax, ntotal);
     u64 *cur = bufA, *oth = bufB;
     for (int p = 1; p < 8; p++) {
         a.shift = 32 + 8 * (p & 3);
         a.src = cur;
         a.dst = oth;
         if (p == 3)
-            launch_rekey_pass(ctx, a, B, nmax, ntotal);
+            launch_osw_pass<GEN_LIST, true>(ctx, a, B, nmax, ntotal);
         else
-            launch_pass<8, GEN_LIST>(ctx, a, B, nmax, ntotal);
+            launch_osw_pass<GEN_LIST, false>(ctx, a, B, nmax, ntotal);
         u64 *t = cur;
         cur = oth;
         oth = t;
@@ -1012,7 +1103,6 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     uint32_t *nact = nullptr, *nact_next = cnts[inext];
     const uint32_t mb = ctx->max_batch; // pair layout: counts at +0, largest group at +mb
     HIP_TRY(ctx, hipMemsetAsync(nact_next, 0, 2 * mb * sizeof(uint32_t), st));
-    HIP_TRY(ctx, hipMemsetAsync(bt.errflag, 0, sizeof(uint32_t), st));
 
     RefineArgs r{};
     r.n = bt.n;
@@ -1210,7 +1300,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         HIP_TRY(ctx, hipMemcpyAsync(&err, bt.errflag, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
         if (err) {
-            bzh_set_error(ctx, "BWT tail rounds saw a group larger than their window (internal error)");
+            bzh_set_error(ctx, err & 2 ? "BWT initial sort: a look-back gave up waiting (internal error)"
+                                       : "BWT tail rounds saw a group larger than their window (internal error)");
             return BZH_E_HIP;
         }
     }
