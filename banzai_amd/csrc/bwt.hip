@@ -66,7 +66,8 @@ struct SortArgs {
     uint32_t recrank; // GEN_ACTIVE: src records carry the suffix's current group rank (refine wrote it back)
     // single-pass (look-back) scatter of the initial sort only:
     u64 *look;             // [B][TPB][256] tile status words  [pass:32][state:2][count:30]
-    const uint32_t *dbase; // [B][256] exclusive scan of the block's byte counts = first slot of every digit
+    const uint32_t *dbase; // [B][512] first slot of every digit (exclusive scan of the pass's digit totals)
+    uint32_t doff;         // which 128/256-entry group of dbase this pass uses
     uint32_t *err;         // bit 1: a look-back gave up (internal error, never a hang)
     uint32_t pass;         // id of this pass in the status words (stale words read as "not there yet")
 };
@@ -280,7 +281,7 @@ __global__ void __launch_bounds__(1024) byte_base(const uint8_t *blk, const uint
     }
     uint32_t tot;
     const uint32_t ex = block_excl_add(c, ls, &tot);
-    if (threadIdx.x < 256) dbase[(size_t)b * 256 + threadIdx.x] = ex;
+    if (threadIdx.x < 256) dbase[(size_t)b * 512 + threadIdx.x] = ex;
 }
 
 constexpr uint32_t LOOK_LOCAL = 1u, LOOK_GLOBAL = 2u;
@@ -398,7 +399,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
         }
         __hip_atomic_store(col + (size_t)tile * NBMAX, look_word(a.pass, LOOK_GLOBAL, acc + mytot), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
-        goff[bin] = a.dbase[(size_t)b * 256 + bin] + acc;
+        goff[bin] = a.dbase[(size_t)b * 512 + a.doff + bin] + acc;
     }
     __syncthreads();
     u64 *dst = a.dst + (size_t)b * a.S;
@@ -424,6 +425,8 @@ struct RefineArgs {
     uint32_t *headp;     // [B][S]
     uint8_t *flg;        // [B][S]
     int2 *tagg;          // [B][TPB]
+    uint32_t *dig;       // [B][TPB][512] or nullptr: per tile, counts of the three 7-bit digits of the new rank over
+                         // the suffixes left unresolved (bases of the next SWEEP round's look-back passes)
     uint32_t writeback;  // leave [new rank:20 @40][0][suffix] / LIST_INVALID (resolved) in the list
     uint32_t *nact_next; // [B]
     uint32_t *maxgrp;    // [B] largest refined group (members), atomicMax
@@ -594,7 +597,13 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
     uint32_t *rank = a.rank + base;
     uint32_t *sa = a.sa + base;
     uint32_t *headp = a.headp + base;
+    __shared__ uint32_t dh[384];
+    if (a.dig) {
+        for (int k = threadIdx.x; k < 384; k += SORT_THREADS) dh[k] = 0;
+        __syncthreads();
+    }
     uint32_t unresolved = 0, biggest = 0;
+    uint32_t ph = 0, pc = 0, ph7 = 0, pc7 = 0; // open runs of the digit counting
     u64 outv[SORT_ITEMS]; // SA position : group rank : suffix (20 bits each), all ones = none
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; k++) outv[k] = ~0ull;
@@ -617,15 +626,43 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
                 rank[i] = single ? (head | RANK_RESOLVED) : head;
                 outv[k] = ((u64)(single ? 1u : 0u) << 60) | ((u64)pos << 40) | ((u64)head << 20) | i;
                 unresolved += single ? 0u : 1u;
+                if (a.dig && !single) {
+                    // heads rise with q, so a thread's 16 entries share their upper digits (and, inside
+                    // a group, the whole head): count runs in registers, touch LDS once per run
+                    if (head != ph) {
+                        if (pc) atomicAdd(&dh[ph & 127u], pc);
+                        ph = head;
+                        pc = 0;
+                    }
+                    pc++;
+                    if ((head >> 7) != ph7) {
+                        if (pc7) {
+                            atomicAdd(&dh[128 + (ph7 & 127u)], pc7);
+                            atomicAdd(&dh[256 + (ph7 >> 7)], pc7);
+                        }
+                        ph7 = head >> 7;
+                        pc7 = 0;
+                    }
+                    pc7++;
+                }
                 if ((q + 1 == cnt) || (fn & 2u)) biggest = max(biggest, q - (uint32_t)cd + 1u); // last of its group
             }
         }
+    }
+    if (pc) atomicAdd(&dh[ph & 127u], pc);
+    if (pc7) {
+        atomicAdd(&dh[128 + (ph7 & 127u)], pc7);
+        atomicAdd(&dh[256 + (ph7 >> 7)], pc7);
     }
     // SA update through LDS so that consecutive lanes store consecutive positions
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; k++) lds[slot_of(e0 + k)] = outv[k];
     __syncthreads();
+    if (a.dig) {
+        uint32_t *row = a.dig + ((size_t)b * a.TPB + tile) * 512;
+        for (int k = threadIdx.x; k < 384; k += SORT_THREADS) row[k] = dh[k];
+    }
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; k++) {
         const uint32_t e = k * SORT_THREADS + threadIdx.x;
@@ -1006,7 +1043,7 @@ static void launch_pass(bzh_ctx *ctx, SortArgs &a, uint32_t B, uint32_t maxcnt, 
 }
 
 // one pass of the initial sort: single kernel (look-back scatter)
-template <int MODE, bool REKEY>
+template <int BITS, int MODE, bool REKEY>
 static void launch_osw_pass(bzh_ctx *ctx, SortArgs &a, uint32_t B, uint32_t maxcnt, uint64_t elems)
 {
     const uint32_t tiles = (maxcnt + SORT_TILE - 1) / SORT_TILE;
@@ -1019,7 +1056,7 @@ static void launch_osw_pass(bzh_ctx *ctx, SortArgs &a, uint32_t B, uint32_t maxc
         e0 = bzh_event(ctx);
         hipEventRecord(e0, ctx->stream);
     }
-    radix_scatter<8, MODE, REKEY, true><<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(a);
+    radix_scatter<BITS, MODE, REKEY, true><<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(a);
     if (ctx->profiling) {
         e1 = bzh_event(ctx);
         hipEventRecord(e1, ctx->stream);
@@ -1027,6 +1064,39 @@ static void launch_osw_pass(bzh_ctx *ctx, SortArgs &a, uint32_t B, uint32_t maxc
         ctx->stats.bwt_sort_launches += 1;
         ctx->stats.bwt_sort_elems += elems;
     }
+}
+
+// One workgroup per block: column sums of refine's digit rows, then the exclusive scan inside each
+// of the three digits -> dbase[b][k*128 + d] = first list slot of digit d in SWEEP pass k.
+__global__ void __launch_bounds__(768) sweep_bases(RefineArgs a, uint32_t *dbase)
+{
+    const uint32_t b = blockIdx.x;
+    if (a.gate && a.gate[b] == 0) return;
+    const uint32_t cnt = a.cnt[b];
+    const uint32_t ntile = (cnt + SORT_TILE - 1) / SORT_TILE;
+    const uint32_t col = threadIdx.x % 384, seg = threadIdx.x / 384;
+    const uint32_t half = (ntile + 1) / 2;
+    const uint32_t t0 = seg ? half : 0u, t1 = seg ? ntile : half;
+    const uint32_t *p = a.dig + (size_t)b * a.TPB * 512 + col;
+    uint32_t sum = 0, t = t0;
+    for (; t + 8 <= t1; t += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = p[(size_t)(t + k) * 512];
+#pragma unroll
+        for (int k = 0; k < 8; k++) sum += v[k];
+    }
+    for (; t < t1; t++) sum += p[(size_t)t * 512];
+    __shared__ uint32_t part[384];
+    __shared__ uint32_t ls[16];
+    if (seg) part[col] = sum;
+    __syncthreads();
+    const uint32_t c = seg ? 0u : sum + part[col];
+    uint32_t tot;
+    const uint32_t ex = block_excl_add(c, ls, &tot); // threads 0..383 in (digit, value) order, the rest add 0
+    if (!seg) part[col] = ex;
+    __syncthreads();
+    if (!seg) dbase[(size_t)b * 512 + col] = ex - part[col & ~127u];
 }
 
 static void launch_refine(bzh_ctx *ctx, RefineArgs &r, uint32_t B, uint32_t maxcnt)
@@ -1038,6 +1108,7 @@ static void launch_refine(bzh_ctx *ctx, RefineArgs &r, uint32_t B, uint32_t maxc
     flag_tiles<<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(r);
     flag_carry<<<dim3(B), 1024, 0, ctx->stream>>>(r);
     refine<<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(r);
+    if (r.dig) sweep_bases<<<dim3(B), 768, 0, ctx->stream>>>(r, ctx->bt.dbase);
 }
 
 // Suffix-sort and emit the last column for blocks 0..B-1 of the batch (bt.rle / bt.n filled).
@@ -1065,31 +1136,31 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     // passes 4-7 order by those.  A plain pass over every suffix costs far less than a doubling round
     // does per suffix, so this replaces "4-byte sort + refine + first doubling round".
     // The passes run as single look-back kernels (no histogram / scan launches): their digit bases
-    // are the block's byte counts.  Status words and bases live in sa / headp, which nothing uses
-    // before the first refine.
+    // are the block's byte counts.
     a.cnt = bt.n;
     a.gate = bt.n;
     a.shift = 32;
     a.h = 4; // key offset for GEN_BYTES4
     a.src = nullptr;
     a.dst = bufA;
-    a.look = reinterpret_cast<u64 *>(bt.sa);
-    a.dbase = bt.headp;
+    a.look = reinterpret_cast<u64 *>(bt.hist);
+    a.dbase = bt.dbase;
+    a.doff = 0;
     a.err = bt.errflag;
     a.pass = 0;
     HIP_TRY(ctx, hipMemsetAsync(bt.errflag, 0, sizeof(uint32_t), st));
     HIP_TRY(ctx, hipMemsetAsync(a.look, 0, (size_t)B * bt.TPB * NBMAX * sizeof(u64), st));
-    byte_base<<<dim3(B), 1024, 0, st>>>(bt.rle, bt.n, bt.headp, bt.S);
-    launch_osw_pass<GEN_BYTES4, false>(ctx, a, B, nmax, ntotal);
+    byte_base<<<dim3(B), 1024, 0, st>>>(bt.rle, bt.n, bt.dbase, bt.S);
+    launch_osw_pass<8, GEN_BYTES4, false>(ctx, a, B, nmax, ntotal);
     u64 *cur = bufA, *oth = bufB;
     for (int p = 1; p < 8; p++) {
         a.shift = 32 + 8 * (p & 3);
         a.src = cur;
         a.dst = oth;
         if (p == 3)
-            launch_osw_pass<GEN_LIST, true>(ctx, a, B, nmax, ntotal);
+            launch_osw_pass<8, GEN_LIST, true>(ctx, a, B, nmax, ntotal);
         else
-            launch_osw_pass<GEN_LIST, false>(ctx, a, B, nmax, ntotal);
+            launch_osw_pass<8, GEN_LIST, false>(ctx, a, B, nmax, ntotal);
         u64 *t = cur;
         cur = oth;
         oth = t;
@@ -1119,6 +1190,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     r.S = bt.S;
     r.TPB = bt.TPB;
     r.init = 1;
+    r.dig = bt.hist; // the first round may be a SWEEP
     launch_refine(ctx, r, B, nmax);
 
     // ---- doubling rounds ---------------------------------------------------------------------------
@@ -1224,20 +1296,24 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         if (!maxact) {
             // every unresolved block is in TAIL mode
         } else if (!active_mode) {
+            // three look-back passes; the last refine left the digit bases (sweep_bases)
             a.cnt = bt.n; // enumerate SA positions
             a.shift = 40;
+            a.doff = 0;
             a.src = nullptr;
             a.dst = bufA;
-            launch_pass<7, GEN_SWEEP>(ctx, a, B, nmax, sum);
+            launch_osw_pass<7, GEN_SWEEP, false>(ctx, a, B, nmax, sum);
             a.cnt = nact;
             a.shift = 47;
+            a.doff = 128;
             a.src = bufA;
             a.dst = bufB;
-            launch_pass<7, GEN_LIST>(ctx, a, B, maxact, sum);
+            launch_osw_pass<7, GEN_LIST, false>(ctx, a, B, maxact, sum);
             a.shift = 54;
+            a.doff = 256;
             a.src = bufB;
             a.dst = bufA;
-            launch_pass<7, GEN_LIST>(ctx, a, B, maxact, sum);
+            launch_osw_pass<7, GEN_LIST, false>(ctx, a, B, maxact, sum);
             next_cur = bufA;
             next_oth = bufB;
         } else {
@@ -1287,6 +1363,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             r.nact_next = nact_next;
             r.maxgrp = nact_next + mb;
             r.init = 0;
+            r.dig = active_mode ? nullptr : bt.hist; // only a SWEEP round needs the digit bases
             r.writeback = 1;
             r.gate = bt.gateR;
             launch_refine(ctx, r, B, maxact);

@@ -62,7 +62,8 @@ struct Batch {
     uint32_t *headp; // [B][S] group rank by SA position (SWEEP rounds read it instead of gathering)
     uint2 *listA;   // [B][S] (key, suffix)
     uint2 *listB;   // [B][S]
-    uint32_t *hist; // [B][256*TPB]
+    uint32_t *hist; // [B][TPB][512]: 2 KiB per sort tile -- digit-count rows, look-back status words, refine's digit rows
+    uint32_t *dbase; // [B][512] digit bases of the look-back passes
     uint8_t *flg;   // [B][S]
     int2 *tagg;     // [B][TPB] tile aggregates (last group start, last boundary)
     uint32_t *nactA; // [B]
