@@ -79,7 +79,8 @@ static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
     carve(p, bt.listA, NB * S);
     carve(p, bt.listB, NB * S);
     carve(p, bt.hist, NB * 512 * bt.TPB);
-    carve(p, bt.dbase, NB * 512);
+    carve(p, bt.dbase, NB * DB_STRIDE);
+    carve(p, bt.dtot, NB * DB_STRIDE);
     carve(p, bt.flg, NB * S);
     carve(p, bt.tagg, NB * bt.TPB);
     // per-round state: three rotating {unresolved counts[NB], largest group[NB]} pairs, each pair

@@ -44,7 +44,8 @@ enum GenMode : int {
     GEN_BYTES4 = 0, // element e is suffix e keyed by its 4-byte cyclic prefix
     GEN_SWEEP = 1,  // doubling round, SA-order enumeration
     GEN_ACTIVE = 2, // doubling round, re-key the previous sorted list
-    GEN_LIST = 3    // element e is src[e]
+    GEN_LIST = 3,   // element e is src[e]
+    GEN_LISTH = 4   // element e is src[e] unless that is LIST_INVALID (a hole)
 };
 
 constexpr u64 SUF_MASK = 0xFFFFFull;
@@ -66,7 +67,7 @@ struct SortArgs {
     uint32_t recrank; // GEN_ACTIVE: src records carry the suffix's current group rank (refine wrote it back)
     // single-pass (look-back) scatter of the initial sort only:
     u64 *look;             // [B][TPB][256] tile status words  [pass:32][state:2][count:30]
-    const uint32_t *dbase; // [B][512] first slot of every digit (exclusive scan of the pass's digit totals)
+    const uint32_t *dbase; // [B][DB_STRIDE] first slot of every digit (exclusive scan of the pass's digit totals)
     uint32_t doff;         // which 128/256-entry group of dbase this pass uses
     uint32_t *err;         // bit 1: a look-back gave up (internal error, never a hang)
     uint32_t pass;         // id of this pass in the status words (stale words read as "not there yet")
@@ -160,6 +161,9 @@ __device__ __forceinline__ bool gen_elem(const SortArgs &a, uint32_t b, uint32_t
         }
         v = ((u64)r << 40) | ((u64)k2 << 20) | i;
         return true;
+    } else if (MODE == GEN_LISTH) {
+        v = a.src[base + e];
+        return v != LIST_INVALID;
     } else {
         v = a.src[base + e];
         return true;
@@ -281,7 +285,72 @@ __global__ void __launch_bounds__(1024) byte_base(const uint8_t *blk, const uint
     }
     uint32_t tot;
     const uint32_t ex = block_excl_add(c, ls, &tot);
-    if (threadIdx.x < 256) dbase[(size_t)b * 512 + threadIdx.x] = ex;
+    if (threadIdx.x < 256) dbase[(size_t)b * DB_STRIDE + threadIdx.x] = ex;
+}
+
+// ACTIVE round, step 1: re-key the previous sorted list ONCE (gen_elem<GEN_ACTIVE>: one gather per
+// unresolved suffix) into dst -- same slot, LIST_INVALID where the suffix is resolved -- and count
+// all five 8-bit digits of the new keys (bits 20..59) into the block's totals, from which
+// active_bases makes the bases of the five look-back passes that follow.
+__global__ void __launch_bounds__(SORT_THREADS) active_gen(SortArgs a, uint32_t *dtot)
+{
+    uint32_t b, tile;
+    if (!wg_map(a.T, a.B, b, tile)) return;
+    if (a.gate[b] == 0) return;
+    const uint32_t cnt = a.cnt[b], n = a.n[b];
+    const uint32_t ntile = (cnt + SORT_TILE - 1) / SORT_TILE;
+    if (tile >= ntile) return;
+    __shared__ uint32_t h[5 * 256];
+    for (int k = threadIdx.x; k < 5 * 256; k += SORT_THREADS) h[k] = 0;
+    __syncthreads();
+    u64 *dst = a.dst + (size_t)b * a.S;
+    const int lane = threadIdx.x & 63;
+#pragma unroll 4
+    for (int k = 0; k < SORT_ITEMS; k++) {
+        const uint32_t e = tile * SORT_TILE + k * SORT_THREADS + threadIdx.x;
+        u64 v = LIST_INVALID;
+        const bool ok = e < cnt && gen_elem<GEN_ACTIVE, true>(a, b, e, n, v);
+        if (e < cnt) dst[e] = ok ? v : LIST_INVALID;
+        if (ok) {
+            atomicAdd(&h[(uint32_t)(v >> 20) & 255u], 1u);
+            atomicAdd(&h[256 + ((uint32_t)(v >> 28) & 255u)], 1u);
+            atomicAdd(&h[512 + ((uint32_t)(v >> 36) & 255u)], 1u);
+        }
+        // the list is ordered by rank, so a wavefront's 64 suffixes nearly always share the two upper
+        // rank digits: one LDS add per distinct value instead of 64 adds onto the same counter
+        const uint32_t up = (uint32_t)(v >> 44) & 0xFFFFu;
+        u64 todo = __ballot(ok);
+        while (todo) {
+            const int first = __ffsll((long long)todo) - 1;
+            const uint32_t u0 = (uint32_t)__builtin_amdgcn_readlane((int)up, first);
+            const u64 same = __ballot(ok && up == u0) & todo;
+            if (lane == first) {
+                const uint32_t c = (uint32_t)__popcll(same);
+                atomicAdd(&h[768 + (u0 & 255u)], c);
+                atomicAdd(&h[1024 + (u0 >> 8)], c);
+            }
+            todo &= ~same;
+        }
+    }
+    __syncthreads();
+    uint32_t *tot = dtot + (size_t)b * DB_STRIDE;
+    for (int k = threadIdx.x; k < 5 * 256; k += SORT_THREADS)
+        if (h[k]) atomicAdd(&tot[k], h[k]);
+}
+
+// One workgroup per block: exclusive scan inside each of the five digits.
+__global__ void __launch_bounds__(256) active_bases(const uint32_t *dtot, uint32_t *dbase, const uint32_t *gate)
+{
+    const uint32_t b = blockIdx.x;
+    if (gate[b] == 0) return;
+    __shared__ uint32_t ls[8];
+#pragma unroll 1
+    for (int p = 0; p < 5; p++) {
+        const uint32_t v = dtot[(size_t)b * DB_STRIDE + p * 256 + threadIdx.x];
+        uint32_t tot;
+        const uint32_t ex = block_excl_add(v, ls, &tot);
+        dbase[(size_t)b * DB_STRIDE + p * 256 + threadIdx.x] = ex;
+    }
 }
 
 constexpr uint32_t LOOK_LOCAL = 1u, LOOK_GLOBAL = 2u;
@@ -399,7 +468,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
         }
         __hip_atomic_store(col + (size_t)tile * NBMAX, look_word(a.pass, LOOK_GLOBAL, acc + mytot), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
-        goff[bin] = a.dbase[(size_t)b * 512 + a.doff + bin] + acc;
+        goff[bin] = a.dbase[(size_t)b * DB_STRIDE + a.doff + bin] + acc;
     }
     __syncthreads();
     u64 *dst = a.dst + (size_t)b * a.S;
@@ -1096,7 +1165,7 @@ __global__ void __launch_bounds__(768) sweep_bases(RefineArgs a, uint32_t *dbase
     const uint32_t ex = block_excl_add(c, ls, &tot); // threads 0..383 in (digit, value) order, the rest add 0
     if (!seg) part[col] = ex;
     __syncthreads();
-    if (!seg) dbase[(size_t)b * 512 + col] = ex - part[col & ~127u];
+    if (!seg) dbase[(size_t)b * DB_STRIDE + col] = ex - part[col & ~127u];
 }
 
 static void launch_refine(bzh_ctx *ctx, RefineArgs &r, uint32_t B, uint32_t maxcnt)
@@ -1317,25 +1386,39 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             next_cur = bufA;
             next_oth = bufB;
         } else {
-            next_cur = oth; // 5 passes leave the new list in `oth`
-            next_oth = cur;
+            // re-key once (active_gen), then five look-back passes on bits 20..59; the list ends in `cur`
             {
-                u64 *c = cur, *o = oth;
-                a.cnt = prevcnt; // re-key the previous sorted list
+                const uint32_t gt = (prevmax + SORT_TILE - 1) / SORT_TILE;
+                HIP_TRY(ctx, hipMemsetAsync(bt.dtot, 0, (size_t)B * DB_STRIDE * sizeof(uint32_t), st));
+                a.cnt = prevcnt;
+                a.src = cur;
+                a.dst = oth;
+                a.T = gt;
+                a.B = B;
+                if (gt) {
+                    active_gen<<<dim3(xcd_grid(gt, B)), SORT_THREADS, 0, st>>>(a, bt.dtot);
+                    active_bases<<<dim3(B), 256, 0, st>>>(bt.dtot, bt.dbase, bt.gateR);
+                }
+                u64 *c = oth, *o = cur;
                 a.shift = 20;
+                a.doff = 0;
                 a.src = c;
                 a.dst = o;
-                launch_pass<8, GEN_ACTIVE>(ctx, a, B, prevmax, sum);
+                launch_osw_pass<8, GEN_LISTH, false>(ctx, a, B, prevmax, sum); // skips the holes
                 a.cnt = nact;
                 for (int p = 1; p < 5; p++) {
                     u64 *t = c;
                     c = o;
                     o = t;
                     a.shift = 20 + 8 * p;
+                    a.doff = 256 * p;
                     a.src = c;
                     a.dst = o;
-                    launch_pass<8, GEN_LIST>(ctx, a, B, maxact, sum);
+                    launch_osw_pass<8, GEN_LIST, false>(ctx, a, B, maxact, sum);
                 }
+                // gen: cur -> oth; passes: oth -> cur -> oth -> cur -> oth -> cur
+                next_cur = cur;
+                next_oth = oth;
             }
         }
         if (maxtail) { // blocks in TAIL mode: in place in their own buffer, independent of cur/oth

@@ -34,6 +34,7 @@ void bzh_set_error(bzh_ctx *ctx, const char *fmt, ...);
 // Every per-block device array uses one stride S (bytes/elements per bzip2 block), a multiple
 // of the sort tile so tiles never straddle blocks.
 constexpr int SORT_THREADS = 256;
+constexpr int DB_STRIDE = 1280; // digit-base entries per block: up to 5 digits x 256 values
 constexpr int SORT_ITEMS = 16;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS; // 4096 elements per workgroup
 constexpr uint32_t RANK_RESOLVED = 0x80000000u;      // suffix is alone in its group
@@ -63,7 +64,8 @@ struct Batch {
     uint2 *listA;   // [B][S] (key, suffix)
     uint2 *listB;   // [B][S]
     uint32_t *hist; // [B][TPB][512]: 2 KiB per sort tile -- digit-count rows, look-back status words, refine's digit rows
-    uint32_t *dbase; // [B][512] digit bases of the look-back passes
+    uint32_t *dbase; // [B][DB_STRIDE] digit bases of the look-back passes
+    uint32_t *dtot;  // [B][DB_STRIDE] digit totals of an ACTIVE round (5 digits x 256)
     uint8_t *flg;   // [B][S]
     int2 *tagg;     // [B][TPB] tile aggregates (last group start, last boundary)
     uint32_t *nactA; // [B]
