@@ -10,27 +10,34 @@
 //      init pass :  [ 4 bytes of the cyclic prefix : 32 ][ 0 : 12 ][ suffix : 20 ]
 //      rounds    :  [ 0:4 ][ group rank r : 20 ][ key2 = rank[i+h] : 20 ][ suffix i : 20 ]
 // (n < 2^20 at every level).  rank = first SA position of the suffix's group, bit 31 = resolved.
-// Initial LSD radix sort on the 8-byte prefix (8 passes x 8 bits, key half swapped after pass 4).
-// A doubling round with depth h comes
-// in two forms, chosen per round from the unresolved fraction:
+// Initial LSD radix sort on the 8-byte prefix (8 passes x 8 bits, key half swapped after pass 4),
+// then doubling rounds from depth h = 8, each in one of three forms:
 //   SWEEP  (most suffixes unresolved): unresolved suffixes are ENUMERATED in SA order of suffix
 //          i+h (a coalesced sweep of SA + rank gathers) and stably sorted by r only -- 3 passes of
 //          7 bits; stability leaves every group in key2 order, key2 is carried only for flagging;
-//   ACTIVE (few unresolved): the previous round's sorted list is re-keyed and sorted on (r, key2)
-//          -- 5 passes of 8 bits over the unresolved suffixes only, nothing proportional to n.
+//   ACTIVE (few unresolved): the previous round's sorted list is re-keyed once (active_gen) and
+//          sorted on (r, key2) -- 5 passes of 8 bits over the unresolved suffixes only;
+//   TAIL   (per block, once all its groups are small): groups are ranked locally (tail_*).
 // Then boundary flags, max-scan of group heads, rank/SA update; resolved suffixes drop out.
 // When h >= n the survivors are identical rotations (block = w^k): key2 becomes n-1-i (ACTIVE) or
 // the enumeration runs over descending i (SWEEP), the reference's tie rule.
 //
+// Every radix pass is ONE kernel (radix_scatter): a tile publishes its digit counts and finds its
+// first slots by decoupled look-back over the earlier tiles of its block; the digit totals a pass
+// needs up front are a by-product of the step before it (byte_base / refine + sweep_bases /
+// active_gen + active_bases), so nothing is ever read just to be counted.
+//
 // Launch geometry: workgroup ids are mapped so that all tiles of bzip2 block b run on XCD b mod 8
 // (wg_map), keeping the block's rank/SA arrays (3.6 MB each) inside one 4 MiB L2.
 // Kernels (integer only, HBM/LDS bound, no MFMA):
-//   radix_hist     per-tile digit histogram in LDS                -> hist[b][digit][tile]
-//   radix_scan     per-block exclusive scan of hist (1 workgroup per bzip2 block)
-//   radix_scatter  stable scatter: wave match-any ranking, per-wave LDS cursors, elements
-//                  reordered in LDS so each digit's run leaves the CU as coalesced stores
+//   byte_base      digit bases of the 8 initial passes (= byte counts of the cyclic block)
+//   radix_scatter  stable single-pass scatter: wave match-any ranking, per-wave LDS cursors,
+//                  look-back for the tile's global offsets, elements reordered in LDS so each
+//                  digit's run leaves the CU as coalesced stores
 //   flag_tiles / flag_carry / refine   boundary flags, max-scan of group heads, rank + SA update
 //                  (tiles staged through LDS: coalesced global access, blocked per-thread scans)
+//   sweep_bases / active_gen / active_bases   digit bases of the SWEEP / ACTIVE passes
+//   tail_sort / tail_apply / tail_scan / tail_compact   TAIL rounds
 //   bwt_emit       last column, ptr, has_byte
 #include <vector>
 
@@ -61,7 +68,6 @@ struct SortArgs {
     const uint32_t *headp; // [B][S] group rank of the suffix at each SA position
     const u64 *src;       // [B][S]
     u64 *dst;             // [B][S]
-    uint32_t *hist;       // [B][NBMAX*TPB]
     uint32_t S, TPB, h, shift;
     uint32_t T, B; // launch geometry: tiles per block in this launch, blocks
     uint32_t recrank; // GEN_ACTIVE: src records carry the suffix's current group rank (refine wrote it back)
@@ -167,89 +173,6 @@ __device__ __forceinline__ bool gen_elem(const SortArgs &a, uint32_t b, uint32_t
     } else {
         v = a.src[base + e];
         return true;
-    }
-}
-
-template <int BITS, int MODE>
-__global__ void __launch_bounds__(SORT_THREADS) radix_hist(SortArgs a)
-{
-    constexpr int NB = 1 << BITS;
-    uint32_t b, tile;
-    if (!wg_map(a.T, a.B, b, tile)) return;
-    if (a.gate[b] == 0) return;
-    const uint32_t cnt = a.cnt[b], n = a.n[b];
-    const uint32_t ntile = (cnt + SORT_TILE - 1) / SORT_TILE;
-    if (tile >= ntile) return;
-    __shared__ uint32_t h[NB];
-    for (int k = threadIdx.x; k < NB; k += SORT_THREADS) h[k] = 0;
-    __syncthreads();
-#pragma unroll 4
-    for (int k = 0; k < SORT_ITEMS; k++) {
-        const uint32_t e = tile * SORT_TILE + k * SORT_THREADS + threadIdx.x;
-        if (e < cnt) {
-            u64 v;
-            // in ACTIVE mode the first digit lies in key2, so it must be generated
-            if (gen_elem<MODE, MODE == GEN_ACTIVE>(a, b, e, n, v)) atomicAdd(&h[(uint32_t)(v >> a.shift) & (NB - 1)], 1u);
-        }
-    }
-    __syncthreads();
-    uint32_t *out = a.hist + (size_t)b * NBMAX * a.TPB;
-    for (int k = threadIdx.x; k < NB; k += SORT_THREADS) out[(size_t)tile * NBMAX + k] = h[k]; // tile-major rows
-}
-
-// One workgroup per bzip2 block: exclusive scan of hist in (digit major, tile minor) order.  The
-// table is stored tile-major (one row of NB counts per tile), so thread (segment, digit) walks a
-// contiguous range of tiles down its digit's column and a wavefront always touches 64 consecutive
-// counts: sum the column segment, scan the 1024 segment sums in (digit, segment) order, walk again.
-template <int BITS>
-__global__ void __launch_bounds__(1024) radix_scan(SortArgs a)
-{
-    constexpr int NB = 1 << BITS;
-    constexpr int SEG = 1024 / NB; // column segments per digit
-    const uint32_t b = blockIdx.x;
-    if (a.gate[b] == 0) return;
-    const uint32_t cnt = a.cnt[b];
-    const uint32_t ntile = (cnt + SORT_TILE - 1) / SORT_TILE;
-    uint32_t *hist = a.hist + (size_t)b * NBMAX * a.TPB;
-    const uint32_t seg = threadIdx.x / NB, bin = threadIdx.x % NB;
-    const uint32_t per = (ntile + SEG - 1) / SEG;
-    const uint32_t t0 = min(ntile, seg * per), t1 = min(ntile, t0 + per);
-    uint32_t *col = hist + bin;
-    uint32_t sum = 0;
-    uint32_t t = t0;
-    for (; t + 8 <= t1; t += 8) {
-        uint32_t v[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = col[(size_t)(t + k) * NBMAX];
-#pragma unroll
-        for (int k = 0; k < 8; k++) sum += v[k];
-    }
-    for (; t < t1; t++) sum += col[(size_t)t * NBMAX];
-    __shared__ uint32_t ord[1024];
-    __shared__ uint32_t lds[20];
-    ord[bin * SEG + seg] = sum;
-    __syncthreads();
-    uint32_t tot;
-    const uint32_t mine = ord[threadIdx.x];
-    const uint32_t ex = block_excl_add(mine, lds, &tot);
-    ord[threadIdx.x] = ex;
-    __syncthreads();
-    uint32_t run = ord[bin * SEG + seg];
-    t = t0;
-    for (; t + 8 <= t1; t += 8) {
-        uint32_t v[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = col[(size_t)(t + k) * NBMAX];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            col[(size_t)(t + k) * NBMAX] = run;
-            run += v[k];
-        }
-    }
-    for (; t < t1; t++) {
-        const uint32_t v = col[(size_t)t * NBMAX];
-        col[(size_t)t * NBMAX] = run;
-        run += v;
     }
 }
 
@@ -361,13 +284,13 @@ __device__ __forceinline__ u64 look_word(uint32_t pass, uint32_t state, uint32_t
 
 // REKEY: the element leaves with the key of the NEXT key half (bytes i..i+3 of the rotation) --
 // used by the last pass over the low half of the 8-byte prefix.
-// OSW ("one sweep"): no histogram / scan launches before this kernel.  The tile publishes its digit
+// Single pass: no histogram / scan launches before this kernel.  The tile publishes its digit
 // counts, then each digit's thread looks back over the earlier tiles of the block (decoupled
 // look-back: a predecessor offers either its own counts or, once known, its inclusive prefix) for
 // the tile's first slot; digit bases come from a.dbase.  A status word is one 64-bit atomic, so no
 // fences are needed; tiles only ever wait for LOWER workgroup ids, which the dispatcher starts
 // first; waits are bounded (a.err) so that a logic error cannot hang the device.
-template <int BITS, int MODE, bool REKEY = false, bool OSW = false>
+template <int BITS, int MODE, bool REKEY = false>
 __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
 {
     constexpr int NB = 1 << BITS;
@@ -412,11 +335,8 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
     if (threadIdx.x < NB) {
         const uint32_t bin = threadIdx.x;
         binstart[bin] = ex;
-        if (OSW)
-            __hip_atomic_store(a.look + ((size_t)b * a.TPB + tile) * NBMAX + bin, look_word(a.pass, LOOK_LOCAL, mytot),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else
-            goff[bin] = a.hist[(size_t)b * NBMAX * a.TPB + (size_t)tile * NBMAX + bin];
+        __hip_atomic_store(a.look + ((size_t)b * a.TPB + tile) * NBMAX + bin, look_word(a.pass, LOOK_LOCAL, mytot),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t g = ex;
 #pragma unroll
         for (int w = 0; w < NW; w++) {
@@ -446,7 +366,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
             stage[basepos + off] = v[k];
         }
     }
-    if (OSW && threadIdx.x < NB) { // look back for the counts of digit `bin` in tiles 0 .. tile-1
+    if (threadIdx.x < NB) { // look back for the counts of digit `bin` in tiles 0 .. tile-1
         const uint32_t bin = threadIdx.x;
         u64 *col = a.look + (size_t)b * a.TPB * NBMAX + bin;
         uint32_t acc = 0, spins = 0;
@@ -1087,33 +1007,9 @@ __global__ void __launch_bounds__(256) bwt_emit(Batch bt, uint32_t T, uint32_t B
 }
 
 // ---- host driver -----------------------------------------------------------------------------------
-template <int BITS, int MODE>
-static void launch_pass(bzh_ctx *ctx, SortArgs &a, uint32_t B, uint32_t maxcnt, uint64_t elems)
-{
-    const uint32_t tiles = (maxcnt + SORT_TILE - 1) / SORT_TILE;
-    if (tiles == 0) return;
-    a.T = tiles;
-    a.B = B;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    radix_hist<BITS, MODE><<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(a);
-    radix_scan<BITS><<<dim3(B), 1024, 0, ctx->stream>>>(a);
-    if (ctx->profiling) { // HIP events bracket the dominant kernel only
-        e0 = bzh_event(ctx);
-        hipEventRecord(e0, ctx->stream);
-    }
-    radix_scatter<BITS, MODE><<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(a);
-    if (ctx->profiling) {
-        e1 = bzh_event(ctx);
-        hipEventRecord(e1, ctx->stream);
-        ctx->sort_spans.push_back({e0, e1});
-        ctx->stats.bwt_sort_launches += 1;
-        ctx->stats.bwt_sort_elems += elems; // elements this launch writes
-    }
-}
-
-// one pass of the initial sort: single kernel (look-back scatter)
+// one radix pass = one kernel (look-back scatter)
 template <int BITS, int MODE, bool REKEY>
-static void launch_osw_pass(bzh_ctx *ctx, SortArgs &a, uint32_t B, uint32_t maxcnt, uint64_t elems)
+static void launch_pass(bzh_ctx *ctx, SortArgs &a, uint32_t B, uint32_t maxcnt, uint64_t elems)
 {
     const uint32_t tiles = (maxcnt + SORT_TILE - 1) / SORT_TILE;
     if (tiles == 0) return;
@@ -1125,7 +1021,7 @@ static void launch_osw_pass(bzh_ctx *ctx, SortArgs &a, uint32_t B, uint32_t maxc
         e0 = bzh_event(ctx);
         hipEventRecord(e0, ctx->stream);
     }
-    radix_scatter<BITS, MODE, REKEY, true><<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(a);
+    radix_scatter<BITS, MODE, REKEY><<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(a);
     if (ctx->profiling) {
         e1 = bzh_event(ctx);
         hipEventRecord(e1, ctx->stream);
@@ -1195,7 +1091,6 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     a.rank = bt.rank;
     a.sa = bt.sa;
     a.headp = bt.headp;
-    a.hist = bt.hist;
     a.S = bt.S;
     a.TPB = bt.TPB;
     a.h = 0;
@@ -1220,16 +1115,16 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     HIP_TRY(ctx, hipMemsetAsync(bt.errflag, 0, sizeof(uint32_t), st));
     HIP_TRY(ctx, hipMemsetAsync(a.look, 0, (size_t)B * bt.TPB * NBMAX * sizeof(u64), st));
     byte_base<<<dim3(B), 1024, 0, st>>>(bt.rle, bt.n, bt.dbase, bt.S);
-    launch_osw_pass<8, GEN_BYTES4, false>(ctx, a, B, nmax, ntotal);
+    launch_pass<8, GEN_BYTES4, false>(ctx, a, B, nmax, ntotal);
     u64 *cur = bufA, *oth = bufB;
     for (int p = 1; p < 8; p++) {
         a.shift = 32 + 8 * (p & 3);
         a.src = cur;
         a.dst = oth;
         if (p == 3)
-            launch_osw_pass<8, GEN_LIST, true>(ctx, a, B, nmax, ntotal);
+            launch_pass<8, GEN_LIST, true>(ctx, a, B, nmax, ntotal);
         else
-            launch_osw_pass<8, GEN_LIST, false>(ctx, a, B, nmax, ntotal);
+            launch_pass<8, GEN_LIST, false>(ctx, a, B, nmax, ntotal);
         u64 *t = cur;
         cur = oth;
         oth = t;
@@ -1371,18 +1266,18 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             a.doff = 0;
             a.src = nullptr;
             a.dst = bufA;
-            launch_osw_pass<7, GEN_SWEEP, false>(ctx, a, B, nmax, sum);
+            launch_pass<7, GEN_SWEEP, false>(ctx, a, B, nmax, sum);
             a.cnt = nact;
             a.shift = 47;
             a.doff = 128;
             a.src = bufA;
             a.dst = bufB;
-            launch_osw_pass<7, GEN_LIST, false>(ctx, a, B, maxact, sum);
+            launch_pass<7, GEN_LIST, false>(ctx, a, B, maxact, sum);
             a.shift = 54;
             a.doff = 256;
             a.src = bufB;
             a.dst = bufA;
-            launch_osw_pass<7, GEN_LIST, false>(ctx, a, B, maxact, sum);
+            launch_pass<7, GEN_LIST, false>(ctx, a, B, maxact, sum);
             next_cur = bufA;
             next_oth = bufB;
         } else {
@@ -1404,7 +1299,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
                 a.doff = 0;
                 a.src = c;
                 a.dst = o;
-                launch_osw_pass<8, GEN_LISTH, false>(ctx, a, B, prevmax, sum); // skips the holes
+                launch_pass<8, GEN_LISTH, false>(ctx, a, B, prevmax, sum); // skips the holes
                 a.cnt = nact;
                 for (int p = 1; p < 5; p++) {
                     u64 *t = c;
@@ -1414,7 +1309,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
                     a.doff = 256 * p;
                     a.src = c;
                     a.dst = o;
-                    launch_osw_pass<8, GEN_LIST, false>(ctx, a, B, maxact, sum);
+                    launch_pass<8, GEN_LIST, false>(ctx, a, B, maxact, sum);
                 }
                 // gen: cur -> oth; passes: oth -> cur -> oth -> cur -> oth -> cur
                 next_cur = cur;

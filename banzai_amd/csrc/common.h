@@ -63,7 +63,7 @@ struct Batch {
     uint32_t *headp; // [B][S] group rank by SA position (SWEEP rounds read it instead of gathering)
     uint2 *listA;   // [B][S] (key, suffix)
     uint2 *listB;   // [B][S]
-    uint32_t *hist; // [B][TPB][512]: 2 KiB per sort tile -- digit-count rows, look-back status words, refine's digit rows
+    uint32_t *hist; // [B][TPB][512]: 2 KiB per sort tile -- look-back status words (256 x u64) or refine digit rows
     uint32_t *dbase; // [B][DB_STRIDE] digit bases of the look-back passes
     uint32_t *dtot;  // [B][DB_STRIDE] digit totals of an ACTIVE round (5 digits x 256)
     uint8_t *flg;   // [B][S]
