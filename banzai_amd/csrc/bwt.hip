@@ -24,13 +24,13 @@
 //
 // Every radix pass is ONE kernel (radix_scatter): a tile publishes its digit counts and finds its
 // first slots by decoupled look-back over the earlier tiles of its block; the digit totals a pass
-// needs up front are a by-product of the step before it (byte_base / refine + sweep_bases /
+// needs up front are a by-product of the step before it (byte_count / refine + sweep_bases /
 // active_gen + active_bases), so nothing is ever read just to be counted.
 //
 // Launch geometry: workgroup ids are mapped so that all tiles of bzip2 block b run on XCD b mod 8
 // (wg_map), keeping the block's rank/SA arrays (3.6 MB each) inside one 4 MiB L2.
 // Kernels (integer only, HBM/LDS bound, no MFMA):
-//   byte_base      digit bases of the 8 initial passes (= byte counts of the cyclic block)
+//   byte_count     digit totals of the 8 initial passes (= byte counts of the cyclic block)
 //   radix_scatter  stable single-pass scatter: wave match-any ranking, per-wave LDS cursors,
 //                  look-back for the tile's global offsets, elements reordered in LDS so each
 //                  digit's run leaves the CU as coalesced stores
@@ -176,20 +176,24 @@ __device__ __forceinline__ bool gen_elem(const SortArgs &a, uint32_t b, uint32_t
     }
 }
 
-// Digit bases of the initial sort.  Every one of its 8 passes keys on one byte of the CYCLIC
-// rotation, so each pass's digit histogram is the block's byte histogram: one workgroup per block
-// counts the bytes once (per-wave private counters) and leaves the exclusive scan.
-__global__ void __launch_bounds__(1024) byte_base(const uint8_t *blk, const uint32_t *nn, uint32_t *dbase, uint32_t S)
+// Digit totals of the initial sort.  Every one of its 8 passes keys on one byte of the CYCLIC
+// rotation, so each pass's digit histogram is the block's byte histogram: BYTE_SEGS workgroups per
+// block count a segment each (per-wave private counters) and add it to dtot[b][0..255];
+// active_bases(…, 1) then leaves the exclusive scan in dbase.
+constexpr int BYTE_SEGS = 8;
+__global__ void __launch_bounds__(1024) byte_count(const uint8_t *blk, const uint32_t *nn, uint32_t *dtot, uint32_t S)
 {
-    const uint32_t b = blockIdx.x, n = nn[b];
+    const uint32_t b = blockIdx.y, n = nn[b];
     const uint8_t *s = blk + (size_t)b * S;
+    const uint32_t per = ((n + BYTE_SEGS - 1) / BYTE_SEGS + 3u) & ~3u; // keeps the dword loads aligned
+    const uint32_t lo = min(n, blockIdx.x * per), hi = min(n, lo + per);
+    if (lo >= hi) return;
     __shared__ uint32_t h[16][256];
-    __shared__ uint32_t ls[20];
     for (int k = threadIdx.x; k < 16 * 256; k += 1024) (&h[0][0])[k] = 0;
     __syncthreads();
     uint32_t *mine = h[threadIdx.x >> 6];
-    for (uint32_t i = threadIdx.x * 4; i < n; i += 4096) {
-        if (i + 4 <= n) {
+    for (uint32_t i = lo + threadIdx.x * 4; i < hi; i += 4096) {
+        if (i + 4 <= hi) {
             uint32_t w;
             __builtin_memcpy(&w, s + i, 4);
             atomicAdd(&mine[w & 255u], 1u);
@@ -197,18 +201,16 @@ __global__ void __launch_bounds__(1024) byte_base(const uint8_t *blk, const uint
             atomicAdd(&mine[(w >> 16) & 255u], 1u);
             atomicAdd(&mine[w >> 24], 1u);
         } else {
-            for (uint32_t j = i; j < n; j++) atomicAdd(&mine[s[j]], 1u);
+            for (uint32_t j = i; j < hi; j++) atomicAdd(&mine[s[j]], 1u);
         }
     }
     __syncthreads();
-    uint32_t c = 0;
     if (threadIdx.x < 256) {
+        uint32_t c = 0;
 #pragma unroll
         for (int w = 0; w < 16; w++) c += h[w][threadIdx.x];
+        if (c) atomicAdd(&dtot[(size_t)b * DB_STRIDE + threadIdx.x], c);
     }
-    uint32_t tot;
-    const uint32_t ex = block_excl_add(c, ls, &tot);
-    if (threadIdx.x < 256) dbase[(size_t)b * DB_STRIDE + threadIdx.x] = ex;
 }
 
 // ACTIVE round, step 1: re-key the previous sorted list ONCE (gen_elem<GEN_ACTIVE>: one gather per
@@ -261,14 +263,14 @@ __global__ void __launch_bounds__(SORT_THREADS) active_gen(SortArgs a, uint32_t 
         if (h[k]) atomicAdd(&tot[k], h[k]);
 }
 
-// One workgroup per block: exclusive scan inside each of the five digits.
-__global__ void __launch_bounds__(256) active_bases(const uint32_t *dtot, uint32_t *dbase, const uint32_t *gate)
+// One workgroup per block: exclusive scan inside each of the ndig digit groups of dtot.
+__global__ void __launch_bounds__(256) active_bases(const uint32_t *dtot, uint32_t *dbase, const uint32_t *gate, int ndig)
 {
     const uint32_t b = blockIdx.x;
     if (gate[b] == 0) return;
     __shared__ uint32_t ls[8];
 #pragma unroll 1
-    for (int p = 0; p < 5; p++) {
+    for (int p = 0; p < ndig; p++) {
         const uint32_t v = dtot[(size_t)b * DB_STRIDE + p * 256 + threadIdx.x];
         uint32_t tot;
         const uint32_t ex = block_excl_add(v, ls, &tot);
@@ -1114,7 +1116,9 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     a.pass = 0;
     HIP_TRY(ctx, hipMemsetAsync(bt.errflag, 0, sizeof(uint32_t), st));
     HIP_TRY(ctx, hipMemsetAsync(a.look, 0, (size_t)B * bt.TPB * NBMAX * sizeof(u64), st));
-    byte_base<<<dim3(B), 1024, 0, st>>>(bt.rle, bt.n, bt.dbase, bt.S);
+    HIP_TRY(ctx, hipMemsetAsync(bt.dtot, 0, (size_t)B * DB_STRIDE * sizeof(uint32_t), st));
+    byte_count<<<dim3(BYTE_SEGS, B), 1024, 0, st>>>(bt.rle, bt.n, bt.dtot, bt.S);
+    active_bases<<<dim3(B), 256, 0, st>>>(bt.dtot, bt.dbase, bt.n, 1);
     launch_pass<8, GEN_BYTES4, false>(ctx, a, B, nmax, ntotal);
     u64 *cur = bufA, *oth = bufB;
     for (int p = 1; p < 8; p++) {
@@ -1292,7 +1296,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
                 a.B = B;
                 if (gt) {
                     active_gen<<<dim3(xcd_grid(gt, B)), SORT_THREADS, 0, st>>>(a, bt.dtot);
-                    active_bases<<<dim3(B), 256, 0, st>>>(bt.dtot, bt.dbase, bt.gateR);
+                    active_bases<<<dim3(B), 256, 0, st>>>(bt.dtot, bt.dbase, bt.gateR, 5);
                 }
                 u64 *c = oth, *o = cur;
                 a.shift = 20;
