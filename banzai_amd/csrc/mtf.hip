@@ -116,10 +116,16 @@ __device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_re
 // NR = key registers in use (names < 64*NR).  All control flow is wave-uniform (scalar).
 template <int NR>
 __device__ __forceinline__ void walk_tile(const uint8_t *s, uint8_t *o, const int32_t *keys, const uint8_t *names,
-                                          uint32_t base_p, uint32_t tile_len, int lane)
+                                          int *lkeys, uint32_t base_p, uint32_t tile_len, int lane)
 {
     int k0 = keys[lane], k1 = NR > 1 ? keys[64 + lane] : INT32_MIN, k2 = NR > 2 ? keys[128 + lane] : INT32_MIN,
         k3 = NR > 2 ? keys[192 + lane] : INT32_MIN;
+    if (NR > 1) { // LDS copy of the keys (one wavefront per workgroup: program order is enough)
+        lkeys[lane] = k0;
+        lkeys[64 + lane] = k1;
+        lkeys[128 + lane] = k2;
+        lkeys[192 + lane] = k3;
+    }
     int front; // name at the head of the recency list = arg max key
     {
         int best = k0, bsym = lane;
@@ -136,6 +142,9 @@ __device__ __forceinline__ void walk_tile(const uint8_t *s, uint8_t *o, const in
         }
         front = __builtin_amdgcn_readfirstlane(bsym); // keys are distinct, every lane agrees
     }
+    // A byte equal to its predecessor is at the front of the list: position 0, nothing to update.
+    // The lanes find those in parallel (change mask); the scalar walk below only visits the others.
+    uint32_t carry_last = (uint32_t)front; // name of the byte before the chunk (list head at tile entry)
 #pragma unroll 1
     for (uint32_t cbase = 0; cbase < tile_len; cbase += 1024) {
         // 16 bytes per lane (S is padded so the vector load stays inside the arena), renamed once
@@ -147,47 +156,71 @@ __device__ __forceinline__ void walk_tile(const uint8_t *s, uint8_t *o, const in
             in[d] = (uint32_t)names[w & 255u] | ((uint32_t)names[(w >> 8) & 255u] << 8) |
                     ((uint32_t)names[(w >> 16) & 255u] << 16) | ((uint32_t)names[w >> 24] << 24);
         }
-        int o0 = 0, o1 = 0, o2 = 0, o3 = 0;
         const uint32_t clen = tile_len - cbase < 1024 ? tile_len - cbase : 1024;
         const uint32_t nl = (clen + 15) / 16;
+        // change mask: bit k = (byte k of this lane != the byte before it)
+        uint32_t pw = (uint32_t)__shfl_up((int)in[3], 1, 64);
+        if (lane == 0) pw = carry_last << 24;
+        uint32_t chg = 0;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const uint32_t x = in[d];
+            const uint32_t df = x ^ ((x << 8) | (pw >> 24));
+            chg |= ((df & 0xFFu) ? 1u : 0u) << (4 * d);
+            chg |= ((df & 0xFF00u) ? 2u : 0u) << (4 * d);
+            chg |= ((df & 0xFF0000u) ? 4u : 0u) << (4 * d);
+            chg |= ((df & 0xFF000000u) ? 8u : 0u) << (4 * d);
+            pw = x;
+        }
+        {
+            const uint32_t lo = (uint32_t)lane * 16u;
+            const uint32_t nv = clen > lo ? (clen - lo < 16u ? clen - lo : 16u) : 0u;
+            chg &= (1u << nv) - 1u; // bytes past the end of the tile are never visited
+        }
+        { // name of the chunk's last byte, for the next chunk's first comparison
+            const uint32_t e = clen - 1;
+            const uint32_t w = (uint32_t)rdlane((int)(((e >> 2) & 3u) == 0 ? in[0] : ((e >> 2) & 3u) == 1 ? in[1] : ((e >> 2) & 3u) == 2 ? in[2] : in[3]),
+                                                (int)(e >> 4));
+            carry_last = (w >> (8 * (e & 3u))) & 255u;
+        }
+        int o0 = 0, o1 = 0, o2 = 0, o3 = 0;
 #pragma unroll 1
         for (uint32_t li = 0; li < nl; li++) {
-            const uint32_t lim = clen - li * 16; // bytes valid in this lane (>= 1)
+            const uint32_t m = (uint32_t)rdlane((int)chg, (int)li);
+            if (m == 0) continue; // 16 bytes at the front of the list
             const bool me = (uint32_t)lane == li;
 #pragma unroll
             for (int d = 0; d < 4; d++) {
+                if (((m >> (4 * d)) & 15u) == 0) continue;
                 const uint32_t w = (uint32_t)rdlane((int)in[d], (int)li);
                 uint32_t ow = 0;
 #pragma unroll
                 for (int kb = 0; kb < 4; kb++) {
-                    if ((uint32_t)(d * 4 + kb) < lim) {
+                    if (m & (1u << (4 * d + kb))) {
                         const int c = (int)((w >> (8 * kb)) & 255u);
-                        if (c != front) {
-                            const int p = (int)(base_p + cbase + li * 16 + d * 4 + kb);
-                            const int l = c & 63, sel = c >> 6;
-                            const bool mine = lane == l;
-                            int prev = rdlane(k0, l);
-                            k0 = (mine && sel == 0) ? p : k0;
-                            if (NR > 1) {
-                                const int q1 = rdlane(k1, l);
-                                prev = sel == 1 ? q1 : prev;
-                                k1 = (mine && sel == 1) ? p : k1;
-                            }
+                        const int p = (int)(base_p + cbase + li * 16 + d * 4 + kb);
+                        int prev;
+                        if (NR == 1) { // names < 64: the key sits in lane c
+                            prev = rdlane(k0, c);
+                            k0 = lane == c ? p : k0;
+                        } else {
+                            // old key through the LDS copy (all lanes read / write the same word), new key
+                            // into the one lane whose name index matches: no scalar register selection
+                            prev = __builtin_amdgcn_readfirstlane(lkeys[c]);
+                            lkeys[c] = p;
+                            k0 = lane == c ? p : k0;
+                            k1 = lane + 64 == c ? p : k1;
                             if (NR > 2) {
-                                const int q2 = rdlane(k2, l), q3 = rdlane(k3, l);
-                                prev = sel == 2 ? q2 : prev;
-                                prev = sel == 3 ? q3 : prev;
-                                k2 = (mine && sel == 2) ? p : k2;
-                                k3 = (mine && sel == 3) ? p : k3;
+                                k2 = lane + 128 == c ? p : k2;
+                                k3 = lane + 192 == c ? p : k3;
                             }
-                            // c's own key is already p (> prev), every other key is unchanged:
-                            // position = (keys above prev) - 1 for the symbol itself.
-                            uint32_t cnt = (uint32_t)__popcll(__ballot(k0 > prev)) - 1u;
-                            if (NR > 1) cnt += (uint32_t)__popcll(__ballot(k1 > prev));
-                            if (NR > 2) cnt += (uint32_t)__popcll(__ballot(k2 > prev)) + (uint32_t)__popcll(__ballot(k3 > prev));
-                            ow |= cnt << (8 * kb);
-                            front = c;
                         }
+                        // c's own key is already p (> prev), every other key is unchanged:
+                        // position = (keys above prev) - 1 for the symbol itself.
+                        uint32_t cnt = (uint32_t)__popcll(__ballot(k0 > prev)) - 1u;
+                        if (NR > 1) cnt += (uint32_t)__popcll(__ballot(k1 > prev));
+                        if (NR > 2) cnt += (uint32_t)__popcll(__ballot(k2 > prev)) + (uint32_t)__popcll(__ballot(k3 > prev));
+                        ow |= cnt << (8 * kb);
                     }
                 }
                 if (d == 0) o0 = me ? (int)ow : o0;
@@ -208,6 +241,7 @@ __global__ void __launch_bounds__(64) mtf_walk(Batch bt, const int32_t *tlast, u
     if (base_p >= n) return;
     const int lane = threadIdx.x;
     __shared__ uint8_t names[256];
+    __shared__ int lkeys[256];
     __shared__ uint32_t ls[4];
     const uint32_t num_names = build_names(bt.hasbyte + (size_t)b * 256, names, ls);
     const int32_t *keys = tlast + ((size_t)b * MT + tile) * 256;
@@ -216,11 +250,11 @@ __global__ void __launch_bounds__(64) mtf_walk(Batch bt, const int32_t *tlast, u
     const uint32_t remain = n - base_p;
     const uint32_t tile_len = remain < MTF_TILE ? remain : MTF_TILE;
     if (num_names <= 64)
-        walk_tile<1>(s, o, keys, names, base_p, tile_len, lane);
+        walk_tile<1>(s, o, keys, names, lkeys, base_p, tile_len, lane);
     else if (num_names <= 128)
-        walk_tile<2>(s, o, keys, names, base_p, tile_len, lane);
+        walk_tile<2>(s, o, keys, names, lkeys, base_p, tile_len, lane);
     else
-        walk_tile<4>(s, o, keys, names, base_p, tile_len, lane);
+        walk_tile<4>(s, o, keys, names, lkeys, base_p, tile_len, lane);
 }
 
 // ---- RLE2 --------------------------------------------------------------------------------------------
