@@ -7,7 +7,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbzhip.so")
+# $BZH_LIB selects another build of the same library (A/B timing of kernel variants, scripts/ab.sh)
+LIB_PATH = os.environ.get("BZH_LIB") or os.path.join(_HERE, "libbzhip.so")
 
 u8p = ctypes.POINTER(ctypes.c_uint8)
 u16p = ctypes.POINTER(ctypes.c_uint16)

@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
     if (tile >= ntile) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    __shared__ uint32_t cur[NW][NB];  // per-wave cursors (tile-local positions)
+    __shared__ uint32_t cur[NW][NB];  // per-wave counters, then cursors (tile-local positions)
     __shared__ uint32_t binstart[NB]; // tile-local start of each digit's run
     __shared__ uint32_t goff[NB];     // global offset of this tile's run of each digit
     __shared__ u64 stage[SORT_TILE];  // tile in digit order
@@ -322,9 +322,40 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
         if (e < cnt && gen_elem<MODE, true>(a, b, e, n, v[k])) actmask |= 1u << k;
     }
     __syncthreads();
+    // Rank inside the wavefront, once: a step's 64 elements are grouped by digit with BITS ballots
+    // (match-any); every lane reads its digit's running count, the lowest lane of each group then
+    // adds the group size (LDS operations of one wavefront execute in order, so the next step sees
+    // it); wr = count before the step + lanes of the group below this one = the element's stable
+    // rank among the wavefront's elements with that digit.
+    uint32_t wr[SORT_ITEMS / 2]; // 16 bits each
 #pragma unroll
-    for (int k = 0; k < SORT_ITEMS; k++)
-        if (actmask & (1u << k)) atomicAdd(&cur[wave][(uint32_t)(v[k] >> a.shift) & (NB - 1)], 1u);
+    for (int k = 0; k < SORT_ITEMS / 2; k++) wr[k] = 0;
+#pragma unroll
+    for (int k = 0; k < SORT_ITEMS; k++) {
+        const bool act = (actmask >> k) & 1u;
+        const uint32_t d = (uint32_t)(v[k] >> a.shift) & (NB - 1);
+        // match-any: keep the lanes whose digit agrees with mine in every bit.  Inactive lanes are
+        // outside the initial mask, so their (arbitrary) digit bits need no masking in the ballots.
+        const u64 m0 = __ballot(act);
+        uint32_t mlo = (uint32_t)m0, mhi = (uint32_t)(m0 >> 32);
+#pragma unroll
+        for (int bit = 0; bit < BITS; bit++) {
+            const int om = ((int)(d << (31 - bit))) >> 31; // all ones if my digit has the bit
+            const u64 bm = __builtin_amdgcn_ballot_w64(om != 0);
+            mlo &= ~((uint32_t)bm ^ (uint32_t)om);
+            mhi &= ~((uint32_t)(bm >> 32) ^ (uint32_t)om);
+        }
+        if (act) {
+            const uint32_t before = cur[wave][d];
+            const uint32_t off = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+            if (off == 0) cur[wave][d] = before + (uint32_t)(__popc(mlo) + __popc(mhi));
+            wr[k >> 1] |= (before + off) << (16 * (k & 1));
+        }
+        // the next step's reads must follow this store in program order (another lane wrote the
+        // count I read next); the DS unit keeps one wavefront's operations in order, so a compiler
+        // barrier is all that is needed -- `volatile` would turn these into flat sc0 sc1 accesses
+        asm volatile("" ::: "memory");
+    }
     __syncthreads();
     // digit totals -> tile-local exclusive starts; cursors = start + counts of earlier waves
     uint32_t mytot = 0;
@@ -348,24 +379,12 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
         }
     }
     __syncthreads();
-    volatile uint32_t *mycur = cur[wave];
-    const u64 lt = (1ull << lane) - 1ull;
+    // placement: tile-local slot = start of (digit, wave) + rank inside the wave
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; k++) {
-        const bool act = (actmask >> k) & 1u;
-        const uint32_t d = (uint32_t)(v[k] >> a.shift) & (NB - 1);
-        u64 m = __ballot(act);
-#pragma unroll
-        for (int bit = 0; bit < BITS; bit++) {
-            const bool one = (d >> bit) & 1u;
-            const u64 bm = __ballot(act && one);
-            m &= one ? bm : ~bm;
-        }
-        if (act) {
-            const uint32_t basepos = mycur[d];
-            const uint32_t off = __popcll(m & lt);
-            if (off == 0) mycur[d] = basepos + __popcll(m); // lowest lane of the digit group advances
-            stage[basepos + off] = v[k];
+        if ((actmask >> k) & 1u) {
+            const uint32_t d = (uint32_t)(v[k] >> a.shift) & (NB - 1);
+            stage[cur[wave][d] + ((wr[k >> 1] >> (16 * (k & 1))) & 0xFFFFu)] = v[k];
         }
     }
     if (threadIdx.x < NB) { // look back for the counts of digit `bin` in tiles 0 .. tile-1
