@@ -44,6 +44,7 @@
 #include "common.h"
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 typedef unsigned long long u64;
 
@@ -1027,6 +1028,24 @@ __global__ void __launch_bounds__(256) bwt_emit(Batch bt, uint32_t T, uint32_t B
     if (seen[threadIdx.x]) bt.hasbyte[(size_t)b * 256 + threadIdx.x] = 1;
 }
 
+// Start of a round in one launch: the gates travel as kernel arguments (<= 2 x 256 words) and the
+// next round's counters are cleared -- instead of a memset plus a host-to-device copy, each of which
+// costs a launch-sized gap.
+constexpr uint32_t SETUP_MAX = 256;
+struct RoundSetup {
+    uint32_t gates[2 * SETUP_MAX]; // [0, mb): radix gates, [mb, 2 mb): tail gates
+};
+__global__ void __launch_bounds__(256) round_setup(RoundSetup rs, uint32_t *gateR, uint32_t *zero, uint32_t mb, uint32_t dtot_words,
+                                                   uint32_t *dtot)
+{
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < 2 * mb) {
+        gateR[t] = rs.gates[t]; // gateT follows gateR in memory
+        zero[t] = 0;
+    }
+    for (uint32_t k = t; k < dtot_words; k += gridDim.x * 256) dtot[k] = 0; // ACTIVE rounds: digit totals
+}
+
 // ---- host driver -----------------------------------------------------------------------------------
 // one radix pass = one kernel (look-back scatter)
 template <int BITS, int MODE, bool REKEY>
@@ -1267,11 +1286,20 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             nact_next = cnts[inew];
             inext = inew;
         }
-        HIP_TRY(ctx, hipMemsetAsync(nact_next, 0, 2 * mb * sizeof(uint32_t), st));
-        HIP_TRY(ctx, hipMemcpyAsync(bt.gateR, hgR, 2 * mb * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        // ACTIVE costs ~5 list passes over the unresolved suffixes, SWEEP a full SA sweep (hist +
-        // scatter) plus 3 passes: switch once the unresolved fraction is small; never switch back.
+        // ACTIVE costs ~5 list passes over the unresolved suffixes, SWEEP a full SA sweep plus 3
+        // passes: switch once the unresolved fraction is small; never switch back.
         if (!active_mode && nsum && sum * 3 < nsum) active_mode = true;
+        const bool active_round = maxact && active_mode;
+        if (mb <= SETUP_MAX) {
+            RoundSetup rs;
+            memcpy(rs.gates, hgR, 2 * mb * sizeof(uint32_t)); // hgT follows hgR in the pinned block
+            const uint32_t dw = active_round ? B * DB_STRIDE : 0u;
+            round_setup<<<dim3(active_round ? 64 : (2 * mb + 255) / 256), 256, 0, st>>>(rs, bt.gateR, nact_next, mb, dw, bt.dtot);
+        } else {
+            HIP_TRY(ctx, hipMemsetAsync(nact_next, 0, 2 * mb * sizeof(uint32_t), st));
+            HIP_TRY(ctx, hipMemcpyAsync(bt.gateR, hgR, 2 * mb * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            if (active_round) HIP_TRY(ctx, hipMemsetAsync(bt.dtot, 0, (size_t)B * DB_STRIDE * sizeof(uint32_t), st));
+        }
 
         a.h = h;
         a.recrank = round > 0; // every refine after the initial one writes ranks back into the list
@@ -1307,7 +1335,6 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             // re-key once (active_gen), then five look-back passes on bits 20..59; the list ends in `cur`
             {
                 const uint32_t gt = (prevmax + SORT_TILE - 1) / SORT_TILE;
-                HIP_TRY(ctx, hipMemsetAsync(bt.dtot, 0, (size_t)B * DB_STRIDE * sizeof(uint32_t), st));
                 a.cnt = prevcnt;
                 a.src = cur;
                 a.dst = oth;
