@@ -28,6 +28,10 @@ class Block(ctypes.Structure):
                 ("crc", ctypes.c_uint32)]
 
 
+_BLOCK_DTYPE = np.dtype([("in_off", "<u8"), ("in_len", "<u8"), ("rle_len", "<u4"), ("crc", "<u4")])
+assert _BLOCK_DTYPE.itemsize == ctypes.sizeof(Block)
+
+
 class Stats(ctypes.Structure):
     _fields_ = [(k, ctypes.c_double) for k in
                 ("ms_plan", "ms_rle1", "ms_bwt", "ms_mtf", "ms_huff", "ms_pack", "ms_total", "ms_bwt_sort")] + \
@@ -263,8 +267,9 @@ class Context:
         self.check(lib().bzh_plan_device(self._h, ctypes.c_void_p(d_in), n, ctypes.byref(nb)))
         blocks = (Block * max(1, nb.value))()
         self.check(lib().bzh_plan_blocks(self._h, blocks, max(1, nb.value)))
-        return [(int(blocks[k].in_off), int(blocks[k].in_len), int(blocks[k].rle_len), int(blocks[k].crc))
-                for k in range(nb.value)]
+        # one numpy view instead of 4 ctypes field reads per block (≈ 1 ms per 1000 blocks otherwise)
+        arr = np.frombuffer(blocks, dtype=_BLOCK_DTYPE, count=nb.value)
+        return list(zip(arr["in_off"].tolist(), arr["in_len"].tolist(), arr["rle_len"].tolist(), arr["crc"].tolist()))
 
     def encode_range_device(self, b0, b1, d_out, cap):
         nbits = ctypes.c_uint64(0)

@@ -32,13 +32,17 @@ def encode_sharded(engine, dist=None, rank=0, world=1):
     if world == 1:
         return engine.assemble([(part, nbits)], [b[3] for b in blocks])
     bits = torch.tensor([nbits], dtype=torch.int64, device=part.device)
-    all_bits = [torch.zeros_like(bits) for _ in range(world)]
-    dist.all_gather(all_bits, bits)
-    slabs = [torch.empty_like(part) for _ in range(world)] if rank == 0 else None
-    dist.gather(part, slabs, dst=0)  # encoded blocks -> rank 0 (RCCL over xGMI on a GPU node)
+    all_bits = torch.zeros(world, dtype=torch.int64, device=part.device)
+    dist.all_gather_into_tensor(all_bits, bits)
+    nb = all_bits.tolist()  # one read-back for all ranks' lengths
+    # gather only as many bytes as the longest bit string needs (whole 32-bit words), not the slab capacity
+    used = min(engine.cap, (max(nb) + 31) // 32 * 4)
+    send = part[:used]
+    slabs = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+    dist.gather(send, slabs, dst=0)  # encoded blocks -> rank 0 (RCCL over xGMI on a GPU node)
     if rank != 0:
         return 0
-    segs = [(slabs[k], int(all_bits[k].item())) for k in range(world)]
+    segs = [(slabs[k], nb[k]) for k in range(world)]
     return engine.assemble(segs, [b[3] for b in blocks])
 
 
