@@ -297,7 +297,7 @@ class Context:
     def stream_feed(self, data, eof=False):
         """-> stream bytes that became final with this feed"""
         n = len(data)
-        a = np.frombuffer(bytes(data), dtype=np.uint8) if n else np.zeros(1, np.uint8)
+        a = np.frombuffer(data, dtype=np.uint8) if n else np.zeros(1, np.uint8)  # zero-copy view of any buffer
         need = int(lib().bzh_stream_bound(self._h, n))
         if self._sbuf is None or self._sbuf.size < need:
             self._sbuf = np.empty(need, dtype=np.uint8)

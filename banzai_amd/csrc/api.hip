@@ -14,6 +14,8 @@
 
 #include "common.h"
 
+static void stream_join(bzh_ctx *ctx); // waits for a streaming pass in flight (defined with bzh_stream_*)
+
 void bzh_set_error(bzh_ctx *ctx, const char *fmt, ...)
 {
     if (!ctx) return;
@@ -125,7 +127,10 @@ extern "C" int bzh_create(bzh_ctx **out, int device, int level, int max_batch)
     ctx->device = device;
     ctx->level = level;
     ctx->M = 100000u * (uint32_t)level - 1u; // lib/rle.rs:121
-    ctx->max_batch = max_batch ? (uint32_t)max_batch : 128u;
+    // default: a batch covers about 115 MB of RLE1 output at every level (128 level-9 blocks)
+    ctx->max_batch = max_batch ? (uint32_t)max_batch : std::min<uint32_t>(1024u, 128u * 9u / (uint32_t)level);
+    // a streaming pass is worth launching once a full batch of input is pending
+    ctx->strm.min_feed = std::min<size_t>((size_t)128 << 20, (size_t)ctx->max_batch * (ctx->M + 1));
     Batch probe{}, probe2{};
     ctx->arena_size = layout_batch(probe, nullptr, ctx->max_batch, ctx->M);
     // the same memory also serves as two half-batch arenas (lanes, see ensure_lanes)
@@ -167,13 +172,17 @@ extern "C" void bzh_destroy(bzh_ctx *ctx)
     if (ctx->d_stage_out) hipFree(ctx->d_stage_out);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
     if (ctx->d_crctab) hipFree(ctx->d_crctab);
+    if (ctx->strm.worker.joinable()) ctx->strm.worker.join();
     for (int k = 0; k < 2; k++)
         if (ctx->strm.d_buf[k]) hipFree(ctx->strm.d_buf[k]);
+    if (ctx->strm.h_out) hipHostFree(ctx->strm.h_out);
+    if (ctx->strm.copy_stream) hipStreamDestroy(ctx->strm.copy_stream);
     delete ctx;
 }
 
 extern "C" int bzh_set_stream(bzh_ctx *ctx, void *hip_stream)
 {
+    if (ctx) stream_join(ctx);
     if (!ctx) return BZH_E_ARG;
     ctx->stream = (hipStream_t)hip_stream;
     return BZH_OK;
@@ -181,6 +190,7 @@ extern "C" int bzh_set_stream(bzh_ctx *ctx, void *hip_stream)
 
 extern "C" int bzh_set_lanes(bzh_ctx *ctx, int lanes)
 {
+    if (ctx) stream_join(ctx);
     if (!ctx || (lanes != 1 && lanes != 2)) return BZH_E_ARG;
     ctx->nlanes = lanes;
     return BZH_OK;
@@ -236,6 +246,7 @@ static int ensure_stage(bzh_ctx *ctx, uint8_t *&buf, size_t &cur, size_t need)
 extern "C" int bzh_bwt_batch(bzh_ctx *ctx, const uint8_t *in, const uint64_t *offs, const uint32_t *lens,
                              size_t nblk, uint8_t *bwt_out, uint32_t *ptr, uint8_t *has_byte)
 {
+    if (ctx) stream_join(ctx);
     if (!ctx || !in || !offs || !lens || !bwt_out || !ptr || !has_byte) return BZH_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     stats_begin(ctx);
@@ -272,6 +283,7 @@ extern "C" int bzh_bwt_batch(bzh_ctx *ctx, const uint8_t *in, const uint64_t *of
 extern "C" int bzh_bwt(bzh_ctx *ctx, const uint8_t *in, size_t n, uint8_t *bwt_out, uint32_t *ptr,
                        uint8_t *has_byte)
 {
+    if (ctx) stream_join(ctx);
     if (!ctx || !ptr || !has_byte) return BZH_E_ARG;
     if (n == 0) { // lib/bwt.rs:535-541
         memset(has_byte, 0, 256);
@@ -288,6 +300,7 @@ extern "C" int bzh_bwt(bzh_ctx *ctx, const uint8_t *in, size_t n, uint8_t *bwt_o
 extern "C" int bzh_mtf(bzh_ctx *ctx, const uint8_t *bwt, size_t n, const uint8_t *has_byte, uint16_t *syms,
                        size_t *m, uint32_t *freqs, uint32_t *num_syms)
 {
+    if (ctx) stream_join(ctx);
     if (!ctx || !bwt || !has_byte || !syms || !m || !freqs || !num_syms || n == 0 || n > ctx->M) return BZH_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     stats_begin(ctx);
@@ -321,6 +334,7 @@ extern "C" int bzh_huffman(bzh_ctx *ctx, const uint16_t *syms, size_t m, uint32_
                            uint8_t *bits_out, size_t cap, uint64_t *nbits, uint8_t *code_lengths,
                            uint32_t *num_tables)
 {
+    if (ctx) stream_join(ctx);
     if (!ctx || !syms || !freqs || !bits_out || !nbits || m == 0 || m > (size_t)ctx->M + 1 || num_syms < 3 ||
         num_syms > 258)
         return BZH_E_ARG;
@@ -654,6 +668,7 @@ static int check_in_ptr(bzh_ctx *ctx, const void *d_in)
 
 extern "C" int bzh_plan_device(bzh_ctx *ctx, const void *d_in, size_t n, size_t *nblocks)
 {
+    if (ctx) stream_join(ctx);
     if (!ctx || (!d_in && n) || !nblocks) return BZH_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     BZH_TRY(check_in_ptr(ctx, d_in));
@@ -686,6 +701,7 @@ extern "C" int bzh_plan_blocks(const bzh_ctx *ctx, bzh_block *out, size_t max_bl
 extern "C" int bzh_encode_range_device(bzh_ctx *ctx, size_t b0, size_t b1, void *d_out, size_t cap,
                                        uint64_t *nbits)
 {
+    if (ctx) stream_join(ctx);
     if (!ctx || !d_out || !nbits || b0 > b1) return BZH_E_ARG;
     if (b1 > ctx->plan_blocks.size()) return BZH_E_STATE;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -703,6 +719,7 @@ extern "C" int bzh_assemble_device(bzh_ctx *ctx, const void *const *d_segs, cons
                                    const uint32_t *block_crcs, size_t nblocks, void *d_out, size_t cap,
                                    size_t *out_len)
 {
+    if (ctx) stream_join(ctx);
     if (!ctx || !d_out || !out_len || (nseg && (!d_segs || !seg_bits)) || (nblocks && !block_crcs)) return BZH_E_ARG;
     if (((uintptr_t)d_out & 3u) != 0) return BZH_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -733,6 +750,7 @@ extern "C" int bzh_assemble_device(bzh_ctx *ctx, const void *const *d_segs, cons
 extern "C" int bzh_encode_device(bzh_ctx *ctx, const void *d_in, size_t n, void *d_out, size_t cap, size_t *out_len,
                                  size_t *consumed)
 {
+    if (ctx) stream_join(ctx);
     if (!ctx || (!d_in && n) || !d_out || !out_len) return BZH_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -788,6 +806,7 @@ extern "C" int bzh_encode_device(bzh_ctx *ctx, const void *d_in, size_t n, void 
 extern "C" int bzh_encode(bzh_ctx *ctx, const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len,
                           size_t *consumed)
 {
+    if (ctx) stream_join(ctx);
     if (!ctx || (!in && n) || !out || !out_len) return BZH_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -809,6 +828,7 @@ extern "C" int bzh_encode(bzh_ctx *ctx, const uint8_t *in, size_t n, uint8_t *ou
 extern "C" int bzh_rle1_split(bzh_ctx *ctx, const uint8_t *in, size_t n, bzh_block *blocks, size_t max_blocks,
                               size_t *nblocks, uint8_t *rle_out, size_t rle_cap)
 {
+    if (ctx) stream_join(ctx);
     if (!ctx || (!in && n) || !blocks || !nblocks) return BZH_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -840,6 +860,7 @@ extern "C" int bzh_rle1_split(bzh_ctx *ctx, const uint8_t *in, size_t n, bzh_blo
 
 extern "C" int bzh_crc32(bzh_ctx *ctx, const uint8_t *in, size_t n, uint32_t *crc)
 {
+    if (ctx) stream_join(ctx);
     if (!ctx || (!in && n) || !crc) return BZH_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     BZH_TRY(ensure_stage(ctx, ctx->d_stage_in, ctx->stage_in_size, n + 16));
@@ -852,15 +873,32 @@ extern "C" int bzh_crc32(bzh_ctx *ctx, const uint8_t *in, size_t n, uint32_t *cr
 // Streaming
 // ================================================================================================
 
+static inline void put_be32(uint8_t *p, uint32_t v)
+{
+    p[0] = (uint8_t)(v >> 24);
+    p[1] = (uint8_t)(v >> 16);
+    p[2] = (uint8_t)(v >> 8);
+    p[3] = (uint8_t)v;
+}
+
+// Waits for the pass in flight (if any); its results stay in strm.pass until stream_collect.
+static void stream_join(bzh_ctx *ctx)
+{
+    auto &s = ctx->strm;
+    if (s.worker.joinable()) s.worker.join();
+}
+
 extern "C" int bzh_stream_begin(bzh_ctx *ctx)
 {
     if (!ctx) return BZH_E_ARG;
     auto &s = ctx->strm;
+    stream_join(ctx);
+    s.inflight = false;
     s.active = true;
     s.header_done = false;
-    s.pend.clear();
-    s.cur = 0;
-    s.carry = 0;
+    s.pending = 0;
+    s.fill = 0;
+    s.head = 0;
     s.bitpos = 0;
     s.carry_word = 0;
     s.stream_crc = 0;
@@ -871,9 +909,11 @@ extern "C" int bzh_stream_begin(bzh_ctx *ctx)
 extern "C" size_t bzh_stream_bound(const bzh_ctx *ctx, size_t n)
 {
     if (!ctx) return 0;
-    // everything pending may be released by this call: carried raw bytes (< 52 MB: one block of a
-    // maximal run) + what was held back below STREAM_MIN_FEED + n, at worst-case expansion, plus framing
-    const size_t raw = n + ctx->strm.min_feed + ((size_t)52 << 20);
+    // everything not yet handed out may be released by this call: the pass in flight, the bytes waiting
+    // for the next pass, n, and a carried tail (< 52 MB: one block of a maximal run), at worst-case
+    // expansion, plus framing
+    const auto &s = ctx->strm;
+    const size_t raw = n + s.pending + (s.inflight ? s.pass.total : 0) + ((size_t)52 << 20);
     return raw + raw / 4 + (raw / 70000 + 4) * 4096 + 65536;
 }
 
@@ -886,12 +926,95 @@ extern "C" int bzh_stream_set_chunk(bzh_ctx *ctx, size_t bytes)
     return BZH_OK;
 }
 
-static inline void put_be32(uint8_t *p, uint32_t v)
+// Headroom kept in front of the fed bytes for the tail a pass leaves unconsumed (normally well below
+// one block of raw input; larger tails -- a block inside one enormous run -- regrow the buffer).
+static const size_t STREAM_HEAD = (size_t)4 << 20;
+
+// Makes d_buf[fill] hold `head` bytes of headroom + the pending bytes + `extra` more, keeping the
+// pending bytes.
+static int stream_reserve(bzh_ctx *ctx, size_t head, size_t extra)
 {
-    p[0] = (uint8_t)(v >> 24);
-    p[1] = (uint8_t)(v >> 16);
-    p[2] = (uint8_t)(v >> 8);
-    p[3] = (uint8_t)v;
+    auto &s = ctx->strm;
+    const int f = s.fill;
+    if (s.d_buf[f] && head <= s.head && s.head + s.pending + extra + 16 <= s.cap[f]) return BZH_OK;
+    const size_t nhead = align_up(std::max(head, std::max(s.head, STREAM_HEAD)), 4096);
+    const size_t want = align_up(nhead + std::max(s.pending + extra, s.min_feed) + ((size_t)16 << 20), 4096);
+    uint8_t *nb = nullptr;
+    if (hipMalloc((void **)&nb, want) != hipSuccess) {
+        bzh_set_error(ctx, "hipMalloc(%zu) failed", want);
+        return BZH_E_NOMEM;
+    }
+    if (s.pending) HIP_TRY(ctx, hipMemcpyAsync(nb + nhead, s.d_buf[f] + s.head, s.pending, hipMemcpyDeviceToDevice, s.copy_stream));
+    HIP_TRY(ctx, hipStreamSynchronize(s.copy_stream));
+    if (s.d_buf[f]) hipFree(s.d_buf[f]);
+    s.d_buf[f] = nb;
+    s.cap[f] = want;
+    s.head = nhead;
+    return BZH_OK;
+}
+
+// The pass in flight, on its own thread: split, encode the blocks whose cut cannot move any more,
+// bring their bits to pinned host memory.  Touches the context's plan / batch state and ctx->stream
+// only; the feeding thread meanwhile uses the other buffer and the copy stream.
+static void stream_pass(bzh_ctx *ctx)
+{
+    auto &s = ctx->strm;
+    auto &p = s.pass;
+    p.used = 0;
+    p.nbits = 0;
+    p.out_bytes = 0;
+    p.lastw = 0;
+    p.crcs.clear();
+    p.rc = [&]() -> int {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        const uint8_t *buf = s.d_buf[p.buf] + p.off;
+        BZH_TRY(rle1_plan(ctx, buf, p.total));
+        const size_t nb = ctx->plan_blocks.size();
+        size_t F = nb; // blocks that are final
+        if (!p.eof) {
+            F = 0;
+            while (F < nb && !ctx->plan_open[F]) F++;
+        }
+        if (F == 0) return BZH_OK;
+        p.used = F == nb ? p.total : (size_t)ctx->plan_blocks[F].in_off;
+        size_t raw = 0;
+        for (size_t k = 0; k < F; k++) raw += ctx->plan_blocks[k].in_len;
+        const size_t dcap = (raw + raw / 4 + (F + 2) * 4096 + 65536) & ~(size_t)3;
+        BZH_TRY(ensure_stage(ctx, ctx->d_stage_out, ctx->stage_out_size, dcap));
+        uint8_t seed_be[4];
+        put_be32(seed_be, p.seed);
+        uint32_t seed;
+        memcpy(&seed, seed_be, 4);
+        memset(&ctx->stats, 0, sizeof ctx->stats);
+        ctx->sort_spans.clear();
+        ctx->evnext = 0;
+        BZH_TRY(encode_range(ctx, 0, F, ctx->d_stage_out, ctx->stage_out_size & ~(size_t)3, p.phase, &p.nbits,
+                             p.phase ? &seed : nullptr));
+        const uint64_t bits_in_buf = p.phase + p.nbits;
+        const size_t full_words = (size_t)(bits_in_buf / 32);
+        if (full_words * 4 + 8 > s.h_out_cap) {
+            if (s.h_out) hipHostFree(s.h_out);
+            s.h_out = nullptr;
+            s.h_out_cap = 0;
+            const size_t want = align_up(full_words * 4 + full_words / 2 + 4096, 4096);
+            if (hipHostMalloc((void **)&s.h_out, want) != hipSuccess) {
+                bzh_set_error(ctx, "hipHostMalloc(%zu) failed", want);
+                return BZH_E_NOMEM;
+            }
+            s.h_out_cap = want;
+        }
+        const size_t nbytes = full_words * 4 + ((bits_in_buf & 31u) ? 4 : 0);
+        if (nbytes) HIP_TRY(ctx, hipMemcpyAsync(s.h_out, ctx->d_stage_out, nbytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        p.out_bytes = full_words * 4;
+        if (bits_in_buf & 31u) {
+            const uint8_t *w = s.h_out + full_words * 4;
+            p.lastw = ((uint32_t)w[0] << 24) | ((uint32_t)w[1] << 16) | ((uint32_t)w[2] << 8) | w[3];
+        }
+        for (size_t k = 0; k < F; k++) p.crcs.push_back(ctx->plan_blocks[k].crc);
+        return BZH_OK;
+    }();
 }
 
 extern "C" int bzh_stream_feed(bzh_ctx *ctx, const uint8_t *in, size_t n, int eof, uint8_t *out, size_t cap,
@@ -914,15 +1037,22 @@ extern "C" int bzh_stream_feed(bzh_ctx *ctx, const uint8_t *in, size_t n, int eo
         *out_len = produced;
         return BZH_OK;
     }
+    if (cap < bzh_stream_bound(ctx, n)) return BZH_E_CAP; // before anything is consumed: the call can be repeated
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
-    s.pend.insert(s.pend.end(), in, in + n);
-    if (!eof && s.pend.size() < s.min_feed) return BZH_OK;
+    if (!s.copy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&s.copy_stream, hipStreamNonBlocking));
+
+    // 1. the fed bytes go straight to the device, behind what is already waiting there; this runs
+    //    while the previous pass (if any) is still encoding
+    if (n) {
+        BZH_TRY(stream_reserve(ctx, s.head, n));
+        HIP_TRY(ctx, hipMemcpyAsync(s.d_buf[s.fill] + s.head + s.pending, in, n, hipMemcpyHostToDevice, s.copy_stream));
+        HIP_TRY(ctx, hipStreamSynchronize(s.copy_stream)); // `in` belongs to the caller again on return
+        s.pending += n;
+    }
+    if (!eof && s.pending < s.min_feed) return BZH_OK;
 
     size_t opos = 0;
-    auto need_cap = [&](size_t more) { return opos + more <= cap; };
     if (!s.header_done) { // lib/lib.rs:18-22
-        if (!need_cap(4)) return BZH_E_CAP;
         out[0] = 0x42;
         out[1] = 0x5A;
         out[2] = 0x68;
@@ -931,107 +1061,73 @@ extern "C" int bzh_stream_feed(bzh_ctx *ctx, const uint8_t *in, size_t n, int eo
         s.bitpos = 32;
         s.header_done = true;
     }
+    // 2. take the results of the pass in flight: its bits are final now
+    size_t left = 0;
+    const uint8_t *tail = nullptr;
+    auto collect = [&]() -> int {
+        stream_join(ctx);
+        s.inflight = false;
+        const auto &p = s.pass;
+        if (p.rc != BZH_OK) {
+            s.active = false;
+            return p.rc;
+        }
+        memcpy(out + opos, s.h_out, p.out_bytes);
+        opos += p.out_bytes;
+        if (p.nbits) {
+            s.carry_word = p.lastw;
+            s.bitpos += p.nbits;
+        }
+        for (uint32_t c : p.crcs) s.stream_crc = c ^ ((s.stream_crc << 1) | (s.stream_crc >> 31)); // lib/lib.rs:107-108
+        s.consumed += p.used;
+        left = p.total - p.used;
+        tail = s.d_buf[p.buf] + p.off + p.used;
+        return BZH_OK;
+    };
+    if (s.inflight) BZH_TRY(collect());
 
-    const size_t total = s.carry + s.pend.size();
-    if (total > 0) {
-        // carried bytes already sit at the start of d_buf[cur]; append the pending ones
-        if (total + 16 > s.cap[s.cur]) {
-            uint8_t *nb = nullptr;
-            const size_t want = align_up(total + total / 4 + (1 << 20), 4096);
-            if (hipMalloc((void **)&nb, want) != hipSuccess) {
-                bzh_set_error(ctx, "hipMalloc(%zu) failed", want);
-                return BZH_E_NOMEM;
-            }
-            if (s.carry) HIP_TRY(ctx, hipMemcpyAsync(nb, s.d_buf[s.cur], s.carry, hipMemcpyDeviceToDevice, st));
-            HIP_TRY(ctx, hipStreamSynchronize(st));
-            if (s.d_buf[s.cur]) hipFree(s.d_buf[s.cur]);
-            s.d_buf[s.cur] = nb;
-            s.cap[s.cur] = want;
-        }
-        uint8_t *buf = s.d_buf[s.cur];
-        if (!s.pend.empty())
-            HIP_TRY(ctx, hipMemcpyAsync(buf + s.carry, s.pend.data(), s.pend.size(), hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));
-        s.pend.clear();
-
-        BZH_TRY(rle1_plan(ctx, buf, total));
-        const size_t nb = ctx->plan_blocks.size();
-        size_t F = nb; // blocks that are final
-        if (!eof) {
-            F = 0;
-            while (F < nb && !ctx->plan_open[F]) F++;
-        }
-        size_t used = 0;
-        if (F > 0) {
-            used = F == nb ? total : (size_t)ctx->plan_blocks[F].in_off;
-            size_t raw = 0;
-            for (size_t k = 0; k < F; k++) raw += ctx->plan_blocks[k].in_len;
-            const size_t dcap = (raw + raw / 4 + (F + 2) * 4096 + 65536) & ~(size_t)3;
-            BZH_TRY(ensure_stage(ctx, ctx->d_stage_out, ctx->stage_out_size, dcap));
-            const uint32_t phase = (uint32_t)(s.bitpos & 31u);
-            uint8_t seed_be[4];
-            put_be32(seed_be, s.carry_word);
-            uint32_t seed;
-            memcpy(&seed, seed_be, 4);
-            uint64_t nbits = 0;
-            memset(&ctx->stats, 0, sizeof ctx->stats);
-            ctx->sort_spans.clear();
-            ctx->evnext = 0;
-            BZH_TRY(encode_range(ctx, 0, F, ctx->d_stage_out, ctx->stage_out_size & ~(size_t)3, phase, &nbits,
-                                 phase ? &seed : nullptr));
-            const uint64_t bits_in_buf = phase + nbits;
-            const size_t full_words = (size_t)(bits_in_buf / 32);
-            if (!need_cap(full_words * 4)) return BZH_E_CAP;
-            if (full_words)
-                HIP_TRY(ctx, hipMemcpyAsync(out + opos, ctx->d_stage_out, full_words * 4, hipMemcpyDeviceToHost, st));
-            uint8_t lastw[4] = {0, 0, 0, 0};
-            if (bits_in_buf & 31u)
-                HIP_TRY(ctx, hipMemcpyAsync(lastw, ctx->d_stage_out + full_words * 4, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(ctx, hipStreamSynchronize(st));
-            opos += full_words * 4;
-            s.carry_word = ((uint32_t)lastw[0] << 24) | ((uint32_t)lastw[1] << 16) | ((uint32_t)lastw[2] << 8) | lastw[3];
-            s.bitpos += nbits;
-            for (size_t k = 0; k < F; k++) // lib/lib.rs:107-108
-                s.stream_crc = ctx->plan_blocks[k].crc ^ ((s.stream_crc << 1) | (s.stream_crc >> 31));
-            s.consumed += used;
-        }
-        // carry the unconsumed tail to the other buffer (no overlapping copy)
-        const size_t left = total - used;
-        const int other = s.cur ^ 1;
+    // 3. start the next pass on [tail of the previous pass | fed bytes]
+    for (;;) {
+        const size_t total = left + s.pending;
+        if (total == 0) break;
+        BZH_TRY(stream_reserve(ctx, left, 0));
         if (left) {
-            if (left + 16 > s.cap[other]) {
-                if (s.d_buf[other]) hipFree(s.d_buf[other]);
-                s.d_buf[other] = nullptr;
-                s.cap[other] = 0;
-                const size_t want = align_up(left + s.min_feed + (1 << 20), 4096);
-                if (hipMalloc((void **)&s.d_buf[other], want) != hipSuccess) {
-                    bzh_set_error(ctx, "hipMalloc(%zu) failed", want);
-                    return BZH_E_NOMEM;
-                }
-                s.cap[other] = want;
-            }
-            HIP_TRY(ctx, hipMemcpyAsync(s.d_buf[other], buf + used, left, hipMemcpyDeviceToDevice, st));
-            HIP_TRY(ctx, hipStreamSynchronize(st));
-            s.cur = other;
+            HIP_TRY(ctx, hipMemcpyAsync(s.d_buf[s.fill] + s.head - left, tail, left, hipMemcpyDeviceToDevice, s.copy_stream));
+            HIP_TRY(ctx, hipStreamSynchronize(s.copy_stream));
         }
-        s.carry = left;
+        auto &p = s.pass;
+        p.buf = s.fill;
+        p.off = s.head - left;
+        p.total = total;
+        p.eof = eof != 0;
+        p.phase = (uint32_t)(s.bitpos & 31u);
+        p.seed = s.carry_word;
+        s.inflight = true;
+        s.worker = std::thread(stream_pass, ctx);
+        s.fill ^= 1; // the other buffer is free: its pass was collected above, its tail copied
+        s.head = STREAM_HEAD;
+        s.pending = 0;
+        if (!eof) break;
+        // 4. end of input: wait for this last pass too (it consumes everything it was given)
+        left = 0;
+        BZH_TRY(collect());
+        if (left == 0) break; // always, at eof; the loop guards against a pass that could not finish its tail
     }
 
     if (eof) { // footer + stream CRC (lib/lib.rs:66-70), zero padding to a byte (lib/out.rs:22-28)
         const uint32_t phase = (uint32_t)(s.bitpos & 31u);
-        uint8_t tail[24];
-        memset(tail, 0, sizeof tail);
-        put_be32(tail, phase ? s.carry_word : 0u);
+        uint8_t tailb[24];
+        memset(tailb, 0, sizeof tailb);
+        put_be32(tailb, phase ? s.carry_word : 0u);
         const uint8_t foot[10] = {0x17, 0x72, 0x45, 0x38, 0x50, 0x90, (uint8_t)(s.stream_crc >> 24),
                                   (uint8_t)(s.stream_crc >> 16), (uint8_t)(s.stream_crc >> 8), (uint8_t)s.stream_crc};
         for (uint32_t k = 0; k < 80; k++) {
             const uint32_t bit = (foot[k >> 3] >> (7 - (k & 7))) & 1u;
             const uint32_t pos = phase + k;
-            tail[pos >> 3] |= (uint8_t)(bit << (7 - (pos & 7)));
+            tailb[pos >> 3] |= (uint8_t)(bit << (7 - (pos & 7)));
         }
         const size_t nbytes = (phase + 80 + 7) / 8;
-        if (!need_cap(nbytes)) return BZH_E_CAP;
-        memcpy(out + opos, tail, nbytes);
+        memcpy(out + opos, tailb, nbytes);
         opos += nbytes;
         s.bitpos += 80;
         s.active = false;
@@ -1040,6 +1136,7 @@ extern "C" int bzh_stream_feed(bzh_ctx *ctx, const uint8_t *in, size_t n, int eo
             s.d_buf[k] = nullptr;
             s.cap[k] = 0;
         }
+        s.head = 0;
     }
     *out_len = opos;
     return BZH_OK;

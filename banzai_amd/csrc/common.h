@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <thread>
 #include <vector>
 
 #include "../../include/bzhip.h"
@@ -138,16 +139,38 @@ struct bzh_ctx {
     // streaming encode (bzh_stream_*)
     struct Stream {
         bool active = false, header_done = false;
-        std::vector<uint8_t> pend;      // host bytes not yet sent to the GPU
+        // Two device buffers.  d_buf[fill] receives the fed bytes from offset `head` on (copy stream);
+        // when a pass starts, the unconsumed tail of the previous pass is placed right before `head`,
+        // so the pass sees one contiguous range.  The previous pass's buffer is free again by then.
         uint8_t *d_buf[2] = {nullptr, nullptr};
         size_t cap[2] = {0, 0};
-        int cur = 0;
-        size_t carry = 0;               // bytes at the start of d_buf[cur] not yet encoded
-        uint64_t bitpos = 0;            // stream bits produced so far
+        int fill = 0;
+        size_t head = 0;                // offset of the first fed byte in d_buf[fill]
+        size_t pending = 0;             // fed bytes waiting in d_buf[fill]
+        uint64_t bitpos = 0;            // stream bits handed out or in `carry_word`
         uint32_t carry_word = 0;        // the bitpos % 32 bits not yet handed out (big-endian word)
         uint32_t stream_crc = 0;
         size_t consumed = 0;
         size_t min_feed = (size_t)32 << 20; // pending bytes that trigger a GPU pass
+        hipStream_t copy_stream = nullptr;  // H2D of fed bytes, concurrent with the pass in flight
+        // the pass in flight (worker thread): plan + encode + D2H of its final blocks
+        std::thread worker;
+        bool inflight = false;
+        struct Pass {
+            int buf = 0;                // which d_buf
+            size_t off = 0, total = 0;  // input range of the pass
+            bool eof = false;
+            uint32_t phase = 0, seed = 0; // bit phase / carried bits at the start of the pass
+            // results
+            int rc = 0;
+            size_t used = 0;            // input bytes consumed by the final blocks
+            uint64_t nbits = 0;
+            size_t out_bytes = 0;       // whole words copied to h_out
+            uint32_t lastw = 0;         // the partial word after them (big-endian value)
+            std::vector<uint32_t> crcs; // CRCs of the final blocks, in order
+        } pass;
+        uint8_t *h_out = nullptr;       // pinned staging of a pass's output
+        size_t h_out_cap = 0;
     } strm;
     bzh_stats stats{};
     std::vector<hipEvent_t> evpool;

@@ -98,15 +98,22 @@ BZH_API int bzh_encode_device(bzh_ctx *ctx, const void *d_in, size_t n, void *d_
 BZH_API int bzh_stream_begin(bzh_ctx *ctx);
 
 /* Feeds n more input bytes; eof != 0 marks the end of the input (n may be 0) and completes the
- * stream.  Writes the stream bytes that became final to out (cap >= bzh_stream_bound(ctx, n));
- * *out_len receives their count.  BZH_E_CAP leaves the stream unusable. */
+ * stream.  Writes the stream bytes that became final to out; *out_len receives their count.
+ * The bytes are copied to the GPU at once (`in` may be reused on return).  Once a full batch is
+ * pending, a pass (split + encode + copy back) starts on an internal thread and the call returns;
+ * its bytes are handed out by the next call that starts a pass, or by the eof call -- so the
+ * caller's reading and copying of the next chunks overlaps with the GPU.
+ * cap must be >= bzh_stream_bound(ctx, n) evaluated right before the call; BZH_E_CAP is returned
+ * before anything is consumed (the call can be repeated with a larger buffer). */
 BZH_API int bzh_stream_feed(bzh_ctx *ctx, const uint8_t *in, size_t n, int eof, uint8_t *out, size_t cap,
                             size_t *out_len);
 
-/* Upper bound of the bytes one bzh_stream_feed(…, n, …) call can return. */
+/* Upper bound of the bytes the next bzh_stream_feed(…, n, …) call can return (depends on what is
+ * pending and in flight, so ask before every call). */
 BZH_API size_t bzh_stream_bound(const bzh_ctx *ctx, size_t n);
 
-/* Pending input that triggers a GPU pass (default 32 MiB; smaller = lower latency, more launches). */
+/* Pending input that triggers a GPU pass (default: one full batch, max_batch blocks of raw input, at most
+ * 128 MiB; smaller = lower latency and less buffering, but more and smaller launches). */
 BZH_API int bzh_stream_set_chunk(bzh_ctx *ctx, size_t bytes);
 
 /* Input bytes encoded so far (after the eof feed: the total, encode()'s return value). */
