@@ -372,6 +372,31 @@ def test_streaming_equals_one_shot(oracle, ctx1):
     assert b"".join(pieces) == oracle.encode(d, 1)
 
 
+def test_streaming_small_buffer_is_refused_before_anything_is_consumed(native, oracle, ctx1):
+    """BZH_E_CAP comes back before the feed is taken: the same feed can be repeated with a buffer of
+    bzh_stream_bound() bytes, and the stream is the one-shot stream (passes overlap with feeding, so
+    the bound depends on what is pending and in flight)"""
+    import ctypes
+    lib = native.lib()
+    d = cases.gen(900_000, "text", 8)
+    ctx1.stream_begin(200_000)
+    out = bytearray()
+    got = ctypes.c_size_t(0)
+    small = np.zeros(16, np.uint8)
+    for k in range(0, len(d) + 1, 300_000):
+        piece = np.frombuffer(d[k:k + 300_000], dtype=np.uint8) if k < len(d) else np.zeros(1, np.uint8)
+        n = min(300_000, len(d) - k) if k < len(d) else 0
+        eof = 1 if k + 300_000 >= len(d) else 0
+        assert lib.bzh_stream_feed(ctx1.handle, native.ptr(piece), n, eof, native.ptr(small), small.size,
+                                   ctypes.byref(got)) == -4  # BZH_E_CAP, nothing consumed
+        buf = np.zeros(int(lib.bzh_stream_bound(ctx1.handle, n)), np.uint8)
+        ctx1.check(lib.bzh_stream_feed(ctx1.handle, native.ptr(piece), n, eof, native.ptr(buf), buf.size, ctypes.byref(got)))
+        out += buf[:got.value].tobytes()
+        if eof:
+            break
+    assert bytes(out) == oracle.encode(d, 1)
+
+
 def test_streaming_public_api_chunked_reader(oracle):
     import banzai_amd
 
