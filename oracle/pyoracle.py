@@ -14,8 +14,8 @@ _SO = os.path.join(_HERE, "libbanzai_oracle.so")
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "banzai_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("banzai_oracle.c", "bz2_decode.c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libbanzai_oracle.so"])
     return _SO
 
@@ -57,6 +57,8 @@ def lib():
         L.orc_encode.restype = ctypes.c_size_t
         L.orc_encode.argtypes = [u8p, ctypes.c_size_t, ctypes.c_int, u8p, ctypes.c_size_t, szp,
                                  ctypes.POINTER(BlockInfo), ctypes.c_size_t, szp]
+        L.orc_bz2_decode.restype = ctypes.c_int
+        L.orc_bz2_decode.argtypes = [u8p, ctypes.c_size_t, u8p, ctypes.c_size_t, szp]
         _lib = L
     return _lib
 
@@ -164,3 +166,30 @@ def encode(data, level=9, want_blocks=False):
     if want_blocks:
         return stream, [infos[k] for k in range(nb.value)]
     return stream
+
+
+class DecodeError(Exception):
+    """orc_bz2_decode status: -1 magic, -2 truncated, -3 format, -4 block CRC, -5 stream CRC, -6 capacity,
+    -7 memory, -8 trailing bytes"""
+
+    def __init__(self, status):
+        super().__init__("bz2 decode status %d" % status)
+        self.status = status
+
+
+def decode(stream, cap=None):
+    """In-repo bzip2 decoder (oracle/bz2_decode.c): stream bytes -> original bytes; raises DecodeError."""
+    a = np.frombuffer(bytes(stream), dtype=np.uint8) if len(stream) else np.zeros(1, np.uint8)
+    if cap is None:
+        cap = 64 + len(stream) * 60  # bzip2 cannot beat ~ 1:50 except on runs; grown below when needed
+    u8p = ctypes.POINTER(ctypes.c_uint8)
+    while True:
+        out = np.empty(max(1, cap), dtype=np.uint8)
+        n = ctypes.c_size_t(0)
+        st = lib().orc_bz2_decode(a.ctypes.data_as(u8p), len(stream), out.ctypes.data_as(u8p), cap, ctypes.byref(n))
+        if st == -6 and cap < (1 << 33):
+            cap *= 8
+            continue
+        if st != 0:
+            raise DecodeError(st)
+        return out[:n.value].tobytes()

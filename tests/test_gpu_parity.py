@@ -177,7 +177,7 @@ def test_stream_bit_exact_level1(oracle, ctx1, mode):
         d = cases.gen(n, mode, 12)
         g = ctx1.encode(d)
         assert g == oracle.encode(d, 1), (mode, n)
-        assert bz2.decompress(g) == d
+        assert bz2.decompress(g) == d and oracle.decode(g) == d  # libbz2 and the in-repo decoder
 
 
 @pytest.mark.parametrize("mode", ["random", "text", "longruns", "shortruns", "same"])
@@ -252,7 +252,7 @@ def test_pathological_config5(oracle, ctx9):
     d = corpus.pathological(8_000_000).tobytes()
     g = ctx9.encode(d)
     assert g == oracle.encode(d, 9)
-    assert bz2.decompress(g) == d
+    assert bz2.decompress(g) == d and oracle.decode(g) == d
 
 
 # ---- device-resident and sharded paths ------------------------------------------------------------------
@@ -310,9 +310,9 @@ def test_output_capacity_error(native):
         assert e.value.status == -4
 
 
-def test_full_size_properties_config3(native):
+def test_full_size_properties_config3(native, oracle):
     """BASELINE.json configs[2] at full size (100,000,000 bytes): properties that do not need the
-    oracle -- libbz2 reproduces the input (pins every CRC, table and block cut), the block table
+    encoding oracle -- libbz2 and the in-repo decoder reproduce the input (pins every CRC, table and block cut), the block table
     tiles the input, RLE1 lengths respect the level, and two runs give identical bytes."""
     import torch
     from banzai_amd import corpus
@@ -332,7 +332,7 @@ def test_full_size_properties_config3(native):
         assert d_out[:ln2].cpu().numpy().tobytes() == first
     assert sum(b[1] for b in blocks) == n and all(0 < b[2] <= 899_999 for b in blocks)
     assert first[:4] == b"BZh9"
-    assert bz2.decompress(first) == data.tobytes()
+    assert bz2.decompress(first) == data.tobytes() and oracle.decode(first) == data.tobytes()
 
 
 # ---- streaming --------------------------------------------------------------------------
