@@ -153,6 +153,11 @@ def main():
             d_s_out = torch.zeros((sample_n // 2 + (1 << 20)) & ~3, dtype=torch.uint8, device=dev)
             slen = ctx.encode_device(d_in.data_ptr(), sample_n, d_s_out.data_ptr(), d_s_out.numel())
             checks["bit_exact_vs_oracle_sample"] = bool(d_s_out[:slen].cpu().numpy().tobytes() == oracle_stream)
+            if total <= 200_000_000:  # the in-repo strict decoder (oracle/bz2_decode.c) on the whole GPU stream
+                try:
+                    checks["inrepo_decoder_roundtrip"] = bool(po.decode(stream_bytes, cap=total + 64) == ref_in)
+                except po.DecodeError:
+                    checks["inrepo_decoder_roundtrip"] = False
             cpu = {"value": round(sample_n / cpu_dt / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": "port",
                    "sample": f"first {sample_n} bytes of the workload, level {LEVEL}, oracle/banzai_oracle.c -O2, "
                              f"1 thread of {os.cpu_count()} host cores"}
