@@ -274,7 +274,7 @@ extern "C" int bzh_bwt_batch(bzh_ctx *ctx, const uint8_t *in, const uint64_t *of
         HIP_TRY(ctx, hipMemcpyAsync(ptr + k0, bt.ptr, B * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(has_byte + k0 * 256, bt.hasbyte, (size_t)B * 256, hipMemcpyDeviceToHost,
                                     ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, bzh_stream_wait(ctx->stream));
     }
     if (ctx->profiling) stats_collect_sort(ctx);
     return BZH_OK;
@@ -315,13 +315,13 @@ extern "C" int bzh_mtf(bzh_ctx *ctx, const uint8_t *bwt, size_t n, const uint8_t
     HIP_TRY(ctx, hipMemcpyAsync(&m32, bt.m, sizeof m32, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(num_syms, bt.nsyms, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(freqs, bt.freqs, 258 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, bzh_stream_wait(st));
     if (m32 == 0 || m32 > n32 + 1) {
         bzh_set_error(ctx, "mtf produced m=%u for n=%u", m32, n32);
         return BZH_E_HIP;
     }
     HIP_TRY(ctx, hipMemcpyAsync(syms, bt.syms, (size_t)m32 * sizeof(uint16_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, bzh_stream_wait(st));
     *m = m32;
     return BZH_OK;
 }
@@ -356,7 +356,7 @@ extern "C" int bzh_huffman(bzh_ctx *ctx, const uint16_t *syms, size_t m, uint32_
     BZH_TRY(huff_prepare(ctx, 1, m32));
     uint64_t total = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&total, bt.bitoff + 1, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, bzh_stream_wait(st));
     const size_t bytes = (size_t)((total + 31) / 32 * 4);
     BZH_TRY(ensure_stage(ctx, ctx->d_stage_out, ctx->stage_out_size, bytes));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_stage_out, 0, bytes, st));
@@ -366,7 +366,7 @@ extern "C" int bzh_huffman(bzh_ctx *ctx, const uint16_t *syms, size_t m, uint32_
     uint32_t nt = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&nt, bt.ntab, 4, hipMemcpyDeviceToHost, st));
     if (code_lengths) HIP_TRY(ctx, hipMemcpyAsync(code_lengths, bt.lens, 3 * 258, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, bzh_stream_wait(st));
     if (num_tables) *num_tables = nt;
     const uint64_t skip = 105 + 32;
     const uint64_t pay = total - skip;
@@ -505,7 +505,7 @@ static int prepare_batch(bzh_ctx *lane, RangeJob &j)
     BZH_TRY(huff_prepare(lane, j.B, j.mmax));
     mark(4);
     HIP_TRY(lane, hipMemcpyAsync(&j.T, lane->bt.bitoff + j.B, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(lane, hipStreamSynchronize(st));
+    HIP_TRY(lane, bzh_stream_wait(st));
     return BZH_OK;
 }
 
@@ -525,7 +525,7 @@ static int encode_range(bzh_ctx *ctx, size_t b0, size_t b1, uint8_t *d_out, size
         lanes = ctx->lanes;
     }
     const size_t NL = lanes.size();
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // the plan and whatever produced the input
+    HIP_TRY(ctx, bzh_stream_wait(ctx->stream)); // the plan and whatever produced the input
     const size_t nb = b1 - b0;
     const uint32_t lane_mb = lanes[0]->max_batch;
     size_t njobs = (nb + lane_mb - 1) / lane_mb;
@@ -615,10 +615,10 @@ static int encode_range(bzh_ctx *ctx, size_t b0, size_t b1, uint8_t *d_out, size
                     hipEventRecord(job.ev[5], st);
                     std::vector<uint32_t> hm(job.B);
                     he = hipMemcpyAsync(hm.data(), lane->bt.m, job.B * 4, hipMemcpyDeviceToHost, st);
-                    if (he == hipSuccess) he = hipStreamSynchronize(st);
+                    if (he == hipSuccess) he = bzh_stream_wait(st);
                     for (uint32_t b = 0; b < job.B; b++) ctx->stats.mtf_syms += hm[b];
                 }
-                if (he == hipSuccess) he = hipStreamSynchronize(st); // the lane's arena is free again
+                if (he == hipSuccess) he = bzh_stream_wait(st); // the lane's arena is free again
                 if (he != hipSuccess) {
                     bzh_set_error(ctx, "pack: %s", hipGetErrorString(he));
                     status = BZH_E_HIP;
@@ -682,7 +682,7 @@ extern "C" int bzh_plan_device(bzh_ctx *ctx, const void *d_in, size_t n, size_t 
     if (ctx->profiling) {
         e1 = bzh_event(ctx);
         hipEventRecord(e1, ctx->stream);
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, bzh_stream_wait(ctx->stream));
         memset(&ctx->stats, 0, sizeof ctx->stats);
         ctx->stats.ms_plan = span_ms(e0, e1);
     }
@@ -743,7 +743,7 @@ extern "C" int bzh_assemble_device(bzh_ctx *ctx, const void *const *d_segs, cons
     }
     stream_frame<<<1, 64, 0, st>>>((uint32_t *)d_out, ctx->level, body, fold_stream_crc(block_crcs, nblocks));
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, bzh_stream_wait(st));
     return BZH_OK;
 }
 
@@ -794,7 +794,7 @@ extern "C" int bzh_encode_device(bzh_ctx *ctx, const void *d_in, size_t n, void 
         t2 = bzh_event(ctx);
         hipEventRecord(t2, st);
     }
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, bzh_stream_wait(st));
     if (ctx->profiling) {
         ctx->stats.ms_plan = span_ms(t0, t1);
         ctx->stats.ms_total = span_ms(t0, t2);
@@ -820,7 +820,7 @@ extern "C" int bzh_encode(bzh_ctx *ctx, const uint8_t *in, size_t n, uint8_t *ou
     *out_len = len;
     if (len > cap) return BZH_E_CAP;
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_stage_out, len, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, bzh_stream_wait(st));
     return BZH_OK;
 }
 
@@ -852,7 +852,7 @@ extern "C" int bzh_rle1_split(bzh_ctx *ctx, const uint8_t *in, size_t n, bzh_blo
                 HIP_TRY(ctx, hipMemcpyAsync(rle_out + pos, bt.rle + (size_t)b * bt.S, len, hipMemcpyDeviceToHost, st));
                 pos += len;
             }
-            HIP_TRY(ctx, hipStreamSynchronize(st));
+            HIP_TRY(ctx, bzh_stream_wait(st));
         }
     }
     return BZH_OK;
@@ -945,7 +945,7 @@ static int stream_reserve(bzh_ctx *ctx, size_t head, size_t extra)
         return BZH_E_NOMEM;
     }
     if (s.pending) HIP_TRY(ctx, hipMemcpyAsync(nb + nhead, s.d_buf[f] + s.head, s.pending, hipMemcpyDeviceToDevice, s.copy_stream));
-    HIP_TRY(ctx, hipStreamSynchronize(s.copy_stream));
+    HIP_TRY(ctx, bzh_stream_wait(s.copy_stream));
     if (s.d_buf[f]) hipFree(s.d_buf[f]);
     s.d_buf[f] = nb;
     s.cap[f] = want;
@@ -1006,7 +1006,7 @@ static void stream_pass(bzh_ctx *ctx)
         }
         const size_t nbytes = full_words * 4 + ((bits_in_buf & 31u) ? 4 : 0);
         if (nbytes) HIP_TRY(ctx, hipMemcpyAsync(s.h_out, ctx->d_stage_out, nbytes, hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));
+        HIP_TRY(ctx, bzh_stream_wait(st));
         p.out_bytes = full_words * 4;
         if (bits_in_buf & 31u) {
             const uint8_t *w = s.h_out + full_words * 4;
@@ -1046,7 +1046,7 @@ extern "C" int bzh_stream_feed(bzh_ctx *ctx, const uint8_t *in, size_t n, int eo
     if (n) {
         BZH_TRY(stream_reserve(ctx, s.head, n));
         HIP_TRY(ctx, hipMemcpyAsync(s.d_buf[s.fill] + s.head + s.pending, in, n, hipMemcpyHostToDevice, s.copy_stream));
-        HIP_TRY(ctx, hipStreamSynchronize(s.copy_stream)); // `in` belongs to the caller again on return
+        HIP_TRY(ctx, bzh_stream_wait(s.copy_stream)); // `in` belongs to the caller again on return
         s.pending += n;
     }
     if (!eof && s.pending < s.min_feed) return BZH_OK;
@@ -1093,7 +1093,7 @@ extern "C" int bzh_stream_feed(bzh_ctx *ctx, const uint8_t *in, size_t n, int eo
         BZH_TRY(stream_reserve(ctx, left, 0));
         if (left) {
             HIP_TRY(ctx, hipMemcpyAsync(s.d_buf[s.fill] + s.head - left, tail, left, hipMemcpyDeviceToDevice, s.copy_stream));
-            HIP_TRY(ctx, hipStreamSynchronize(s.copy_stream));
+            HIP_TRY(ctx, bzh_stream_wait(s.copy_stream));
         }
         auto &p = s.pass;
         p.buf = s.fill;

@@ -1056,19 +1056,29 @@ static void launch_pass(bzh_ctx *ctx, SortArgs &a, uint32_t B, uint32_t maxcnt, 
     a.T = tiles;
     a.B = B;
     a.pass++;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ctx->profiling) {
-        e0 = bzh_event(ctx);
-        hipEventRecord(e0, ctx->stream);
-    }
     radix_scatter<BITS, MODE, REKEY><<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(a);
     if (ctx->profiling) {
-        e1 = bzh_event(ctx);
-        hipEventRecord(e1, ctx->stream);
-        ctx->sort_spans.push_back({e0, e1});
         ctx->stats.bwt_sort_launches += 1;
         ctx->stats.bwt_sort_elems += elems;
     }
+}
+
+// Profiling: HIP events bracket each RUN of consecutive radix_scatter launches (the 8 initial passes,
+// the 3 of a SWEEP round, the 5 of an ACTIVE round -- nothing else runs in between), not every
+// launch: an event pair costs about as much idle time as a small kernel.
+static hipEvent_t span_begin(bzh_ctx *ctx)
+{
+    if (!ctx->profiling) return nullptr;
+    hipEvent_t e = bzh_event(ctx);
+    hipEventRecord(e, ctx->stream);
+    return e;
+}
+static void span_end(bzh_ctx *ctx, hipEvent_t e0)
+{
+    if (!ctx->profiling || !e0) return;
+    hipEvent_t e1 = bzh_event(ctx);
+    hipEventRecord(e1, ctx->stream);
+    ctx->sort_spans.push_back({e0, e1});
 }
 
 // One workgroup per block: column sums of refine's digit rows, then the exclusive scan inside each
@@ -1157,6 +1167,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     HIP_TRY(ctx, hipMemsetAsync(bt.dtot, 0, (size_t)B * DB_STRIDE * sizeof(uint32_t), st));
     byte_count<<<dim3(BYTE_SEGS, B), 1024, 0, st>>>(bt.rle, bt.n, bt.dtot, bt.S);
     active_bases<<<dim3(B), 256, 0, st>>>(bt.dtot, bt.dbase, bt.n, 1);
+    hipEvent_t ev_init = span_begin(ctx);
     launch_pass<8, GEN_BYTES4, false>(ctx, a, B, nmax, ntotal);
     u64 *cur = bufA, *oth = bufB;
     for (int p = 1; p < 8; p++) {
@@ -1171,6 +1182,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         cur = oth;
         oth = t;
     }
+    span_end(ctx, ev_init);
     a.h = 0;
 
     // three rotating count arrays: length of the list in `cur` (prevcnt), unresolved counts of the
@@ -1224,7 +1236,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     ta.TT = (bt.S + TAIL_T - 1) / TAIL_T; // <= 512 (S <= 2^20)
     for (int round = 0; round < 48; round++) {
         HIP_TRY(ctx, hipMemcpyAsync(hact, nact_next, 2 * mb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));
+        HIP_TRY(ctx, bzh_stream_wait(st));
         if (!have_n) {
             for (uint32_t b = 0; b < B; b++) hprev[b] = hn[b];
             have_n = true;
@@ -1317,6 +1329,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             a.doff = 0;
             a.src = nullptr;
             a.dst = bufA;
+            hipEvent_t ev = span_begin(ctx);
             launch_pass<7, GEN_SWEEP, false>(ctx, a, B, nmax, sum);
             a.cnt = nact;
             a.shift = 47;
@@ -1329,6 +1342,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             a.src = bufB;
             a.dst = bufA;
             launch_pass<7, GEN_LIST, false>(ctx, a, B, maxact, sum);
+            span_end(ctx, ev);
             next_cur = bufA;
             next_oth = bufB;
         } else {
@@ -1349,6 +1363,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
                 a.doff = 0;
                 a.src = c;
                 a.dst = o;
+                hipEvent_t ev = span_begin(ctx);
                 launch_pass<8, GEN_LISTH, false>(ctx, a, B, prevmax, sum); // skips the holes
                 a.cnt = nact;
                 for (int p = 1; p < 5; p++) {
@@ -1361,6 +1376,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
                     a.dst = o;
                     launch_pass<8, GEN_LIST, false>(ctx, a, B, maxact, sum);
                 }
+                span_end(ctx, ev);
                 // gen: cur -> oth; passes: oth -> cur -> oth -> cur -> oth -> cur
                 next_cur = cur;
                 next_oth = oth;
@@ -1403,7 +1419,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     {
         uint32_t err = 0;
         HIP_TRY(ctx, hipMemcpyAsync(&err, bt.errflag, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));
+        HIP_TRY(ctx, bzh_stream_wait(st));
         if (err) {
             bzh_set_error(ctx, err & 2 ? "BWT initial sort: a look-back gave up waiting (internal error)"
                                        : "BWT tail rounds saw a group larger than their window (internal error)");

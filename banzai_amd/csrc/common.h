@@ -25,6 +25,21 @@ void bzh_set_error(bzh_ctx *ctx, const char *fmt, ...);
         }                                                                                          \
     } while (0)
 
+// Waits for a stream by polling.  hipStreamSynchronize sleeps on an interrupt and wakes 25-50 us late;
+// the encode path waits ~15 times per batch for a few counters each, so it polls instead (one host core
+// spins while the GPU works) and falls back to the blocking call for long waits.
+#include <chrono>
+static inline hipError_t bzh_stream_wait(hipStream_t st)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned it = 0;; it++) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+        if ((it & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
+            return hipStreamSynchronize(st);
+    }
+}
+
 #define BZH_TRY(expr)                                                                              \
     do {                                                                                           \
         int s_ = (expr);                                                                           \

@@ -809,14 +809,14 @@ int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n)
     plan_split<<<dim3(1), 64, 0, st>>>(pa);
     uint32_t nb = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&nb, pa.nblocks, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, bzh_stream_wait(st));
     if (nb == 0 || nb == 0xFFFFFFFFu || nb > pa.maxblocks) {
         bzh_set_error(ctx, "block split failed (nb=%u)", nb);
         return BZH_E_HIP;
     }
     std::vector<BlockDesc> hb(nb);
     HIP_TRY(ctx, hipMemcpyAsync(hb.data(), pa.blocks, nb * sizeof(BlockDesc), hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, bzh_stream_wait(st));
     uint64_t maxlen = 0;
     for (auto &d : hb) maxlen = d.in_len > maxlen ? d.in_len : maxlen;
     // block CRCs
@@ -830,12 +830,12 @@ int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n)
     }
     crc_finish<<<dim3(nb), 64, 0, st>>>(pa.blocks, w.crcacc, nb, ct);
     HIP_TRY(ctx, hipMemcpyAsync(hb.data(), pa.blocks, nb * sizeof(BlockDesc), hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, bzh_stream_wait(st));
     HIP_TRY(ctx, hipGetLastError());
     {
         std::vector<BlockAux> hax(nb);
         HIP_TRY(ctx, hipMemcpyAsync(hax.data(), pa.aux, nb * sizeof(BlockAux), hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));
+        HIP_TRY(ctx, bzh_stream_wait(st));
         ctx->plan_open.resize(nb);
         for (uint32_t b = 0; b < nb; b++) ctx->plan_open[b] = (uint8_t)hax[b].open;
     }
@@ -888,7 +888,7 @@ int crc_device(bzh_ctx *ctx, const uint8_t *d_in, size_t n, uint32_t *crc_out)
     if (ctiles) crc_tiles<<<dim3(ctiles, 1), RL_THREADS, 0, st>>>(d_in, dd, acc, ct);
     crc_finish<<<dim3(1), 64, 0, st>>>(dd, acc, 1, ct);
     HIP_TRY(ctx, hipMemcpyAsync(&d, dd, sizeof d, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, bzh_stream_wait(st));
     *crc_out = d.crc;
     return BZH_OK;
 }
