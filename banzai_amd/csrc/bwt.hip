@@ -397,7 +397,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
             const u64 w = __hip_atomic_load(col + (size_t)t * NBMAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t state = (uint32_t)(w >> 30) & 3u;
             if ((uint32_t)(w >> 32) != a.pass || state == 0) { // predecessor has not published yet
-                if (++spins > (1u << 22)) {
+                if (++spins > (1u << 26)) { // seconds: only a logic error gets here
                     atomicOr(a.err, 2u);
                     break;
                 }
