@@ -429,7 +429,12 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
 struct RefineArgs {
     const uint32_t *n;   // [B]
     const uint32_t *cnt; // [B] list length (n for the init pass, unresolved count in rounds)
-    u64 *list;           // [B][S] sorted elements (rewritten in place when writeback is set)
+    const u64 *list;     // [B][S] sorted elements
+    u64 *wb;             // [B][S] or nullptr: the block's OTHER list buffer; receives the still unresolved suffixes,
+                         // compacted and in order, as [new rank:20 @40][0][suffix:20]
+    u64 *cstat;          // tile status words of the compaction's look-back (word 192 of the tile's hist row)
+    uint32_t cpass;      // pass id in those words
+    uint32_t *err;       // bit 1: a look-back gave up
     const uint8_t *blk;  // [B][S] the text (init pass: low half of the 8-byte prefix is compared from it)
     uint32_t *rank;      // [B][S]
     uint32_t *sa;        // [B][S]
@@ -438,7 +443,6 @@ struct RefineArgs {
     int2 *tagg;          // [B][TPB]
     uint32_t *dig;       // [B][TPB][512] or nullptr: per tile, counts of the three 7-bit digits of the new rank over
                          // the suffixes left unresolved (bases of the next SWEEP round's look-back passes)
-    uint32_t writeback;  // leave [new rank:20 @40][0][suffix] / LIST_INVALID (resolved) in the list
     uint32_t *nact_next; // [B]
     uint32_t *maxgrp;    // [B] largest refined group (members), atomicMax
     const uint32_t *gate; // [B] skip block when 0 (nullptr = no gating)
@@ -585,12 +589,15 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
         if (q0 + SORT_ITEMS < cnt) nextflag = a.flg[base + q0 + SORT_ITEMS];
     }
     int tg = -1, td = -1;
+    uint32_t ucnt = 0; // own elements that stay unresolved (a singleton = boundary followed by a boundary)
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; k++) {
         const uint32_t f = (packed[k >> 2] >> ((k & 3) * 8)) & 3u;
+        const uint32_t fn = (k + 1 < SORT_ITEMS) ? ((packed[(k + 1) >> 2] >> (((k + 1) & 3) * 8)) & 3u) : nextflag;
         if (q0 + k < cnt) {
             if (f & 1u) tg = (int)(q0 + k);
             if (f & 2u) td = (int)(q0 + k);
+            ucnt += ((f & 2u) && ((q0 + k + 1 == cnt) || (fn & 2u))) ? 0u : 1u;
         }
     }
     __shared__ int l01[2 * SORT_THREADS / 64];
@@ -605,9 +612,48 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
         cg = max(cg, ex0[threadIdx.x - 1]);
         cd = max(cd, ex1[threadIdx.x - 1]);
     }
+    // compaction of the unresolved records: slot = (unresolved in earlier tiles: look-back over the
+    // tile counts) + (in earlier threads of the tile) + (before the element in the thread)
+    __shared__ uint32_t lsu[SORT_THREADS / 64 + 2];
+    __shared__ uint32_t cpre;
+    uint32_t wslot = 0;
+    if (a.wb) {
+        uint32_t utot;
+        const uint32_t uoff = block_excl_add(ucnt, lsu, &utot);
+        if (threadIdx.x == 0) {
+            u64 *st = a.cstat + (size_t)b * a.TPB * NBMAX + 192;
+            uint32_t acc = 0, spins = 0;
+            if (tile > 0) {
+                __hip_atomic_store(st + (size_t)tile * NBMAX, look_word(a.cpass, LOOK_LOCAL, utot), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                int t = (int)tile - 1;
+                while (t >= 0) {
+                    const u64 w = __hip_atomic_load(st + (size_t)t * NBMAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t state = (uint32_t)(w >> 30) & 3u;
+                    if ((uint32_t)(w >> 32) != a.cpass || state == 0) {
+                        if (++spins > (1u << 26)) {
+                            atomicOr(a.err, 2u);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                        continue;
+                    }
+                    acc += (uint32_t)w & 0x3FFFFFFFu;
+                    if (state == LOOK_GLOBAL) break;
+                    t--;
+                }
+            }
+            __hip_atomic_store(st + (size_t)tile * NBMAX, look_word(a.cpass, LOOK_GLOBAL, acc + utot), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            cpre = acc;
+        }
+        __syncthreads();
+        wslot = cpre + uoff;
+    }
     uint32_t *rank = a.rank + base;
     uint32_t *sa = a.sa + base;
     uint32_t *headp = a.headp + base;
+    u64 *wb = a.wb ? a.wb + base : nullptr;
     __shared__ uint32_t dh[384];
     if (a.dig) {
         for (int k = threadIdx.x; k < 384; k += SORT_THREADS) dh[k] = 0;
@@ -637,6 +683,7 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
                 rank[i] = single ? (head | RANK_RESOLVED) : head;
                 outv[k] = ((u64)(single ? 1u : 0u) << 60) | ((u64)pos << 40) | ((u64)head << 20) | i;
                 unresolved += single ? 0u : 1u;
+                if (wb && !single) wb[wslot++] = ((u64)head << 40) | i; // ranked record for ACTIVE re-keying / TAIL
                 if (a.dig && !single) {
                     // heads rise with q, so a thread's 16 entries share their upper digits (and, inside
                     // a group, the whole head): count runs in registers, touch LDS once per run
@@ -683,9 +730,6 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
             const uint32_t head = (uint32_t)(x >> 20) & 0xFFFFFu;
             sa[pos] = (uint32_t)(x & SUF_MASK);
             headp[pos] = head;
-            // the next round re-keys this list (ACTIVE) or sorts it in place (TAIL): leave the new
-            // group rank in the record so that neither has to gather rank[i]
-            if (a.writeback) a.list[base + tile0 + e] = ((x >> 60) & 1ull) ? LIST_INVALID : (((u64)head << 40) | (x & SUF_MASK));
         }
     }
     unresolved = wave_reduce_add(unresolved);
@@ -725,8 +769,8 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
 // consistent) and counts survivors per tile; tail_scan + tail_compact move the still-unresolved
 // records, order preserved, back to the block's own buffer, so the next round touches only what is
 // left.
-constexpr int TAIL_T = 2048, TAIL_G = 256, TAIL_W = TAIL_T + 2 * TAIL_G, TAIL_THREADS = 512;
-constexpr int TAIL_PER = TAIL_W / TAIL_THREADS; // 5 slots per thread
+constexpr int TAIL_T = 2048, TAIL_G = 512, TAIL_W = TAIL_T + 2 * TAIL_G, TAIL_THREADS = 512;
+constexpr int TAIL_PER = TAIL_W / TAIL_THREADS; // 6 slots per thread
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 constexpr uint32_t TAIL_BUF_B = 0x80000000u; // gateT bit: the block's list lives in listB
 constexpr uint32_t TAIL_LEN = 0x3FFFFFFFu;
@@ -1208,6 +1252,9 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     r.S = bt.S;
     r.TPB = bt.TPB;
     r.init = 1;
+    r.wb = nullptr; // the first round reads the list in its initial-sort format (every suffix, unranked)
+    r.cstat = reinterpret_cast<u64 *>(bt.hist);
+    r.err = bt.errflag;
     r.dig = bt.hist; // the first round may be a SWEEP
     launch_refine(ctx, r, B, nmax);
 
@@ -1218,10 +1265,10 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     uint32_t *hgR = ctx->h_pinned + 3 * mb;  // gates uploaded each round
     uint32_t *hgT = ctx->h_pinned + 4 * mb;
     HIP_TRY(ctx, hipMemcpyAsync(hn, bt.n, B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    std::vector<uint32_t> hprev(B), taillen(B, 0); // list length per block; frozen slots once in TAIL mode
+    std::vector<uint32_t> hprev(B), taillen(B, 0); // frozen slots once in TAIL mode
     std::vector<uint8_t> tailmode(B, 0);
     bool active_mode = false, have_n = false;
-    const uint32_t *prevcnt = bt.n; // device: length of the list `cur` per block (radix blocks)
+    const uint32_t *prevcnt = nullptr; // (the list in `cur` is dense after the first round: its length is nact)
     uint32_t h = 8; // the initial sort ordered the rotations by their first 8 bytes
     TailArgs ta{};
     ta.n = bt.n;
@@ -1249,7 +1296,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             if (!tailmode[b] && hact[b] && hmax[b] <= (uint32_t)TAIL_G) {
                 tailmode[b] = 1;
                 // the sorted list in `cur` keeps this many slots, in this buffer, from now on
-                taillen[b] = hprev[b] | (cur == bufB ? TAIL_BUF_B : 0u);
+                taillen[b] = (round == 0 ? hn[b] : hact[b]) | (cur == bufB ? TAIL_BUF_B : 0u);
             }
             if (tailmode[b] == 2) // compacted last round (back into its own buffer)
                 taillen[b] = hact[b] | (taillen[b] & TAIL_BUF_B);
@@ -1263,7 +1310,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
                 hgT[b] = 0;
                 maxact = hact[b] > maxact ? hact[b] : maxact;
                 if (hact[b]) {
-                    prevmax = hprev[b] > prevmax ? hprev[b] : prevmax;
+                    const uint32_t L = round == 0 ? hn[b] : hact[b]; // length of the list in `cur`
+                    prevmax = L > prevmax ? L : prevmax;
                     sum += hact[b];
                     nsum += hn[b];
                 }
@@ -1349,7 +1397,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             // re-key once (active_gen), then five look-back passes on bits 20..59; the list ends in `cur`
             {
                 const uint32_t gt = (prevmax + SORT_TILE - 1) / SORT_TILE;
-                a.cnt = prevcnt;
+                a.cnt = round == 0 ? bt.n : nact; // the initial list holds every suffix, later lists are dense
                 a.src = cur;
                 a.dst = oth;
                 a.T = gt;
@@ -1408,11 +1456,14 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             r.maxgrp = nact_next + mb;
             r.init = 0;
             r.dig = active_mode ? nullptr : bt.hist; // only a SWEEP round needs the digit bases
-            r.writeback = 1;
+            r.wb = oth; // the still unresolved suffixes, ranked, compacted, in order
+            r.cpass = ++a.pass;
             r.gate = bt.gateR;
             launch_refine(ctx, r, B, maxact);
+            u64 *t = cur; // the compacted list is the next round's `cur`
+            cur = oth;
+            oth = t;
         }
-        prevcnt = nact;
 
         if (h < (1u << 30)) h <<= quad ? 2 : 1;
     }
