@@ -771,6 +771,7 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
 // left.
 constexpr int TAIL_T = 2048, TAIL_G = 512, TAIL_W = TAIL_T + 2 * TAIL_G, TAIL_THREADS = 512;
 constexpr int TAIL_PER = TAIL_W / TAIL_THREADS; // 6 slots per thread
+constexpr int TAIL_SMALL = 32; // groups up to this size are ranked by the threads holding their members
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 constexpr uint32_t TAIL_BUF_B = 0x80000000u; // gateT bit: the block's list lives in listB
 constexpr uint32_t TAIL_LEN = 0x3FFFFFFFu;
@@ -924,12 +925,26 @@ __global__ void __launch_bounds__(TAIL_THREADS) tail_sort(TailArgs a)
             }
         }
     }
+    // large owned groups are listed for the cooperative pass below (each by the thread holding its head)
+    __shared__ uint32_t nbig;
+    __shared__ uint32_t bigs[TAIL_W / (TAIL_SMALL + 1) + 1]; // start | size << 16
+    if (threadIdx.x == 0) nbig = 0;
     __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TAIL_PER; j++) {
+        if ((uint32_t)j < cnt && (owned & (1u << j))) {
+            const uint32_t e = idx0 + j, g = gstart[j];
+            const uint32_t sz = (uint32_t)GE[g] - g;
+            if (e == g && sz > (uint32_t)TAIL_SMALL) bigs[atomicAdd(&nbig, 1u)] = g | (sz << 16);
+        }
+    }
+    // small groups: every member counts its own predecessors (at most TAIL_SMALL steps)
 #pragma unroll
     for (int j = 0; j < TAIL_PER; j++) {
         if ((uint32_t)j < cnt && (owned & (1u << j))) {
             const uint32_t e = idx0 + j, r = cr[j], g = gstart[j];
             const uint32_t ge = GE[g];
+            if (ge - g > (uint32_t)TAIL_SMALL) continue;
             // lexicographic key (k2, k3, k4): two 64-bit words compare it
             const uint32_t my_hi = A3[e];
             const u64 my_lo = QUAD ? (((u64)A4[e] << 32) | A5[e]) : 0ull;
@@ -949,6 +964,61 @@ __global__ void __launch_bounds__(TAIL_THREADS) tail_sort(TailArgs a)
                             (ci[j] & (uint32_t)SUF_MASK);
             out[s_lo + (A1[g + u] >> 20)] = rec; // the u-th smallest member takes the slot of the u-th member
         }
+    }
+    // large groups, one after the other, by the whole workgroup: the g x g comparisons are tiled as
+    // (member, slice of the partners) over all threads and the partial counts meet in LDS -- left to
+    // the few threads holding the members, a 512-member group would keep them busy for 3000 steps
+    // while everyone else idles
+    __shared__ uint32_t cless[TAIL_THREADS], ceq[TAIL_THREADS], cbef[TAIL_THREADS];
+    __syncthreads();
+    const uint32_t nb = nbig;
+    for (uint32_t q = 0; q < nb; q++) {
+        const uint32_t g = bigs[q] & 0xFFFFu, sz = bigs[q] >> 16; // sz <= TAIL_G <= TAIL_THREADS
+        uint32_t c = 1; // partner slices per member: the largest power of two with sz * c <= threads
+        while (sz * (c << 1) <= (uint32_t)TAIL_THREADS) c <<= 1;
+        if (threadIdx.x < sz) {
+            cless[threadIdx.x] = 0;
+            ceq[threadIdx.x] = 0;
+            cbef[threadIdx.x] = 0;
+        }
+        __syncthreads();
+        const uint32_t mbr = threadIdx.x / c, sl = threadIdx.x % c;
+        if (mbr < sz) {
+            const uint32_t e = g + mbr;
+            const uint32_t per = (sz + c - 1) / c;
+            const uint32_t f0 = g + sl * per, f1 = min(g + sz, f0 + per);
+            const uint32_t my_hi = A3[e];
+            const u64 my_lo = QUAD ? (((u64)A4[e] << 32) | A5[e]) : 0ull;
+            uint32_t less = 0, eq_before = 0, eq = 0;
+#pragma unroll 4
+            for (uint32_t f = f0; f < f1; f++) {
+                const uint32_t f_hi = A3[f];
+                const u64 f_lo = QUAD ? (((u64)A4[f] << 32) | A5[f]) : 0ull;
+                const bool same = f_hi == my_hi && f_lo == my_lo;
+                less += (f_hi < my_hi) || (f_hi == my_hi && f_lo < my_lo);
+                eq += same;
+                eq_before += same && (f < e);
+            }
+            if (c == 1) {
+                cless[mbr] = less;
+                ceq[mbr] = eq;
+                cbef[mbr] = eq_before;
+            } else {
+                if (less) atomicAdd(&cless[mbr], less);
+                if (eq) atomicAdd(&ceq[mbr], eq);
+                if (eq_before) atomicAdd(&cbef[mbr], eq_before);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < sz) {
+            const uint32_t e = g + threadIdx.x, r = A0[e];
+            const uint32_t less = cless[threadIdx.x], u = less + cbef[threadIdx.x];
+            const bool single = ceq[threadIdx.x] == 1;
+            const u64 rec = ((u64)(single ? 1u : 0u) << 60) | ((u64)(r + less) << 40) | ((u64)(r + u) << 20) |
+                            (A1[e] & (uint32_t)SUF_MASK);
+            out[s_lo + (A1[g + u] >> 20)] = rec;
+        }
+        __syncthreads();
     }
     // (the block's survivor count is produced by tail_apply + tail_scan: per-wave atomics onto one
     // counter per block cost more than the rest of this kernel)
