@@ -37,7 +37,7 @@
 //   flag_tiles / flag_carry / refine   boundary flags, max-scan of group heads, rank + SA update
 //                  (tiles staged through LDS: coalesced global access, blocked per-thread scans)
 //   sweep_bases / active_gen / active_bases   digit bases of the SWEEP / ACTIVE passes
-//   tail_sort / tail_apply / tail_scan / tail_compact   TAIL rounds
+//   tail_sort / tail_finish   TAIL rounds
 //   bwt_emit       last column, ptr, has_byte
 #include <vector>
 
@@ -765,10 +765,9 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
 // block's OTHER list buffer (same slot numbering), so the input stays untouched during the kernel
 // and its records can be trusted: each carries the suffix and its current group rank (written by
 // refine, or by the previous tail round), so nothing has to be gathered but key2.  tail_sort reads
-// only OLD ranks; tail_apply stores the new ranks / SA entries (the kernel boundary keeps rank reads
-// consistent) and counts survivors per tile; tail_scan + tail_compact move the still-unresolved
-// records, order preserved, back to the block's own buffer, so the next round touches only what is
-// left.
+// only OLD ranks; tail_finish stores the new ranks / SA entries (the kernel boundary keeps rank reads
+// consistent) and moves the still-unresolved records, order preserved, back to the block's own
+// buffer, so the next round touches only what is left.
 constexpr int TAIL_T = 2048, TAIL_G = 512, TAIL_W = TAIL_T + 2 * TAIL_G, TAIL_THREADS = 512;
 constexpr int TAIL_PER = TAIL_W / TAIL_THREADS; // 6 slots per thread
 constexpr int TAIL_SMALL = 32; // groups up to this size are ranked by the threads holding their members
@@ -784,7 +783,8 @@ struct TailArgs {
     uint32_t *rank;      // [B][S]
     uint32_t *sa;        // [B][S]
     uint32_t *nact_next; // [B]
-    uint32_t *tcount;    // [B][TT] survivors per tile, then their exclusive scan
+    u64 *stat;           // tile status words of tail_finish's look-back (inside the block's hist rows)
+    uint32_t pass;       // pass id in those words
     uint32_t *err;       // [1] precondition violations
     uint32_t S, h, T, B, TT;
 };
@@ -833,7 +833,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) tail_sort(TailArgs a)
                     if (!(rr & RANK_RESOLVED)) r = rr;
                 }
             }
-            // no unresolved suffix here: a hole for tail_apply / tail_compact
+            // no unresolved suffix here: a hole for tail_finish
             if (r == NONE32 && sl >= r0 && sl < r1) out[sl] = LIST_INVALID;
         }
         A0[w] = r;
@@ -1020,13 +1020,17 @@ __global__ void __launch_bounds__(TAIL_THREADS) tail_sort(TailArgs a)
         }
         __syncthreads();
     }
-    // (the block's survivor count is produced by tail_apply + tail_scan: per-wave atomics onto one
-    // counter per block cost more than the rest of this kernel)
+    // (the block's survivor count is produced by tail_finish: per-wave atomics onto one counter per
+    // block cost more than the rest of this kernel)
     if (bad) atomicOr(a.err, 1u);
 }
 
-// Applies the records of a tile and counts its survivors (records still unresolved).
-__global__ void __launch_bounds__(256) tail_apply(TailArgs a)
+// After tail_sort, one kernel: applies the records of a tile (new ranks / SA entries -- the kernel
+// boundary after tail_sort keeps its rank reads consistent), and moves the records that are still
+// unresolved, order preserved, back to the block's own buffer: a thread owns 8 consecutive slots,
+// a block scan gives the offsets inside the tile, a look-back over the tile counts the offset of the
+// tile.  The last tile leaves the block's survivor count for the host.
+__global__ void __launch_bounds__(256) tail_finish(TailArgs a)
 {
     uint32_t b, tile;
     if (!wg_map(a.T, a.B, b, tile)) return;
@@ -1036,74 +1040,71 @@ __global__ void __launch_bounds__(256) tail_apply(TailArgs a)
     if (r0 >= len) return;
     const size_t base = (size_t)b * a.S;
     const u64 *rec = ((lenw & TAIL_BUF_B) ? a.bufA : a.bufB) + base; // tail_sort's output
+    u64 *dst = ((lenw & TAIL_BUF_B) ? a.bufB : a.bufA) + base;       // back home, compacted
     uint32_t *rank = a.rank + base;
     uint32_t *sa = a.sa + base;
-    uint32_t alive = 0;
-#pragma unroll
-    for (int k = 0; k < TAIL_T / 256; k++) {
-        const uint32_t sl = r0 + k * 256 + threadIdx.x;
-        if (sl < len) {
-            const u64 x = rec[sl];
-            if (x != LIST_INVALID) {
-                const uint32_t i = (uint32_t)(x & SUF_MASK);
-                const uint32_t nr = (uint32_t)(x >> 40) & 0xFFFFFu;
-                const bool res = (x >> 60) & 1ull;
-                rank[i] = res ? (nr | RANK_RESOLVED) : nr;
-                sa[(uint32_t)(x >> 20) & 0xFFFFFu] = i;
-                alive += res ? 0u : 1u;
-            }
-        }
-    }
-    __shared__ uint32_t ls[256 / 64 + 2];
-    uint32_t tot;
-    (void)block_excl_add(alive, ls, &tot);
-    if (threadIdx.x == 0) a.tcount[(size_t)b * a.TT + tile] = tot;
-}
-
-// One workgroup per block: exclusive scan of the per-tile survivor counts (TT <= 512).
-__global__ void __launch_bounds__(512) tail_scan(TailArgs a)
-{
-    const uint32_t b = blockIdx.x;
-    const uint32_t len = a.len[b] & TAIL_LEN;
-    if (len == 0) return;
-    const uint32_t ntile = (len + TAIL_T - 1) / TAIL_T;
-    uint32_t *tc = a.tcount + (size_t)b * a.TT;
-    __shared__ uint32_t ls[512 / 64 + 2];
-    const uint32_t v = threadIdx.x < ntile ? tc[threadIdx.x] : 0;
-    uint32_t tot;
-    const uint32_t ex = block_excl_add(v, ls, &tot);
-    if (threadIdx.x < ntile) tc[threadIdx.x] = ex;
-    if (threadIdx.x == 0) a.nact_next[b] = tot; // unresolved suffixes of the block after this round
-}
-
-// Moves the surviving records of a tile to the other buffer, order preserved.
-__global__ void __launch_bounds__(256) tail_compact(TailArgs a)
-{
-    uint32_t b, tile;
-    if (!wg_map(a.T, a.B, b, tile)) return;
-    const uint32_t lenw = a.len[b];
-    const uint32_t len = lenw & TAIL_LEN;
-    const uint32_t r0 = tile * TAIL_T;
-    if (r0 >= len) return;
-    const size_t base = (size_t)b * a.S;
-    const u64 *src = ((lenw & TAIL_BUF_B) ? a.bufA : a.bufB) + base; // tail_sort's output
-    u64 *dst = ((lenw & TAIL_BUF_B) ? a.bufB : a.bufA) + base;       // back home, compacted
-    constexpr int PER = TAIL_T / 256;
-    const uint32_t s0 = r0 + threadIdx.x * PER;
+    constexpr int PER = TAIL_T / 256, NWV = 256 / 64;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // slot = r0 + k*256 + thread: coalesced reads; survivors keep slot order = (k, wave, lane) order
+    __shared__ uint32_t wc[PER * NWV + 1];
+    __shared__ uint32_t tpre;
     u64 x[PER];
-    uint32_t cnt = 0;
+    uint32_t lo[PER]; // survivors of my wavefront's row k in lower lanes
 #pragma unroll
     for (int k = 0; k < PER; k++) {
-        x[k] = (s0 + k < len) ? src[s0 + k] : LIST_INVALID;
-        if (x[k] != LIST_INVALID && ((x[k] >> 60) & 1ull)) x[k] = LIST_INVALID;
-        cnt += x[k] != LIST_INVALID;
+        const uint32_t sl = r0 + k * 256 + threadIdx.x;
+        x[k] = sl < len ? rec[sl] : LIST_INVALID;
+        if (x[k] != LIST_INVALID) {
+            const uint32_t i = (uint32_t)(x[k] & SUF_MASK);
+            const uint32_t nr = (uint32_t)(x[k] >> 40) & 0xFFFFFu;
+            const bool res = (x[k] >> 60) & 1ull;
+            rank[i] = res ? (nr | RANK_RESOLVED) : nr;
+            sa[(uint32_t)(x[k] >> 20) & 0xFFFFFu] = i;
+            if (res) x[k] = LIST_INVALID;
+        }
+        const u64 m = __ballot(x[k] != LIST_INVALID);
+        lo[k] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (lane == 0) wc[k * NWV + wave] = (uint32_t)__popcll(m);
     }
-    __shared__ uint32_t ls[256 / 64 + 2];
-    uint32_t tot;
-    uint32_t o = a.tcount[(size_t)b * a.TT + tile] + block_excl_add(cnt, ls, &tot);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int q = 0; q < PER * NWV; q++) { // exclusive scan in slot order
+            const uint32_t c = wc[q];
+            wc[q] = tot;
+            tot += c;
+        }
+        u64 *st = a.stat + ((size_t)b * a.TT) * 128 + 96; // one word per tail tile inside the block's hist rows
+        uint32_t acc = 0, spins = 0;
+        if (tile > 0) {
+            __hip_atomic_store(st + (size_t)tile * 128, look_word(a.pass, LOOK_LOCAL, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int t = (int)tile - 1;
+            while (t >= 0) {
+                const u64 w = __hip_atomic_load(st + (size_t)t * 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t state = (uint32_t)(w >> 30) & 3u;
+                if ((uint32_t)(w >> 32) != a.pass || state == 0) {
+                    if (++spins > (1u << 26)) {
+                        atomicOr(a.err, 2u);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                    continue;
+                }
+                acc += (uint32_t)w & 0x3FFFFFFFu;
+                if (state == LOOK_GLOBAL) break;
+                t--;
+            }
+        }
+        __hip_atomic_store(st + (size_t)tile * 128, look_word(a.pass, LOOK_GLOBAL, acc + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tpre = acc;
+        if (r0 + TAIL_T >= len) a.nact_next[b] = acc + tot; // last tile: unresolved suffixes of the block after this round
+    }
+    __syncthreads();
+    const uint32_t pre = tpre;
 #pragma unroll
     for (int k = 0; k < PER; k++)
-        if (x[k] != LIST_INVALID) dst[o++] = x[k];
+        if (x[k] != LIST_INVALID) dst[pre + wc[k * NWV + wave] + lo[k]] = x[k];
 }
 
 // ---- last column ---------------------------------------------------------------------------------
@@ -1348,7 +1349,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     ta.rank = bt.rank;
     ta.sa = bt.sa;
     ta.err = bt.errflag;
-    ta.tcount = bt.alive;
+    ta.stat = reinterpret_cast<u64 *>(bt.hist);
     ta.S = bt.S;
     ta.TT = (bt.S + TAIL_T - 1) / TAIL_T; // <= 512 (S <= 2^20)
     for (int round = 0; round < 48; round++) {
@@ -1510,9 +1511,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
                 tail_sort<true><<<dim3(xcd_grid(ta.T, B)), TAIL_THREADS, 0, st>>>(ta);
             else
                 tail_sort<false><<<dim3(xcd_grid(ta.T, B)), TAIL_THREADS, 0, st>>>(ta);
-            tail_apply<<<dim3(xcd_grid(ta.T, B)), 256, 0, st>>>(ta);
-            tail_scan<<<dim3(B), 512, 0, st>>>(ta);
-            tail_compact<<<dim3(xcd_grid(ta.T, B)), 256, 0, st>>>(ta);
+            ta.pass = ++a.pass;
+            tail_finish<<<dim3(xcd_grid(ta.T, B)), 256, 0, st>>>(ta);
         }
         if (maxact) {
             cur = next_cur;
