@@ -1339,6 +1339,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     std::vector<uint32_t> hprev(B), taillen(B, 0); // frozen slots once in TAIL mode
     std::vector<uint8_t> tailmode(B, 0);
     bool active_mode = false, have_n = false;
+    bool have_list = true; // `cur` holds the list ACTIVE / TAIL need (the initial one, or refine's compacted one)
     const uint32_t *prevcnt = nullptr; // (the list in `cur` is dense after the first round: its length is nact)
     uint32_t h = 8; // the initial sort ordered the rotations by their first 8 bytes
     TailArgs ta{};
@@ -1364,7 +1365,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         uint64_t sum = 0, nsum = 0, tot = 0;
         for (uint32_t b = 0; b < B; b++) {
             tot += hact[b];
-            if (!tailmode[b] && hact[b] && hmax[b] <= (uint32_t)TAIL_G) {
+            if (!tailmode[b] && have_list && hact[b] && hmax[b] <= (uint32_t)TAIL_G) {
                 tailmode[b] = 1;
                 // the sorted list in `cur` keeps this many slots, in this buffer, from now on
                 taillen[b] = (round == 0 ? hn[b] : hact[b]) | (cur == bufB ? TAIL_BUF_B : 0u);
@@ -1419,7 +1420,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         }
         // ACTIVE costs ~5 list passes over the unresolved suffixes, SWEEP a full SA sweep plus 3
         // passes: switch once the unresolved fraction is small; never switch back.
-        if (!active_mode && nsum && sum * 3 < nsum) active_mode = true;
+        if (!active_mode && have_list && nsum && sum * 3 < nsum) active_mode = true;
         const bool active_round = maxact && active_mode;
         if (mb <= SETUP_MAX) {
             RoundSetup rs;
@@ -1526,13 +1527,20 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             r.maxgrp = nact_next + mb;
             r.init = 0;
             r.dig = active_mode ? nullptr : bt.hist; // only a SWEEP round needs the digit bases
-            r.wb = oth; // the still unresolved suffixes, ranked, compacted, in order
+            // The compacted list is only read by ACTIVE re-keying and by blocks entering TAIL mode.  While
+            // nearly everything is still unresolved (periodic inputs: many SWEEP rounds in a row) it is not
+            // written; without it the next round is a SWEEP and no block changes mode (always correct).
+            const bool wbk = active_mode || sum * 10 <= nsum * 9;
+            r.wb = wbk ? oth : nullptr; // the still unresolved suffixes, ranked, compacted, in order
             r.cpass = ++a.pass;
             r.gate = bt.gateR;
             launch_refine(ctx, r, B, maxact);
-            u64 *t = cur; // the compacted list is the next round's `cur`
-            cur = oth;
-            oth = t;
+            if (wbk) { // the compacted list is the next round's `cur`
+                u64 *t = cur;
+                cur = oth;
+                oth = t;
+            }
+            have_list = wbk;
         }
 
         if (h < (1u << 30)) h <<= quad ? 2 : 1;
