@@ -564,6 +564,8 @@ __global__ void __launch_bounds__(1024) flag_carry(RefineArgs a)
     if (e < ntile) t[e] = e == 0 ? make_int2(-1, -1) : make_int2(inc0[e - 1], inc1[e - 1]);
 }
 
+// WB: also write the compacted list of the suffixes that stay unresolved (a.wb)
+template <bool WB>
 __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
 {
     uint32_t b, tile;
@@ -597,7 +599,7 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
         if (q0 + k < cnt) {
             if (f & 1u) tg = (int)(q0 + k);
             if (f & 2u) td = (int)(q0 + k);
-            ucnt += ((f & 2u) && ((q0 + k + 1 == cnt) || (fn & 2u))) ? 0u : 1u;
+            if (WB) ucnt += ((f & 2u) && ((q0 + k + 1 == cnt) || (fn & 2u))) ? 0u : 1u;
         }
     }
     __shared__ int l01[2 * SORT_THREADS / 64];
@@ -617,7 +619,7 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
     __shared__ uint32_t lsu[SORT_THREADS / 64 + 2];
     __shared__ uint32_t cpre;
     uint32_t wslot = 0;
-    if (a.wb) {
+    if (WB) {
         uint32_t utot;
         const uint32_t uoff = block_excl_add(ucnt, lsu, &utot);
         if (threadIdx.x == 0) {
@@ -653,7 +655,7 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
     uint32_t *rank = a.rank + base;
     uint32_t *sa = a.sa + base;
     uint32_t *headp = a.headp + base;
-    u64 *wb = a.wb ? a.wb + base : nullptr;
+    u64 *wb = WB ? a.wb + base : nullptr;
     __shared__ uint32_t dh[384];
     if (a.dig) {
         for (int k = threadIdx.x; k < 384; k += SORT_THREADS) dh[k] = 0;
@@ -683,7 +685,7 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
                 rank[i] = single ? (head | RANK_RESOLVED) : head;
                 outv[k] = ((u64)(single ? 1u : 0u) << 60) | ((u64)pos << 40) | ((u64)head << 20) | i;
                 unresolved += single ? 0u : 1u;
-                if (wb && !single) wb[wslot++] = ((u64)head << 40) | i; // ranked record for ACTIVE re-keying / TAIL
+                if (WB && !single) wb[wslot++] = ((u64)head << 40) | i; // ranked record for ACTIVE re-keying / TAIL
                 if (a.dig && !single) {
                     // heads rise with q, so a thread's 16 entries share their upper digits (and, inside
                     // a group, the whole head): count runs in registers, touch LDS once per run
@@ -1237,7 +1239,10 @@ static void launch_refine(bzh_ctx *ctx, RefineArgs &r, uint32_t B, uint32_t maxc
     r.B = B;
     flag_tiles<<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(r);
     flag_carry<<<dim3(B), 1024, 0, ctx->stream>>>(r);
-    refine<<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(r);
+    if (r.wb)
+        refine<true><<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(r);
+    else
+        refine<false><<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(r);
     if (r.dig) sweep_bases<<<dim3(B), 768, 0, ctx->stream>>>(r, ctx->bt.dbase);
 }
 
