@@ -113,72 +113,70 @@ __global__ void __launch_bounds__(256) huff_segments(Batch bt, const uint32_t *r
 
 // ---- exact heap (lib/huffman.rs:161-298) ---------------------------------------------------------------
 struct HeapMem {
-    uint64_t prio[HUF_SYMS + 2]; // (weight << 8) | depth : lexicographic Priority(usize, u8)
-    uint16_t id[HUF_SYMS + 2];
+    // one word per heap slot: ((weight << 8 | depth) << 10) | node id.  The reference orders by the
+    // lexicographic Priority(usize, u8) alone -- ids never take part in a comparison (they are shifted
+    // out) -- so a slot moves with one LDS access instead of two.
+    uint64_t key[HUF_SYMS + 2];
     int16_t lch[2 * HUF_SYMS], rch[2 * HUF_SYMS];
     int16_t depth[2 * HUF_SYMS];
     uint32_t fr[HUF_SYMS];
 };
+constexpr int HEAP_ID_BITS = 10; // node ids < 2 * 258
 
 __device__ void heap_insert(HeapMem &h, uint32_t &len, uint16_t sym, uint64_t pr) // :196-222
 {
     const uint32_t init_idx = len + 1;
-    h.id[init_idx] = sym;
-    h.prio[init_idx] = pr;
+    const uint64_t mine = (pr << HEAP_ID_BITS) | sym;
+    h.key[init_idx] = mine;
     len++;
     if (init_idx == 1) return;
     uint32_t this_idx = init_idx;
     for (;;) {
         const uint32_t above = this_idx >> 1;
-        const uint64_t ap = h.prio[above];
-        if (pr < ap) {
-            h.prio[this_idx] = ap;
-            h.id[this_idx] = h.id[above];
+        const uint64_t ak = h.key[above];
+        if (pr < (ak >> HEAP_ID_BITS)) {
+            h.key[this_idx] = ak;
             this_idx = above;
             if (this_idx == 1) break;
         } else {
             break;
         }
     }
-    if (this_idx != init_idx) {
-        h.id[this_idx] = sym;
-        h.prio[this_idx] = pr;
-    }
+    if (this_idx != init_idx) h.key[this_idx] = mine;
 }
 
 __device__ void heap_extract(HeapMem &h, uint32_t &len, uint16_t &osym, uint64_t &oprio) // :225-267
 {
-    const uint16_t lsym = h.id[len];
-    const uint64_t lpr = h.prio[len];
+    const uint64_t lk = h.key[len];
+    const uint64_t lpr = lk >> HEAP_ID_BITS;
     len--;
     if (len == 0) {
-        osym = lsym;
+        osym = (uint16_t)(lk & ((1u << HEAP_ID_BITS) - 1u));
         oprio = lpr;
         return;
     }
-    osym = h.id[1];
-    oprio = h.prio[1];
+    const uint64_t top = h.key[1];
+    osym = (uint16_t)(top & ((1u << HEAP_ID_BITS) - 1u));
+    oprio = top >> HEAP_ID_BITS;
     uint32_t this_idx = 1;
     for (;;) {
         const uint32_t left = this_idx << 1;
         if (left > len) break;
         const uint32_t right = left + 1;
         uint32_t below = left;
-        uint64_t bp = h.prio[left];
+        uint64_t bk = h.key[left];
         if (right <= len) {
-            const uint64_t rp = h.prio[right];
-            if (rp < bp) {
+            const uint64_t rk = h.key[right];
+            if ((rk >> HEAP_ID_BITS) < (bk >> HEAP_ID_BITS)) {
                 below = right;
-                bp = rp;
+                bk = rk;
             }
         }
-        if (lpr < bp) break;
-        h.prio[this_idx] = bp;
-        h.id[this_idx] = h.id[below];
+        if (lpr < (bk >> HEAP_ID_BITS)) break;
+        h.key[this_idx] = bk;
         this_idx = below;
     }
-    h.id[this_idx] = lsym;
-    h.prio[this_idx] = lpr;
+    h.key[this_idx] = lk;
 }
 
 __device__ void build_lengths(HeapMem &h, uint32_t nsyms, uint8_t *out) // :271-298
