@@ -1061,8 +1061,12 @@ __global__ void __launch_bounds__(256) tail_finish(TailArgs a)
             const uint32_t nr = (uint32_t)(x[k] >> 40) & 0xFFFFFu;
             const bool res = (x[k] >> 60) & 1ull;
             rank[i] = res ? (nr | RANK_RESOLVED) : nr;
-            sa[(uint32_t)(x[k] >> 20) & 0xFFFFFu] = i;
-            if (res) x[k] = LIST_INVALID;
+            // SA entries matter once final: a block in TAIL mode never runs a SWEEP again (the only
+            // reader of provisional SA order), so unresolved suffixes write theirs when they resolve
+            if (res) {
+                sa[(uint32_t)(x[k] >> 20) & 0xFFFFFu] = i;
+                x[k] = LIST_INVALID;
+            }
         }
         const u64 m = __ballot(x[k] != LIST_INVALID);
         lo[k] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
