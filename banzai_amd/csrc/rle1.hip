@@ -338,6 +338,14 @@ __device__ __forceinline__ Gran gran_eval(const PlanArrays &pa, uint32_t g, uint
     return r;
 }
 
+// First run start at a position > s (n if there is none), from an already evaluated granule g = s / GRAN.
+__device__ __forceinline__ uint32_t next_start_in(const PlanArrays &pa, const Gran &gr, uint32_t g, uint32_t s)
+{
+    const unsigned long long m = __ballot(gr.valid && gr.pos > s && gr.start);
+    if (m) return g * GRAN + (uint32_t)__ffsll((long long)m) - 1u;
+    return pa.nrsg[g + 1 <= pa.ngran ? g + 1 : pa.ngran];
+}
+
 // First run start at a position > s (n if there is none).
 __device__ __forceinline__ uint32_t next_start_after(const PlanArrays &pa, uint32_t s, uint32_t lane)
 {
@@ -358,8 +366,12 @@ __global__ void __launch_bounds__(64) plan_split(PlanArrays pa)
     const uint32_t N = (uint32_t)pa.n, M = pa.M, NT = pa.ntiles;
     const uint64_t total = pa.tc[NT];
     uint32_t s = 0, nb = 0;
+    // The granule the previous cut fell into is usually also the one the next block starts in: keep its
+    // evaluation (run starts + canonical offsets per byte) instead of recomputing it twice per block.
+    Gran cg_eval{};
+    uint32_t cg_idx = 0xFFFFFFFFu;
     while (s < N && nb < pa.maxblocks) {
-        const uint32_t e_first = next_start_after(pa, s, lane);
+        const uint32_t e_first = (s / GRAN == cg_idx) ? next_start_in(pa, cg_eval, cg_idx, s) : next_start_after(pa, s, lane);
         const uint32_t Lr = e_first - s;
         const uint32_t A = canon_len(Lr);
         uint32_t consumed, out, open = 0;
@@ -376,8 +388,11 @@ __global__ void __launch_bounds__(64) plan_split(PlanArrays pa)
             if (e_first >= N) {
                 Ce = total;
             } else {
-                const Gran ge = gran_eval(pa, e_first / GRAN, lane);
-                Ce = __shfl(ge.cpos, (int)(e_first % GRAN), 64);
+                if (e_first / GRAN != cg_idx) {
+                    cg_eval = gran_eval(pa, e_first / GRAN, lane);
+                    cg_idx = e_first / GRAN;
+                }
+                Ce = __shfl(cg_eval.cpos, (int)(e_first % GRAN), 64);
             }
             const uint64_t lim = (uint64_t)(M - A) + Ce; // largest canonical offset that still fits
             if (total <= lim) { // everything to the end of the input fits
@@ -419,7 +434,11 @@ __global__ void __launch_bounds__(64) plan_split(PlanArrays pa)
                 const uint32_t gidx = gb + lane;
                 const bool gok = (uint64_t)gidx * GRAN < pa.n && pa.tc[tl] + pa.cg[gidx] <= lim;
                 const uint32_t gx = gb + (uint32_t)__popcll(__ballot(gok)) - 1u; // lane 0 always ok
-                const Gran gr = gran_eval(pa, gx, lane);
+                if (gx != cg_idx) {
+                    cg_eval = gran_eval(pa, gx, lane);
+                    cg_idx = gx;
+                }
+                const Gran &gr = cg_eval;
                 // last run start in the granule that still fits, else the run covering the granule
                 const unsigned long long fit = __ballot(gr.start && gr.cpos <= lim);
                 uint32_t x;
@@ -433,7 +452,7 @@ __global__ void __launch_bounds__(64) plan_split(PlanArrays pa)
                     Cx = __shfl(gr.cpos, 0, 64) - emitted_before(gx * GRAN - x);
                 }
                 const uint32_t R = (uint32_t)(lim - Cx); // budget left for the run starting at x
-                const uint32_t xe = next_start_after(pa, x, lane);
+                const uint32_t xe = (x / GRAN == cg_idx) ? next_start_in(pa, cg_eval, cg_idx, x) : next_start_after(pa, x, lane);
                 const uint32_t Lx = xe - x;
                 open = xe >= N && (uint64_t)Lx < 255ull * (R / 5u + 2u);
                 uint32_t k, t;
