@@ -248,12 +248,21 @@ __global__ void __launch_bounds__(RL_THREADS) plan_granules(PlanArrays pa)
     }
     uint32_t tot;
     const uint32_t ps = block_excl_add(tsum, ls, &tot);
-    // suffix min of first run starts over the threads of the tile (Hillis-Steele, 8 steps)
-    for (uint32_t dd = 1; dd < RL_THREADS; dd <<= 1) {
-        const uint32_t x = threadIdx.x + dd < RL_THREADS ? sfirst[threadIdx.x + dd] : NONE32;
+    // suffix min of first run starts over the threads of the tile: shuffles inside the wavefront,
+    // then the later wavefronts' minima through LDS (one barrier)
+    {
+        const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        uint32_t sf = sfirst[threadIdx.x];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t x = (uint32_t)__shfl_down((int)sf, d, 64);
+            if (ln + d < 64) sf = min(sf, x);
+        }
+        __shared__ uint32_t wmin[RL_THREADS / 64];
+        if (ln == 0) wmin[wv] = sf;
         __syncthreads();
-        sfirst[threadIdx.x] = min(sfirst[threadIdx.x], x);
-        __syncthreads();
+        for (int w = wv + 1; w < RL_THREADS / 64; w++) sf = min(sf, wmin[w]);
+        sfirst[threadIdx.x] = sf;
     }
     if ((threadIdx.x & 3u) == 0) {
         const size_t g = (size_t)tile * GRAN_PER_TILE + (threadIdx.x >> 2);
