@@ -64,6 +64,8 @@ SIGNATURES = {
     "bzh_stream_consumed": (ctypes.c_size_t, [ctypes.c_void_p]),
     "bzh_plan_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, szp]),
     "bzh_plan_blocks": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Block), ctypes.c_size_t]),
+    "bzh_plan_device_nocrc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, szp]),
+    "bzh_plan_crc_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t]),
     "bzh_encode_range_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p,
                                                ctypes.c_size_t, u64p]),
     "bzh_assemble_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), u64p, ctypes.c_size_t,
@@ -262,14 +264,27 @@ class Context:
                                            ctypes.byref(olen), ctypes.byref(used)))
         return int(olen.value)
 
-    def plan_device(self, d_in, n):
+    def plan_device(self, d_in, n, crc=True):
+        """-> [(in_off, in_len, rle_len, crc)]; crc=False leaves the CRCs (0 here) to encode_range_device /
+        plan_crc_range (the sharded path: a rank only needs the CRCs of the blocks it encodes)"""
         nb = ctypes.c_size_t(0)
-        self.check(lib().bzh_plan_device(self._h, ctypes.c_void_p(d_in), n, ctypes.byref(nb)))
-        blocks = (Block * max(1, nb.value))()
-        self.check(lib().bzh_plan_blocks(self._h, blocks, max(1, nb.value)))
+        fn = lib().bzh_plan_device if crc else lib().bzh_plan_device_nocrc
+        self.check(fn(self._h, ctypes.c_void_p(d_in), n, ctypes.byref(nb)))
+        self._nblocks = nb.value
+        return self.plan_blocks()
+
+    def plan_blocks(self):
+        n = getattr(self, "_nblocks", 0)
+        blocks = (Block * max(1, n))()
+        self.check(lib().bzh_plan_blocks(self._h, blocks, max(1, n)))
         # one numpy view instead of 4 ctypes field reads per block (≈ 1 ms per 1000 blocks otherwise)
-        arr = np.frombuffer(blocks, dtype=_BLOCK_DTYPE, count=nb.value)
+        arr = np.frombuffer(blocks, dtype=_BLOCK_DTYPE, count=n)
         return list(zip(arr["in_off"].tolist(), arr["in_len"].tolist(), arr["rle_len"].tolist(), arr["crc"].tolist()))
+
+    def plan_crc_range(self, b0, b1):
+        """CRCs of plan blocks [b0, b1) (computed now unless already known) -> [crc]"""
+        self.check(lib().bzh_plan_crc_range(self._h, b0, b1))
+        return [b[3] for b in self.plan_blocks()[b0:b1]]
 
     def encode_range_device(self, b0, b1, d_out, cap):
         nbits = ctypes.c_uint64(0)

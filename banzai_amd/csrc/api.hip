@@ -666,7 +666,7 @@ static int check_in_ptr(bzh_ctx *ctx, const void *d_in)
     return BZH_OK;
 }
 
-extern "C" int bzh_plan_device(bzh_ctx *ctx, const void *d_in, size_t n, size_t *nblocks)
+static int plan_device(bzh_ctx *ctx, const void *d_in, size_t n, size_t *nblocks, bool with_crc)
 {
     if (ctx) stream_join(ctx);
     if (!ctx || (!d_in && n) || !nblocks) return BZH_E_ARG;
@@ -678,7 +678,7 @@ extern "C" int bzh_plan_device(bzh_ctx *ctx, const void *d_in, size_t n, size_t 
         e0 = bzh_event(ctx);
         hipEventRecord(e0, ctx->stream);
     }
-    BZH_TRY(rle1_plan(ctx, (const uint8_t *)d_in, n));
+    BZH_TRY(rle1_plan(ctx, (const uint8_t *)d_in, n, with_crc));
     if (ctx->profiling) {
         e1 = bzh_event(ctx);
         hipEventRecord(e1, ctx->stream);
@@ -688,6 +688,25 @@ extern "C" int bzh_plan_device(bzh_ctx *ctx, const void *d_in, size_t n, size_t 
     }
     *nblocks = ctx->plan_blocks.size();
     return BZH_OK;
+}
+
+extern "C" int bzh_plan_device(bzh_ctx *ctx, const void *d_in, size_t n, size_t *nblocks)
+{
+    return plan_device(ctx, d_in, n, nblocks, true);
+}
+
+extern "C" int bzh_plan_device_nocrc(bzh_ctx *ctx, const void *d_in, size_t n, size_t *nblocks)
+{
+    return plan_device(ctx, d_in, n, nblocks, false);
+}
+
+extern "C" int bzh_plan_crc_range(bzh_ctx *ctx, size_t b0, size_t b1)
+{
+    if (ctx) stream_join(ctx);
+    if (!ctx || b0 > b1) return BZH_E_ARG;
+    if (b1 > ctx->plan_blocks.size()) return BZH_E_STATE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return rle1_plan_crc(ctx, b0, b1);
 }
 
 extern "C" int bzh_plan_blocks(const bzh_ctx *ctx, bzh_block *out, size_t max_blocks)
@@ -712,6 +731,7 @@ extern "C" int bzh_encode_range_device(bzh_ctx *ctx, size_t b0, size_t b1, void 
     ctx->evnext = 0;
     *nbits = 0;
     if (b0 == b1) return BZH_OK;
+    BZH_TRY(rle1_plan_crc(ctx, b0, b1)); // no-op unless the plan left the CRCs to the encoder
     return encode_range(ctx, b0, b1, (uint8_t *)d_out, cap, 0, nbits);
 }
 

@@ -142,6 +142,7 @@ struct bzh_ctx {
     size_t plan_n = 0;
     std::vector<bzh_block> plan_blocks;
     std::vector<uint8_t> plan_open;     // per block: 1 = cut not final unless the input ends here
+    std::vector<uint8_t> plan_crc_ok;   // per block: CRC computed (bzh_plan_device_nocrc leaves them to the encoder)
     void *plan_ws = nullptr;            // device scratch of the plan (run tables)
     size_t plan_ws_size = 0;
     // staging
@@ -282,7 +283,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal); // bwt.hi
 int mtf_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax);                 // mtf.hip
 int huff_prepare(bzh_ctx *ctx, uint32_t B, uint32_t mmax);            // huffman.hip: tables, header bits, bit totals
 int huff_pack(bzh_ctx *ctx, uint32_t B, uint32_t mmax, uint8_t *d_out, uint64_t bit_base); // huffman.hip
-int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n);           // rle1.hip
+int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n, bool with_crc = true); // rle1.hip
+int rle1_plan_crc(bzh_ctx *ctx, size_t b0, size_t b1);               // rle1.hip: CRCs of plan blocks [b0, b1)
 int rle1_emit(bzh_ctx *ctx, size_t b0, uint32_t B);                   // rle1.hip: fill bt.rle / bt.n / bt.desc
 int crc_device(bzh_ctx *ctx, const uint8_t *d_in, size_t n, uint32_t *crc_out); // rle1.hip
 

@@ -804,10 +804,11 @@ static PlanWs plan_layout(uint8_t *base, uint64_t n, uint32_t M)
 }
 
 // Plan over d_in[0..n): d_in must be 16-byte aligned.
-int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n)
+int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n, bool with_crc)
 {
     hipStream_t st = ctx->stream;
     ctx->plan_blocks.clear();
+    ctx->plan_crc_ok.clear();
     ctx->plan_in = d_in;
     ctx->plan_n = n;
     if (n == 0) return BZH_OK;
@@ -845,20 +846,6 @@ int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n)
     std::vector<BlockDesc> hb(nb);
     HIP_TRY(ctx, hipMemcpyAsync(hb.data(), pa.blocks, nb * sizeof(BlockDesc), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, bzh_stream_wait(st));
-    uint64_t maxlen = 0;
-    for (auto &d : hb) maxlen = d.in_len > maxlen ? d.in_len : maxlen;
-    // block CRCs
-    const CrcTables *ct = nullptr;
-    BZH_TRY(crc_tables(ctx, &ct));
-    HIP_TRY(ctx, hipMemsetAsync(w.crcacc, 0, (size_t)nb * 4, st));
-    const uint32_t ctiles = (uint32_t)((maxlen + CRC_TILE - 1) / CRC_TILE);
-    for (uint32_t b0 = 0; b0 < nb; b0 += 32768) { // grid.y limit
-        const uint32_t cnt = nb - b0 < 32768 ? nb - b0 : 32768;
-        crc_tiles<<<dim3(ctiles, cnt), RL_THREADS, 0, st>>>(d_in, pa.blocks + b0, w.crcacc + b0, ct);
-    }
-    crc_finish<<<dim3(nb), 64, 0, st>>>(pa.blocks, w.crcacc, nb, ct);
-    HIP_TRY(ctx, hipMemcpyAsync(hb.data(), pa.blocks, nb * sizeof(BlockDesc), hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, bzh_stream_wait(st));
     HIP_TRY(ctx, hipGetLastError());
     {
         std::vector<BlockAux> hax(nb);
@@ -872,7 +859,43 @@ int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n)
         ctx->plan_blocks[b].in_off = hb[b].in_off;
         ctx->plan_blocks[b].in_len = hb[b].in_len;
         ctx->plan_blocks[b].rle_len = hb[b].rle_len;
-        ctx->plan_blocks[b].crc = hb[b].crc;
+        ctx->plan_blocks[b].crc = 0;
+    }
+    ctx->plan_crc_ok.assign(nb, 0);
+    if (with_crc) BZH_TRY(rle1_plan_crc(ctx, 0, nb));
+    return BZH_OK;
+}
+
+// Block CRCs (lib/crc32.rs:31-48 over the raw bytes each block consumed) of plan blocks [b0, b1): into
+// the device descriptors (the block headers read them there) and into ctx->plan_blocks.
+int rle1_plan_crc(bzh_ctx *ctx, size_t b0, size_t b1)
+{
+    if (b1 > ctx->plan_blocks.size() || b0 > b1) return BZH_E_STATE;
+    while (b0 < b1 && ctx->plan_crc_ok[b0]) b0++;
+    while (b1 > b0 && ctx->plan_crc_ok[b1 - 1]) b1--;
+    if (b0 == b1) return BZH_OK;
+    hipStream_t st = ctx->stream;
+    PlanWs w = plan_layout((uint8_t *)ctx->plan_ws, ctx->plan_n, ctx->M);
+    PlanArrays &pa = w.pa;
+    const uint32_t nb = (uint32_t)(b1 - b0);
+    uint64_t maxlen = 0;
+    for (size_t b = b0; b < b1; b++) maxlen = std::max<uint64_t>(maxlen, ctx->plan_blocks[b].in_len);
+    const CrcTables *ct = nullptr;
+    BZH_TRY(crc_tables(ctx, &ct));
+    HIP_TRY(ctx, hipMemsetAsync(w.crcacc + b0, 0, (size_t)nb * 4, st));
+    const uint32_t ctiles = (uint32_t)((maxlen + CRC_TILE - 1) / CRC_TILE);
+    for (uint32_t k0 = 0; k0 < nb; k0 += 32768) { // grid.y limit
+        const uint32_t cnt = nb - k0 < 32768 ? nb - k0 : 32768;
+        crc_tiles<<<dim3(ctiles, cnt), RL_THREADS, 0, st>>>(ctx->plan_in, pa.blocks + b0 + k0, w.crcacc + b0 + k0, ct);
+    }
+    crc_finish<<<dim3(nb), 64, 0, st>>>(pa.blocks + b0, w.crcacc + b0, nb, ct);
+    std::vector<BlockDesc> hb(nb);
+    HIP_TRY(ctx, hipMemcpyAsync(hb.data(), pa.blocks + b0, nb * sizeof(BlockDesc), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, bzh_stream_wait(st));
+    HIP_TRY(ctx, hipGetLastError());
+    for (uint32_t k = 0; k < nb; k++) {
+        ctx->plan_blocks[b0 + k].crc = hb[k].crc;
+        ctx->plan_crc_ok[b0 + k] = 1;
     }
     return BZH_OK;
 }

@@ -10,9 +10,12 @@ cursor between iterations).
 The `engine` is the per-rank compute: on a GPU box it is DeviceEngine (libbzhip.so through the
 C ABI); the CPU tests pass their own engine so that partitioning, gather order and assembly are
 exercised under gloo without a GPU.  An engine provides
-    plan()                         -> [(in_off, in_len, rle_len, crc)]  (identical on every rank)
+    plan()                         -> [(in_off, in_len, rle_len, crc)]  (identical cuts on every rank; the crc
+                                      field may be 0: block CRCs are only needed from the rank that encodes)
     encode_range(b0, b1)           -> (buffer tensor uint8 [cap], nbits)
-    assemble(segments, crcs)       -> stream length; segments = [(tensor, nbits)] in rank order
+    crcs(b0, b1)                   -> [crc] of blocks [b0, b1), valid after encode_range(b0, b1)
+    assemble(segments, crcs)       -> stream length; segments = [(tensor, nbits)] in rank order,
+                                      crcs = all block CRCs in block order
     cap                            -> fixed gather slab size in bytes (same on every rank)
 """
 
@@ -27,14 +30,22 @@ def encode_sharded(engine, dist=None, rank=0, world=1):
     import torch
 
     blocks = engine.plan()
-    b0, b1 = block_range(len(blocks), rank, world)
+    nblk = len(blocks)
+    b0, b1 = block_range(nblk, rank, world)
     part, nbits = engine.encode_range(b0, b1)
+    own = engine.crcs(b0, b1)
     if world == 1:
-        return engine.assemble([(part, nbits)], [b[3] for b in blocks])
-    bits = torch.tensor([nbits], dtype=torch.int64, device=part.device)
-    all_bits = torch.zeros(world, dtype=torch.int64, device=part.device)
-    dist.all_gather_into_tensor(all_bits, bits)
-    nb = all_bits.tolist()  # one read-back for all ranks' lengths
+        return engine.assemble([(part, nbits)], own)
+    # one small all-gather carries every rank's bit count and block CRCs (ranges differ by at most one block)
+    width = 1 + (nblk + world - 1) // world
+    meta = torch.zeros(width, dtype=torch.int64, device=part.device)
+    meta[0] = nbits
+    if own:
+        meta[1:1 + len(own)] = torch.tensor(own, dtype=torch.int64, device=part.device)
+    allmeta = torch.zeros(world * width, dtype=torch.int64, device=part.device)
+    dist.all_gather_into_tensor(allmeta, meta)
+    rows = allmeta.view(world, width).tolist()  # one read-back
+    nb = [int(r[0]) for r in rows]
     # gather only as many bytes as the longest bit string needs (whole 32-bit words), not the slab capacity
     used = min(engine.cap, (max(nb) + 31) // 32 * 4)
     send = part[:used]
@@ -42,8 +53,12 @@ def encode_sharded(engine, dist=None, rank=0, world=1):
     dist.gather(send, slabs, dst=0)  # encoded blocks -> rank 0 (RCCL over xGMI on a GPU node)
     if rank != 0:
         return 0
+    crcs = []
+    for k in range(world):
+        k0, k1 = block_range(nblk, k, world)
+        crcs += [int(c) for c in rows[k][1:1 + (k1 - k0)]]
     segs = [(slabs[k], nb[k]) for k in range(world)]
-    return engine.assemble(segs, [b[3] for b in blocks])
+    return engine.assemble(segs, crcs)
 
 
 class DeviceEngine:
@@ -57,7 +72,10 @@ class DeviceEngine:
         self.part = torch.zeros(seg_cap, dtype=torch.uint8, device=d_in.device)
 
     def plan(self):
-        return self.ctx.plan_device(self.d_in.data_ptr(), self.n)
+        return self.ctx.plan_device(self.d_in.data_ptr(), self.n, crc=False)
+
+    def crcs(self, b0, b1):
+        return [b[3] for b in self.ctx.plan_blocks()[b0:b1]]  # encode_range_device computed them
 
     def encode_range(self, b0, b1):
         nbits = self.ctx.encode_range_device(b0, b1, self.part.data_ptr(), self.cap)

@@ -127,6 +127,14 @@ BZH_API size_t bzh_stream_consumed(const bzh_ctx *ctx);
 BZH_API int bzh_plan_device(bzh_ctx *ctx, const void *d_in, size_t n, size_t *nblocks);
 BZH_API int bzh_plan_blocks(const bzh_ctx *ctx, bzh_block *out, size_t max_blocks);
 
+/* The same split without the block CRCs (their `crc` fields read 0): for the sharded path, where every
+ * rank splits the whole input but only encodes its own blocks.  bzh_encode_range_device computes the
+ * CRCs of the range it encodes (they go into the block headers); bzh_plan_crc_range computes them on
+ * request; afterwards bzh_plan_blocks reports them.  The rank that assembles the stream needs all of
+ * them (bzh_assemble_device's block_crcs), so the ranks exchange them with their bit strings. */
+BZH_API int bzh_plan_device_nocrc(bzh_ctx *ctx, const void *d_in, size_t n, size_t *nblocks);
+BZH_API int bzh_plan_crc_range(bzh_ctx *ctx, size_t b0, size_t b1);
+
 /* Encode blocks [b0, b1) of the plan: per block the header (lib/lib.rs:24-36), symbol map
  * (:39-64) and Huffman payload (lib/huffman.rs:313-575), bit-concatenated from bit 0 of d_out
  * (MSB first, lib/out.rs), zero padded to a 4-byte multiple.  No stream header/footer. */

@@ -25,6 +25,7 @@ for it in range(3):
     b0, b1 = sharded.block_range(len(blocks), N // 2, N)
     part, nbits = eng.encode_range(b0, b1); sync(); t2 = time.perf_counter()
     segs = [(part, nbits)] * N
-    crcs = [b[3] for b in blocks]
+    crcs = [0] * len(blocks)  # timing only: the other ranks' CRCs would arrive with the gather
+    crcs[b0:b1] = eng.crcs(b0, b1)
     n_out = eng.assemble(segs, crcs); sync(); t3 = time.perf_counter()
     print(f"N={N} blocks={len(blocks)} own={b1-b0} plan {1e3*(t1-t0):.2f} ms  encode_range {1e3*(t2-t1):.2f} ms  assemble({N} segs, {nbits//8/1e6:.1f} MB each) {1e3*(t3-t2):.2f} ms  total {1e3*(t3-t0):.2f}", flush=True)

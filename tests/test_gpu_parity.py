@@ -287,6 +287,41 @@ def test_device_path_and_sharded_equals_monolithic(oracle, native):
         assert d_out[:ln2].cpu().numpy().tobytes() == want
 
 
+def test_plan_without_crcs_then_per_range(oracle, native):
+    """the sharded path's plan: cuts without CRCs; encode_range computes those of its range, the rest
+    stay 0 until asked for; assembling with the collected CRCs gives the stream; DeviceEngine end to end"""
+    import torch
+    from banzai_amd import corpus, sharded
+    n = 6_000_123
+    data = corpus.enwik_synthetic(n, seed=11)
+    want = oracle.encode(data.tobytes(), 9)
+    dev = torch.device("cuda", 0)
+    d_in = torch.zeros(n + 16, dtype=torch.uint8, device=dev)
+    d_in[:n] = torch.from_numpy(data).to(dev)
+    cap = (n // 2 + (1 << 20)) & ~3
+    d_out = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    with native.Context(0, 9, 8) as ctx:
+        full = ctx.plan_device(d_in.data_ptr(), n)
+        blocks = ctx.plan_device(d_in.data_ptr(), n, crc=False)
+        assert [b[:3] for b in blocks] == [b[:3] for b in full] and all(b[3] == 0 for b in blocks)
+        nb = len(blocks)
+        mid = nb // 2
+        buf0 = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        bits0 = ctx.encode_range_device(0, mid, buf0.data_ptr(), cap)
+        got = ctx.plan_blocks()
+        assert [b[3] for b in got[:mid]] == [b[3] for b in full[:mid]] and all(b[3] == 0 for b in got[mid:])
+        assert ctx.plan_crc_range(mid, nb) == [b[3] for b in full[mid:]]
+        buf1 = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        bits1 = ctx.encode_range_device(mid, nb, buf1.data_ptr(), cap)
+        crcs = [b[3] for b in ctx.plan_blocks()]
+        ln = ctx.assemble_device([(buf0.data_ptr(), bits0), (buf1.data_ptr(), bits1)], crcs, d_out.data_ptr(), cap)
+        assert d_out[:ln].cpu().numpy().tobytes() == want
+        d_out.zero_()
+        eng = sharded.DeviceEngine(ctx, d_in, n, d_out, cap)
+        ln = sharded.encode_sharded(eng)
+        assert d_out[:ln].cpu().numpy().tobytes() == want
+
+
 def test_two_lanes_same_bytes(oracle, native):
     """bzh_set_lanes(2): half-batches prepared concurrently on two internal streams, packed in order"""
     d = cases.gen(3_000_001, "text", 9) + cases.repeats(1_500_000, 9) + cases.gen(400_000, "longruns", 9)

@@ -34,7 +34,11 @@ class OracleEngine:
     def plan(self):
         _, infos = self.o.encode(self.data, self.level, want_blocks=True)
         self.blocks = [(int(b.in_off), int(b.in_len), int(b.rle_len), int(b.crc)) for b in infos]
-        return self.blocks
+        # like the device engine, hand out the cuts without CRCs: a rank only knows the CRCs of its own blocks
+        return [(o, ln, r, 0) for o, ln, r, _ in self.blocks]
+
+    def crcs(self, b0, b1):
+        return [b[3] for b in self.blocks[b0:b1]]
 
     def encode_range(self, b0, b1):
         buf = torch.zeros(self.cap, dtype=torch.uint8)
