@@ -91,7 +91,7 @@ static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
     bt.nactB = bt.nactA + 2 * NB;
     bt.nactC = bt.nactA + 4 * NB;
     bt.maxgrp = nullptr; // = count array + NB, see bwt_run
-    carve(p, bt.gateR, 2 * NB);
+    carve(p, bt.gateR, 3 * NB); // radix gates, tail gates, depth of every TAIL block
     bt.gateT = bt.gateR + NB;
     carve(p, bt.errflag, 64);
     carve(p, bt.alive, NB * ((S + 2047) / 2048));

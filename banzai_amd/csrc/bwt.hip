@@ -788,7 +788,8 @@ struct TailArgs {
     u64 *stat;           // tile status words of tail_finish's look-back (inside the block's hist rows)
     uint32_t pass;       // pass id in those words
     uint32_t *err;       // [1] precondition violations
-    uint32_t S, h, T, B, TT;
+    const uint32_t *hb;  // [B] depth h of each block (TAIL blocks advance on their own: x4 while the radix path doubles)
+    uint32_t S, T, B, TT;
 };
 
 // record: [resolved:1 @60][new rank:20 @40][SA position:20 @20][suffix:20 @0]
@@ -805,7 +806,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) tail_sort(TailArgs a)
     const uint32_t s_lo = r0 >= (uint32_t)TAIL_G ? r0 - TAIL_G : 0u;
     const uint32_t s_hi = min(len, r1 + (uint32_t)TAIL_G);
     const uint32_t nwin = s_hi - s_lo;
-    const uint32_t n = a.n[b];
+    const uint32_t n = a.n[b], h = a.hb[b];
     const size_t base = (size_t)b * a.S;
     const u64 *buf = ((lenw & TAIL_BUF_B) ? a.bufB : a.bufA) + base; // read only during this kernel
     u64 *out = ((lenw & TAIL_BUF_B) ? a.bufA : a.bufB) + base;       // records, same slot numbering
@@ -904,14 +905,14 @@ __global__ void __launch_bounds__(TAIL_THREADS) tail_sort(TailArgs a)
                 if (s_lo + (ci[j] >> 20) - fs >= (uint32_t)TAIL_G) bad = true; // span beyond the window guarantee
                 const uint32_t i = ci[j] & (uint32_t)SUF_MASK;
                 uint32_t k2, k3 = 0, k4 = 0;
-                if (a.h < n) {
-                    uint32_t i2 = i + a.h;
+                if (h < n) {
+                    uint32_t i2 = i + h;
                     if (i2 >= n) i2 -= n;
                     k2 = rank[i2] & RANK_MASK;
                     if (QUAD) { // two more h-blocks of the (cyclic) rotation
-                        uint32_t i3 = i2 + a.h;
+                        uint32_t i3 = i2 + h;
                         if (i3 >= n) i3 -= n;
-                        uint32_t i4 = i3 + a.h;
+                        uint32_t i4 = i3 + h;
                         if (i4 >= n) i4 -= n;
                         k3 = rank[i3] & RANK_MASK;
                         k4 = rank[i4] & RANK_MASK;
@@ -1154,16 +1155,14 @@ __global__ void __launch_bounds__(256) bwt_emit(Batch bt, uint32_t T, uint32_t B
 // costs a launch-sized gap.
 constexpr uint32_t SETUP_MAX = 256;
 struct RoundSetup {
-    uint32_t gates[2 * SETUP_MAX]; // [0, mb): radix gates, [mb, 2 mb): tail gates
+    uint32_t gates[3 * SETUP_MAX]; // [0, mb): radix gates, [mb, 2 mb): tail gates, [2 mb, 3 mb): depth h of TAIL blocks
 };
 __global__ void __launch_bounds__(256) round_setup(RoundSetup rs, uint32_t *gateR, uint32_t *zero, uint32_t mb, uint32_t dtot_words,
                                                    uint32_t *dtot)
 {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t < 2 * mb) {
-        gateR[t] = rs.gates[t]; // gateT follows gateR in memory
-        zero[t] = 0;
-    }
+    if (t < 3 * mb) gateR[t] = rs.gates[t]; // gateT and gateH follow gateR in memory
+    if (t < 2 * mb) zero[t] = 0;
     for (uint32_t k = t; k < dtot_words; k += gridDim.x * 256) dtot[k] = 0; // ACTIVE rounds: digit totals
 }
 
@@ -1344,9 +1343,11 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     uint32_t *hn = ctx->h_pinned + 2 * mb;   // block lengths
     uint32_t *hgR = ctx->h_pinned + 3 * mb;  // gates uploaded each round
     uint32_t *hgT = ctx->h_pinned + 4 * mb;
+    uint32_t *hgH = ctx->h_pinned + 5 * mb;  // depth of every TAIL block
     HIP_TRY(ctx, hipMemcpyAsync(hn, bt.n, B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     std::vector<uint32_t> hprev(B), taillen(B, 0); // frozen slots once in TAIL mode
     std::vector<uint8_t> tailmode(B, 0);
+    std::vector<uint32_t> htail(B, 0); // a TAIL block's own depth: it may advance x4 while the radix path doubles
     bool active_mode = false, have_n = false;
     bool have_list = true; // `cur` holds the list ACTIVE / TAIL need (the initial one, or refine's compacted one)
     const uint32_t *prevcnt = nullptr; // (the list in `cur` is dense after the first round: its length is nact)
@@ -1371,11 +1372,13 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         }
         // per-block mode: a block whose groups all fit a tail window leaves the radix path for good
         uint32_t maxact = 0, prevmax = 0, maxtail = 0;
-        uint64_t sum = 0, nsum = 0, tot = 0;
+        uint64_t sum = 0, nsum = 0, tot = 0, tailtot = 0;
+        uint32_t maxh = 0;
         for (uint32_t b = 0; b < B; b++) {
             tot += hact[b];
             if (!tailmode[b] && have_list && hact[b] && hmax[b] <= (uint32_t)TAIL_G) {
                 tailmode[b] = 1;
+                htail[b] = h;
                 // the sorted list in `cur` keeps this many slots, in this buffer, from now on
                 taillen[b] = (round == 0 ? hn[b] : hact[b]) | (cur == bufB ? TAIL_BUF_B : 0u);
             }
@@ -1385,10 +1388,14 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
                 tailmode[b] = 2;
                 hgR[b] = 0;
                 hgT[b] = hact[b] ? taillen[b] : 0;
+                hgH[b] = htail[b];
+                tailtot += hact[b];
+                if (hact[b]) maxh = htail[b] > maxh ? htail[b] : maxh;
                 maxtail = (hgT[b] & TAIL_LEN) > maxtail ? (hgT[b] & TAIL_LEN) : maxtail;
             } else {
                 hgR[b] = hact[b];
                 hgT[b] = 0;
+                hgH[b] = 0;
                 maxact = hact[b] > maxact ? hact[b] : maxact;
                 if (hact[b]) {
                     const uint32_t L = round == 0 ? hn[b] : hact[b]; // length of the list in `cur`
@@ -1433,21 +1440,22 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         const bool active_round = maxact && active_mode;
         if (mb <= SETUP_MAX) {
             RoundSetup rs;
-            memcpy(rs.gates, hgR, 2 * mb * sizeof(uint32_t)); // hgT follows hgR in the pinned block
+            memcpy(rs.gates, hgR, 3 * mb * sizeof(uint32_t)); // hgT and hgH follow hgR in the pinned block
             const uint32_t dw = active_round ? B * DB_STRIDE : 0u;
-            round_setup<<<dim3(active_round ? 64 : (2 * mb + 255) / 256), 256, 0, st>>>(rs, bt.gateR, nact_next, mb, dw, bt.dtot);
+            round_setup<<<dim3(active_round ? 64 : (3 * mb + 255) / 256), 256, 0, st>>>(rs, bt.gateR, nact_next, mb, dw, bt.dtot);
         } else {
             HIP_TRY(ctx, hipMemsetAsync(nact_next, 0, 2 * mb * sizeof(uint32_t), st));
-            HIP_TRY(ctx, hipMemcpyAsync(bt.gateR, hgR, 2 * mb * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            HIP_TRY(ctx, hipMemcpyAsync(bt.gateR, hgR, 3 * mb * sizeof(uint32_t), hipMemcpyHostToDevice, st));
             if (active_round) HIP_TRY(ctx, hipMemsetAsync(bt.dtot, 0, (size_t)B * DB_STRIDE * sizeof(uint32_t), st));
         }
 
         a.h = h;
         a.recrank = round > 0; // every refine after the initial one writes ranks back into the list
         a.gate = bt.gateR;
-        // with only TAIL blocks left a round may look three h-blocks ahead: depth 4h instead of 2h
-        // (three gathers per suffix: only once few suffixes are left, where rounds are latency-bound)
-        const bool quad = maxact == 0 && h < (1u << 28) && tot * 10 < ntotal;
+        // a TAIL round may look three h-blocks ahead: depth 4h instead of 2h (three gathers per suffix:
+        // only once few suffixes are left in TAIL blocks, where rounds are latency-bound).  TAIL blocks
+        // carry their own depth, so blocks still on the radix path do not hold them back.
+        const bool quad = maxh < (1u << 28) && tailtot * 10 < ntotal;
         u64 *next_cur = cur, *next_oth = oth;
         if (!maxact) {
             // every unresolved block is in TAIL mode
@@ -1513,7 +1521,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         }
         if (maxtail) { // blocks in TAIL mode: in place in their own buffer, independent of cur/oth
             ta.nact_next = nact_next;
-            ta.h = h;
+            ta.hb = bt.gateR + 2 * mb;
             ta.recrank = round > 0;
             ta.T = (maxtail + TAIL_T - 1) / TAIL_T;
             ta.B = B;
@@ -1552,7 +1560,9 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             have_list = wbk;
         }
 
-        if (h < (1u << 30)) h <<= quad ? 2 : 1;
+        for (uint32_t b = 0; b < B; b++)
+            if (tailmode[b] && htail[b] < (1u << 30)) htail[b] <<= quad ? 2 : 1;
+        if (h < (1u << 30)) h <<= 1;
     }
     {
         uint32_t err = 0;
