@@ -432,6 +432,16 @@ def test_streaming_small_buffer_is_refused_before_anything_is_consumed(native, o
     assert bytes(out) == oracle.encode(d, 1)
 
 
+def test_public_api_level1_default_batch(oracle):
+    """banzai_amd.encode at level 1: the default batch is 1024 blocks there (same bytes per batch as
+    128 level-9 blocks), which uses the copied-gates path of the round setup"""
+    import banzai_amd
+    d = cases.gen(4_000_001, "text", 17) + cases.repeats(1_000_000, 17) + cases.gen(700_000, "longruns", 17)
+    w = io.BytesIO()
+    assert banzai_amd.encode(io.BytesIO(d), w, 1) == len(d)
+    assert w.getvalue() == oracle.encode(d, 1)
+
+
 def test_streaming_public_api_chunked_reader(oracle):
     import banzai_amd
 
