@@ -577,9 +577,11 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
     const size_t base = (size_t)b * a.S;
     const uint32_t tile0 = tile * SORT_TILE;
     __shared__ u64 lds[STAGE_SLOTS];
-    stage_tile(a.list + base, tile0, cnt, lds);
     const uint32_t e0 = threadIdx.x * SORT_ITEMS, q0 = tile0 + e0;
 
+    // flags first: the tile's unresolved count depends on nothing else, and publishing it before the
+    // (slow: the memory system is saturated by rank scatters) staging of the tile lets the later tiles'
+    // look-back find it in place
     uint32_t packed[4] = {0, 0, 0, 0};
     uint32_t nextflag = 2; // flag of element q0+16 (end of list counts as a boundary)
     if (q0 < cnt) {
@@ -602,6 +604,19 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
             if (WB) ucnt += ((f & 2u) && ((q0 + k + 1 == cnt) || (fn & 2u))) ? 0u : 1u;
         }
     }
+    // compaction of the unresolved records: slot = (unresolved in earlier tiles: look-back over the
+    // tile counts) + (in earlier threads of the tile) + (before the element in the thread)
+    __shared__ uint32_t lsu[SORT_THREADS / 64 + 2];
+    __shared__ uint32_t cpre;
+    uint32_t utot = 0, uoff = 0;
+    u64 *cst = a.cstat + (size_t)b * a.TPB * NBMAX + 192;
+    if (WB) {
+        uoff = block_excl_add(ucnt, lsu, &utot);
+        if (threadIdx.x == 0)
+            __hip_atomic_store(cst + (size_t)tile * NBMAX, look_word(a.cpass, tile ? LOOK_LOCAL : LOOK_GLOBAL, utot),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    stage_tile(a.list + base, tile0, cnt, lds);
     __shared__ int l01[2 * SORT_THREADS / 64];
     __shared__ int ex0[SORT_THREADS], ex1[SORT_THREADS];
     block_incl_max2(tg, td, l01);
@@ -614,23 +629,14 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
         cg = max(cg, ex0[threadIdx.x - 1]);
         cd = max(cd, ex1[threadIdx.x - 1]);
     }
-    // compaction of the unresolved records: slot = (unresolved in earlier tiles: look-back over the
-    // tile counts) + (in earlier threads of the tile) + (before the element in the thread)
-    __shared__ uint32_t lsu[SORT_THREADS / 64 + 2];
-    __shared__ uint32_t cpre;
     uint32_t wslot = 0;
     if (WB) {
-        uint32_t utot;
-        const uint32_t uoff = block_excl_add(ucnt, lsu, &utot);
         if (threadIdx.x == 0) {
-            u64 *st = a.cstat + (size_t)b * a.TPB * NBMAX + 192;
             uint32_t acc = 0, spins = 0;
             if (tile > 0) {
-                __hip_atomic_store(st + (size_t)tile * NBMAX, look_word(a.cpass, LOOK_LOCAL, utot), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
                 int t = (int)tile - 1;
                 while (t >= 0) {
-                    const u64 w = __hip_atomic_load(st + (size_t)t * NBMAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const u64 w = __hip_atomic_load(cst + (size_t)t * NBMAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const uint32_t state = (uint32_t)(w >> 30) & 3u;
                     if ((uint32_t)(w >> 32) != a.cpass || state == 0) {
                         if (++spins > (1u << 26)) {
@@ -644,9 +650,9 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
                     if (state == LOOK_GLOBAL) break;
                     t--;
                 }
+                __hip_atomic_store(cst + (size_t)tile * NBMAX, look_word(a.cpass, LOOK_GLOBAL, acc + utot), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
             }
-            __hip_atomic_store(st + (size_t)tile * NBMAX, look_word(a.cpass, LOOK_GLOBAL, acc + utot), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
             cpre = acc;
         }
         __syncthreads();
