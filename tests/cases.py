@@ -68,3 +68,16 @@ def repeats(n, seed, copies=6):
         b = int(rng.integers(a + ln, max(a + ln + 1, n - ln)))
         out[b:b + ln] = out[a:a + ln]
     return bytes(out)
+
+
+def phrase_groups(n, seed, counts=(700, 1500, 2800)):
+    """random lower-case text with a few 40-byte phrases pasted in hundreds to thousands of times:
+    suffix groups of those sizes survive to depth 32 (too large for the TAIL window), then dissolve"""
+    rng = np.random.default_rng(seed)
+    out = rng.integers(97, 123, n, dtype=np.uint8)
+    for k, c in enumerate(counts):
+        phrase = rng.integers(65, 91, 40, dtype=np.uint8)  # upper case: never occurs by chance
+        pos = rng.choice(max(1, n - 50), size=min(c, max(1, n // 60)), replace=False)
+        for p0 in pos:
+            out[p0:p0 + 40] = phrase
+    return out.tobytes()

@@ -55,6 +55,21 @@ def test_bwt_golden_vectors(ctx9):
         assert b.decode() == c["bwt"] and ptr == c["ptr"], c["input"][:40]
 
 
+def test_bwt_mid_size_groups(oracle, ctx9):
+    """groups of 600..3000 equal 40-byte phrases that survive to depth 32: too large for the TAIL window
+    (512), so these blocks stay on the radix path (ACTIVE rounds) while others in the batch are in TAIL
+    mode at their own depth"""
+    for n, seed, counts in ((600_000, 3, (700, 1500, 2800)), (899_000, 4, (513, 1025, 3072)), (120_000, 5, (600, 900))):
+        d = cases.phrase_groups(n, seed, counts)
+        g, o = ctx9.bwt(d), oracle.bwt(d)
+        assert g[0] == o[0] and g[1] == o[1], (n, seed)
+    blocks = [cases.phrase_groups(500_000, 7), cases.gen(400_000, "text", 1),
+              cases.phrase_groups(880_000, 8, counts=(3000, 600, 1200)), cases.repeats(300_000, 2)]
+    for r, blk in zip(ctx9.bwt_batch(blocks), blocks):
+        o = oracle.bwt(blk)
+        assert r[0] == o[0] and r[1] == o[1]
+
+
 def test_bwt_full_block_config2(oracle, ctx9):
     """BASELINE.json configs[1]: one 899,999-byte block of uniform-random bytes, BWT only"""
     from banzai_amd import corpus
