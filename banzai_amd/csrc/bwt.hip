@@ -86,9 +86,20 @@ constexpr u64 LIST_INVALID = ~0ull; // list slot without an unresolved suffix
 // XCD-aware workgroup -> (bzip2 block, tile) map.  Workgroups are dealt round-robin over the 8
 // XCDs (observed dispatch behaviour, used for speed only): ids congruent mod 8 share an XCD and
 // its private 4 MiB L2.  All tiles of block b get ids = b (mod 8).  Grid = 8*ceil(B/8)*T.
+// With fewer than 8 active blocks that would leave XCDs idle (a single block would run on 32 of the
+// 256 CUs): launches that know they have few active blocks set WG_SPREAD in T and get the plain
+// mapping, consecutive workgroup ids = consecutive tiles of one block, i.e. every block on all XCDs.
+// Either way tile t-1 of a block has a lower workgroup id than tile t (the look-backs rely on it).
+constexpr uint32_t WG_SPREAD = 0x80000000u;
 __device__ __forceinline__ bool wg_map(uint32_t T, uint32_t B, uint32_t &b, uint32_t &tile)
 {
     const uint32_t L = blockIdx.x;
+    if (T & WG_SPREAD) {
+        T &= ~WG_SPREAD;
+        b = L / T;
+        tile = L - b * T;
+        return b < B;
+    }
     const uint32_t slot = L >> 3;
     const uint32_t k = slot / T;
     tile = slot - k * T;
@@ -96,7 +107,10 @@ __device__ __forceinline__ bool wg_map(uint32_t T, uint32_t B, uint32_t &b, uint
     return b < B;
 }
 
-static inline uint32_t xcd_grid(uint32_t tiles, uint32_t B) { return 8u * ((B + 7u) / 8u) * tiles; }
+static inline uint32_t xcd_grid(uint32_t tiles, uint32_t B)
+{
+    return (tiles & WG_SPREAD) ? (tiles & ~WG_SPREAD) * B : 8u * ((B + 7u) / 8u) * tiles;
+}
 
 // 4 bytes of the cyclic text starting at position i (big-endian), i < n.
 __device__ __forceinline__ uint32_t text4(const uint8_t *s, uint32_t i, uint32_t n)
@@ -1125,6 +1139,7 @@ __global__ void __launch_bounds__(256) bwt_emit(Batch bt, uint32_t T, uint32_t B
 {
     uint32_t b, tile;
     if (!wg_map(T, B, b, tile)) return;
+    T &= ~WG_SPREAD;
     const uint32_t n = bt.n[b];
     const size_t base = (size_t)b * bt.S;
     const uint8_t *s = bt.rle + base;
@@ -1179,10 +1194,10 @@ static void launch_pass(bzh_ctx *ctx, SortArgs &a, uint32_t B, uint32_t maxcnt, 
 {
     const uint32_t tiles = (maxcnt + SORT_TILE - 1) / SORT_TILE;
     if (tiles == 0) return;
-    a.T = tiles;
+    a.T = tiles | ctx->wgflag;
     a.B = B;
     a.pass++;
-    radix_scatter<BITS, MODE, REKEY><<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(a);
+    radix_scatter<BITS, MODE, REKEY><<<dim3(xcd_grid(a.T, B)), SORT_THREADS, 0, ctx->stream>>>(a);
     if (ctx->profiling) {
         ctx->stats.bwt_sort_launches += 1;
         ctx->stats.bwt_sort_elems += elems;
@@ -1244,14 +1259,14 @@ static void launch_refine(bzh_ctx *ctx, RefineArgs &r, uint32_t B, uint32_t maxc
 {
     const uint32_t tiles = (maxcnt + SORT_TILE - 1) / SORT_TILE;
     if (tiles == 0) return;
-    r.T = tiles;
+    r.T = tiles | ctx->wgflag;
     r.B = B;
-    flag_tiles<<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(r);
+    flag_tiles<<<dim3(xcd_grid(r.T, B)), SORT_THREADS, 0, ctx->stream>>>(r);
     flag_carry<<<dim3(B), 1024, 0, ctx->stream>>>(r);
     if (r.wb)
-        refine<true><<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(r);
+        refine<true><<<dim3(xcd_grid(r.T, B)), SORT_THREADS, 0, ctx->stream>>>(r);
     else
-        refine<false><<<dim3(xcd_grid(tiles, B)), SORT_THREADS, 0, ctx->stream>>>(r);
+        refine<false><<<dim3(xcd_grid(r.T, B)), SORT_THREADS, 0, ctx->stream>>>(r);
     if (r.dig) sweep_bases<<<dim3(B), 768, 0, ctx->stream>>>(r, ctx->bt.dbase);
 }
 
@@ -1296,6 +1311,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     HIP_TRY(ctx, hipMemsetAsync(bt.dtot, 0, (size_t)B * DB_STRIDE * sizeof(uint32_t), st));
     byte_count<<<dim3(BYTE_SEGS, B), 1024, 0, st>>>(bt.rle, bt.n, bt.dtot, bt.S);
     active_bases<<<dim3(B), 256, 0, st>>>(bt.dtot, bt.dbase, bt.n, 1);
+    ctx->wgflag = B < 8 ? WG_SPREAD : 0u; // the initial sort and its refine run on every block
     hipEvent_t ev_init = span_begin(ctx);
     launch_pass<8, GEN_BYTES4, false>(ctx, a, B, nmax, ntotal);
     u64 *cur = bufA, *oth = bufB;
@@ -1379,7 +1395,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         // per-block mode: a block whose groups all fit a tail window leaves the radix path for good
         uint32_t maxact = 0, prevmax = 0, maxtail = 0;
         uint64_t sum = 0, nsum = 0, tot = 0, tailtot = 0;
-        uint32_t maxh = 0;
+        uint32_t maxh = 0, nrad_act = 0, ntail_act = 0;
         for (uint32_t b = 0; b < B; b++) {
             tot += hact[b];
             if (!tailmode[b] && have_list && hact[b] && hmax[b] <= (uint32_t)TAIL_G) {
@@ -1396,6 +1412,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
                 hgT[b] = hact[b] ? taillen[b] : 0;
                 hgH[b] = htail[b];
                 tailtot += hact[b];
+                ntail_act += hact[b] != 0;
                 if (hact[b]) maxh = htail[b] > maxh ? htail[b] : maxh;
                 maxtail = (hgT[b] & TAIL_LEN) > maxtail ? (hgT[b] & TAIL_LEN) : maxtail;
             } else {
@@ -1403,6 +1420,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
                 hgT[b] = 0;
                 hgH[b] = 0;
                 maxact = hact[b] > maxact ? hact[b] : maxact;
+                nrad_act += hact[b] != 0;
                 if (hact[b]) {
                     const uint32_t L = round == 0 ? hn[b] : hact[b]; // length of the list in `cur`
                     prevmax = L > prevmax ? L : prevmax;
@@ -1455,6 +1473,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             if (active_round) HIP_TRY(ctx, hipMemsetAsync(bt.dtot, 0, (size_t)B * DB_STRIDE * sizeof(uint32_t), st));
         }
 
+        ctx->wgflag = nrad_act < 8 ? WG_SPREAD : 0u; // radix launches of this round
         a.h = h;
         a.recrank = round > 0; // every refine after the initial one writes ranks back into the list
         a.gate = bt.gateR;
@@ -1495,10 +1514,10 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
                 a.cnt = round == 0 ? bt.n : nact; // the initial list holds every suffix, later lists are dense
                 a.src = cur;
                 a.dst = oth;
-                a.T = gt;
+                a.T = gt | ctx->wgflag;
                 a.B = B;
                 if (gt) {
-                    active_gen<<<dim3(xcd_grid(gt, B)), SORT_THREADS, 0, st>>>(a, bt.dtot);
+                    active_gen<<<dim3(xcd_grid(a.T, B)), SORT_THREADS, 0, st>>>(a, bt.dtot);
                     active_bases<<<dim3(B), 256, 0, st>>>(bt.dtot, bt.dbase, bt.gateR, 5);
                 }
                 u64 *c = oth, *o = cur;
@@ -1529,7 +1548,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             ta.nact_next = nact_next;
             ta.hb = bt.gateR + 2 * mb;
             ta.recrank = round > 0;
-            ta.T = (maxtail + TAIL_T - 1) / TAIL_T;
+            ta.T = ((maxtail + TAIL_T - 1) / TAIL_T) | (ntail_act < 8 ? WG_SPREAD : 0u);
             ta.B = B;
             if (quad)
                 tail_sort<true><<<dim3(xcd_grid(ta.T, B)), TAIL_THREADS, 0, st>>>(ta);
@@ -1585,6 +1604,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     uint32_t gx = (nmax + 1023) / 1024;
     if (gx > 256) gx = 256;
     if (gx == 0) gx = 1;
+    if (B < 8) gx |= WG_SPREAD;
     bwt_emit<<<dim3(xcd_grid(gx, B)), 256, 0, st>>>(bt, gx, B);
     HIP_TRY(ctx, hipGetLastError());
     return BZH_OK;

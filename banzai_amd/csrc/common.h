@@ -140,6 +140,7 @@ struct bzh_ctx {
     // plan
     const uint8_t *plan_in = nullptr; // device
     size_t plan_n = 0;
+    uint32_t wgflag = 0;                // WG_SPREAD for the launches of the current group when few blocks are active
     std::vector<bzh_block> plan_blocks;
     std::vector<uint8_t> plan_open;     // per block: 1 = cut not final unless the input ends here
     std::vector<uint8_t> plan_crc_ok;   // per block: CRC computed (bzh_plan_device_nocrc leaves them to the encoder)
