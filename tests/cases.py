@@ -81,3 +81,31 @@ def phrase_groups(n, seed, counts=(700, 1500, 2800)):
         for p0 in pos:
             out[p0:p0 + 40] = phrase
     return out.tobytes()
+
+
+def mixture(rng, max_len):
+    """one random input built from random segments (the shapes the reference's fuzzers stumble on: runs
+    around the RLE1 thresholds, periodic pieces, noise, text, single bytes), total length <= max_len"""
+    out = bytearray()
+    target = rng.randrange(0, max_len + 1)
+    while len(out) < target:
+        kind = rng.randrange(7)
+        ln = min(target - len(out), rng.choice([1, 2, 3, 5, 50, 255, 256, 1000, 5000, 40000]))
+        if kind == 0:
+            out += bytes([rng.randrange(256)]) * ln
+        elif kind == 1:
+            w = bytes(rng.randrange(256) for _ in range(rng.choice([1, 2, 3, 4, 5, 7, 16, 255, 256, 257])))
+            out += (w * (ln // len(w) + 1))[:ln]
+        elif kind == 2:
+            out += bytes(rng.randrange(256) for _ in range(min(ln, 3000)))
+        elif kind == 3:
+            out += (b"the quick brown fox jumps over the lazy dog; " * (ln // 40 + 1))[:ln]
+        elif kind == 4:
+            b = rng.randrange(256)
+            for _ in range(min(ln, 400) // 4 + 1):
+                out += bytes([b]) * rng.choice([3, 4, 5, 254, 255, 256, 259]) + bytes([(b + 1) & 255])
+        elif kind == 5:
+            out += bytes(rng.choice(b"ab") for _ in range(min(ln, 2000)))
+        else:
+            out += out[-min(len(out), ln):] if out else b"x"
+    return bytes(out[:max_len])

@@ -270,6 +270,26 @@ def test_pathological_config5(oracle, ctx9):
     assert bz2.decompress(g) == d and oracle.decode(g) == d
 
 
+def test_fuzz_lite(oracle, native):
+    """seeded stand-in for the reference's fuzz targets (fuzz/fuzz_targets/encode.rs, round_trip.rs):
+    random mixtures at random levels must equal the oracle's stream and decode back to the input"""
+    import random
+    rng = random.Random(20240611)
+    ctxs = {}
+    try:
+        for k in range(70):
+            level = rng.choice([1, 1, 1, 2, 3, 9])
+            d = cases.mixture(rng, rng.choice([0, 10, 1000, 99_999, 100_001, 350_000]))
+            if level not in ctxs:
+                ctxs[level] = native.Context(0, level, 8)
+            g = ctxs[level].encode(d)
+            assert g == oracle.encode(d, level), (k, level, len(d))
+            assert oracle.decode(g) == d, (k, level, len(d))
+    finally:
+        for c in ctxs.values():
+            c.close()
+
+
 # ---- device-resident and sharded paths ------------------------------------------------------------------
 def test_device_path_and_sharded_equals_monolithic(oracle, native):
     """bzh_encode_device == oracle, and plan + 3 x encode_range + assemble (the N>1 protocol, here
