@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--bytes", type=int, default=SEGMENT, help="bytes per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=32_000_000, help="bytes of the workload timed on the CPU oracle")
+    ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="bytes of the workload timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
