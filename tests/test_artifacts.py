@@ -1,0 +1,42 @@
+"""The committed measurement artefacts keep the bench contract: one JSON line with the driver's keys,
+a `roofline` and a `cpu_baseline` object, and a rocprofv3 kernel summary of the same command whose
+average duration for the dominant kernel agrees with the HIP-event figure in the line."""
+import csv
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "profiles")
+
+
+def _line(name):
+    with open(os.path.join(PROF, name)) as f:
+        return json.loads(f.read().strip().splitlines()[-1])
+
+
+def test_bench_line_contract():
+    d = _line("r01_bench_n1.json")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["unit"] == "MB/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["dtype"] == "u8" and d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r) and r["bound"] == "hbm"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    c = d["cpu_baseline"]
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] == "port" and c["cores"] == 1
+    assert all(d["checks"].values())
+    # value is whole-job throughput of the named workload: bytes per step / time per step
+    assert abs(d["value"] - 100_000_000 / d["ms_per_step"] / 1e3) / d["value"] < 0.01
+
+
+def test_rocprof_summary_agrees_with_the_line():
+    d = _line("r01_bench_n1_under_rocprof.json")
+    with open(os.path.join(PROF, "r01_kernel_stats_bench_n1.csv")) as f:
+        rows = [r for r in csv.DictReader(f) if r["Name"].startswith("void radix_scatter")]
+    calls = sum(int(r["Calls"]) for r in rows)
+    mean_us = sum(int(r["TotalDurationNs"]) for r in rows) / calls / 1e3
+    assert calls > 0 and abs(mean_us - d["roofline"]["avg_launch_us"]) / mean_us < 0.05
+    t = json.load(open(os.path.join(PROF, "r01_pmc_traffic.json")))
+    assert t["radix_scatter_all"]["hbm_bytes_per_launch"] > 0
