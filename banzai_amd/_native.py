@@ -66,6 +66,7 @@ SIGNATURES = {
     "bzh_plan_blocks": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Block), ctypes.c_size_t]),
     "bzh_plan_device_nocrc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, szp]),
     "bzh_plan_crc_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t]),
+    "bzh_plan_open": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_size_t]),
     "bzh_encode_range_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p,
                                                ctypes.c_size_t, u64p]),
     "bzh_assemble_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), u64p, ctypes.c_size_t,
@@ -280,6 +281,13 @@ class Context:
         # one numpy view instead of 4 ctypes field reads per block (≈ 1 ms per 1000 blocks otherwise)
         arr = np.frombuffer(blocks, dtype=_BLOCK_DTYPE, count=n)
         return list(zip(arr["in_off"].tolist(), arr["in_len"].tolist(), arr["rle_len"].tolist(), arr["crc"].tolist()))
+
+    def plan_open(self):
+        """per block of the last plan: True if its cut could still move were the input longer"""
+        n = getattr(self, "_nblocks", 0)
+        flags = np.zeros(max(1, n), dtype=np.uint8)
+        self.check(lib().bzh_plan_open(self._h, ptr(flags), max(1, n)))
+        return [bool(x) for x in flags[:n]]
 
     def plan_crc_range(self, b0, b1):
         """CRCs of plan blocks [b0, b1) (computed now unless already known) -> [crc]"""

@@ -709,6 +709,14 @@ extern "C" int bzh_plan_crc_range(bzh_ctx *ctx, size_t b0, size_t b1)
     return rle1_plan_crc(ctx, b0, b1);
 }
 
+extern "C" int bzh_plan_open(const bzh_ctx *ctx, uint8_t *out, size_t max_blocks)
+{
+    if (!ctx || !out) return BZH_E_ARG;
+    if (max_blocks < ctx->plan_open.size()) return BZH_E_CAP;
+    for (size_t k = 0; k < ctx->plan_open.size(); k++) out[k] = ctx->plan_open[k];
+    return BZH_OK;
+}
+
 extern "C" int bzh_plan_blocks(const bzh_ctx *ctx, bzh_block *out, size_t max_blocks)
 {
     if (!ctx || !out) return BZH_E_ARG;

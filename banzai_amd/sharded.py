@@ -1,47 +1,91 @@
 """Block-sharded encode across ranks (one process per GPU), SURVEY.md section 8(e).
 
 bzip2 blocks are independent once the sequential split is known, so the path shards with no
-data-path collective: every rank runs the split on the whole input (replicated, cheap), encodes a
-contiguous range of blocks into a bit string that starts at bit 0, and one gather brings the bit
-strings to rank 0, which funnel-shifts them into the stream and folds the stream CRC in block
-order (reference lib/lib.rs:101-126 carries only `raw`, `stream_crc`, `consumed` and the bit
-cursor between iterations).
+data-path collective.  Ownership goes by START OFFSET: the input is divided at fixed byte offsets
+B_0 = 0 < B_1 < ... < B_world = n and rank r encodes the blocks that start in [B_r, B_{r+1}).  A block's
+cut depends only on the bytes before it (plus a little look-ahead), so rank r splits just the prefix
+of the input up to B_{r+1} plus a margin -- the splitter marks the cuts that could still move if the
+input went on ("open", the streaming rule), everything before the first open block is exact -- instead
+of every rank splitting everything.  The split is the one sequential step (about 3 us per block on one
+wavefront), so the low ranks, whose prefixes are short, get slightly longer ranges (`offsets`).
+Each rank encodes its blocks into a bit string that starts at bit 0; one small all-gather (bit
+counts, block CRCs) and one gather of the bit strings bring everything to rank 0, which funnel-shifts
+them into the stream and folds the stream CRC in block order (reference lib/lib.rs:101-126 carries
+only `raw`, `stream_crc`, `consumed` and the bit cursor between iterations).
 
 The `engine` is the per-rank compute: on a GPU box it is DeviceEngine (libbzhip.so through the
 C ABI); the CPU tests pass their own engine so that partitioning, gather order and assembly are
 exercised under gloo without a GPU.  An engine provides
-    plan()                         -> [(in_off, in_len, rle_len, crc)]  (identical cuts on every rank; the crc
-                                      field may be 0: block CRCs are only needed from the rank that encodes)
-    encode_range(b0, b1)           -> (buffer tensor uint8 [cap], nbits)
-    crcs(b0, b1)                   -> [crc] of blocks [b0, b1), valid after encode_range(b0, b1)
+    n                              -> input length in bytes
+    plan(prefix)                   -> ([(in_off, in_len, rle_len, crc)], [open]) for input[0:prefix]; the crc
+                                      field may be 0 (block CRCs are only needed from the rank that encodes)
+    encode_range(b0, b1)           -> (buffer tensor uint8 [cap], nbits) for blocks [b0, b1) of the last plan
+    crcs(b0, b1)                   -> [crc] of those blocks, valid after encode_range(b0, b1)
     assemble(segments, crcs)       -> stream length; segments = [(tensor, nbits)] in rank order,
                                       crcs = all block CRCs in block order
     cap                            -> fixed gather slab size in bytes (same on every rank)
+    min_block                      -> least number of input bytes a block consumes (bounds blocks per range)
 """
+
+# cost of splitting one more input byte relative to encoding it (plan ~5 us/MB against ~160 us/MB):
+# rank r+1's range is this much shorter than rank r's, which evens out split + encode over the ranks
+PLAN_COST = 0.03
+MARGIN = 4 << 20  # bytes planned beyond the end of the own range; grown when the last own cut is still open
 
 
 def block_range(nblocks, rank, world):
-    """Contiguous share of rank: blocks [b0, b1)."""
+    """Contiguous share of rank by block COUNT: blocks [b0, b1) (used where a full plan is at hand)."""
     return rank * nblocks // world, (rank + 1) * nblocks // world
+
+
+def offsets(n, world):
+    """Range boundaries B_0..B_world (bytes): geometric lengths, ratio 1/(1 + PLAN_COST)."""
+    q = 1.0 / (1.0 + PLAN_COST)
+    w = [q ** r for r in range(world)]
+    tot = sum(w)
+    out, acc = [0], 0.0
+    for r in range(world - 1):
+        acc += w[r]
+        out.append(int(n * acc / tot))
+    out.append(n)
+    return out
+
+
+def own_blocks(engine, rank, world):
+    """Plan as far as needed and return (blocks, b0, b1): this rank's blocks are blocks[b0:b1] of that plan."""
+    n = engine.n
+    bounds = offsets(n, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    margin = MARGIN
+    while True:
+        prefix = n if rank == world - 1 else min(n, hi + margin)
+        blocks, is_open = engine.plan(prefix)
+        b0 = next((k for k, b in enumerate(blocks) if b[0] >= lo), len(blocks))
+        b1 = next((k for k, b in enumerate(blocks) if b[0] >= hi), len(blocks))
+        # exact if the plan saw the whole input, or if a block starting at/after `hi` exists whose predecessor's
+        # cut is final (a cut is final once its block is not open; the cuts before a final cut are final too)
+        if prefix == n or (b1 < len(blocks) and (b1 == 0 or not is_open[b1 - 1])):
+            return blocks, b0, b1
+        margin *= 4
 
 
 def encode_sharded(engine, dist=None, rank=0, world=1):
     """Run one sharded encode.  Returns the stream length on rank 0 (0 elsewhere)."""
     import torch
 
-    blocks = engine.plan()
-    nblk = len(blocks)
-    b0, b1 = block_range(nblk, rank, world)
+    blocks, b0, b1 = own_blocks(engine, rank, world)
     part, nbits = engine.encode_range(b0, b1)
     own = engine.crcs(b0, b1)
     if world == 1:
         return engine.assemble([(part, nbits)], own)
-    # one small all-gather carries every rank's bit count and block CRCs (ranges differ by at most one block)
-    width = 1 + (nblk + world - 1) // world
+    # one small all-gather carries every rank's bit count, block count and block CRCs
+    bounds = offsets(engine.n, world)
+    width = 2 + max(bounds[r + 1] - bounds[r] for r in range(world)) // max(1, engine.min_block) + 2
     meta = torch.zeros(width, dtype=torch.int64, device=part.device)
     meta[0] = nbits
+    meta[1] = len(own)
     if own:
-        meta[1:1 + len(own)] = torch.tensor(own, dtype=torch.int64, device=part.device)
+        meta[2:2 + len(own)] = torch.tensor(own, dtype=torch.int64, device=part.device)
     allmeta = torch.zeros(world * width, dtype=torch.int64, device=part.device)
     dist.all_gather_into_tensor(allmeta, meta)
     rows = allmeta.view(world, width).tolist()  # one read-back
@@ -54,9 +98,8 @@ def encode_sharded(engine, dist=None, rank=0, world=1):
     if rank != 0:
         return 0
     crcs = []
-    for k in range(world):
-        k0, k1 = block_range(nblk, k, world)
-        crcs += [int(c) for c in rows[k][1:1 + (k1 - k0)]]
+    for r in rows:
+        crcs += [int(c) for c in r[2:2 + int(r[1])]]
     segs = [(slabs[k], nb[k]) for k in range(world)]
     return engine.assemble(segs, crcs)
 
@@ -70,16 +113,20 @@ class DeviceEngine:
         self.ctx, self.d_in, self.n, self.d_out = ctx, d_in, n, d_out
         self.cap = seg_cap
         self.part = torch.zeros(seg_cap, dtype=torch.uint8, device=d_in.device)
+        # RLE1 expands by at most 5/4, so a block of M = 100000*level - 1 output bytes eats at least 0.8 M input
+        # bytes (only the stream's last block may be shorter)
+        self.min_block = (100000 * ctx.level - 1) * 4 // 5
 
-    def plan(self):
-        return self.ctx.plan_device(self.d_in.data_ptr(), self.n, crc=False)
-
-    def crcs(self, b0, b1):
-        return [b[3] for b in self.ctx.plan_blocks()[b0:b1]]  # encode_range_device computed them
+    def plan(self, prefix):
+        blocks = self.ctx.plan_device(self.d_in.data_ptr(), prefix, crc=False)
+        return blocks, self.ctx.plan_open()
 
     def encode_range(self, b0, b1):
         nbits = self.ctx.encode_range_device(b0, b1, self.part.data_ptr(), self.cap)
         return self.part, nbits
+
+    def crcs(self, b0, b1):
+        return [b[3] for b in self.ctx.plan_blocks()[b0:b1]]  # encode_range_device computed them
 
     def assemble(self, segments, crcs):
         segs = [(t.data_ptr(), nb) for t, nb in segments]

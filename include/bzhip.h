@@ -135,6 +135,12 @@ BZH_API int bzh_plan_blocks(const bzh_ctx *ctx, bzh_block *out, size_t max_block
 BZH_API int bzh_plan_device_nocrc(bzh_ctx *ctx, const void *d_in, size_t n, size_t *nblocks);
 BZH_API int bzh_plan_crc_range(bzh_ctx *ctx, size_t b0, size_t b1);
 
+/* Per block of the plan: 1 if its cut is NOT final unless the planned input is the whole input -- the cut
+ * lies in the input's last run, or the block reaches the end of the input (the streaming rule of
+ * bzh_stream_feed).  A plan over a PREFIX of a longer input therefore yields the true blocks of the whole
+ * input up to the first open one: ranks of the sharded path plan only as far as their own block range. */
+BZH_API int bzh_plan_open(const bzh_ctx *ctx, uint8_t *out, size_t max_blocks);
+
 /* Encode blocks [b0, b1) of the plan: per block the header (lib/lib.rs:24-36), symbol map
  * (:39-64) and Huffman payload (lib/huffman.rs:313-575), bit-concatenated from bit 0 of d_out
  * (MSB first, lib/out.rs), zero padded to a 4-byte multiple.  No stream header/footer. */

@@ -357,6 +357,41 @@ def test_plan_without_crcs_then_per_range(oracle, native):
         assert d_out[:ln].cpu().numpy().tobytes() == want
 
 
+def test_offset_ownership_with_prefix_plans_on_device(oracle, native):
+    """the N > 1 protocol rank by rank on one GPU: every rank plans only a prefix of the input (small
+    look-ahead, so cuts come back open and the margin has to grow inside a 3 MB run), encodes the blocks
+    that start in its byte range, and the assembled stream is the single-GPU stream"""
+    import torch
+    from banzai_amd import corpus, sharded
+    data = np.concatenate([corpus.enwik_synthetic(5_000_000, seed=13), np.zeros(3_000_000, np.uint8),
+                           corpus.enwik_synthetic(2_500_000, seed=14)])
+    n = data.size
+    want = oracle.encode(data.tobytes(), 9)
+    dev = torch.device("cuda", 0)
+    d_in = torch.zeros(n + 16, dtype=torch.uint8, device=dev)
+    d_in[:n] = torch.from_numpy(data).to(dev)
+    cap = (n // 2 + (1 << 20)) & ~3
+    d_out = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    old = sharded.MARGIN
+    sharded.MARGIN = 100_000
+    try:
+        with native.Context(0, 9, 8) as ctx:
+            eng = sharded.DeviceEngine(ctx, d_in, n, d_out, cap)
+            for world in (2, 3, 7):
+                segs, keep, crcs = [], [], []
+                for r in range(world):
+                    blocks, b0, b1 = sharded.own_blocks(eng, r, world)
+                    part, nbits = eng.encode_range(b0, b1)
+                    keep.append(part.clone())
+                    segs.append((keep[-1], nbits))
+                    crcs += eng.crcs(b0, b1)
+                d_out.zero_()
+                ln = eng.assemble(segs, crcs)
+                assert d_out[:ln].cpu().numpy().tobytes() == want, world
+    finally:
+        sharded.MARGIN = old
+
+
 def test_two_lanes_same_bytes(oracle, native):
     """bzh_set_lanes(2): half-batches prepared concurrently on two internal streams, packed in order"""
     d = cases.gen(3_000_001, "text", 9) + cases.repeats(1_500_000, 9) + cases.gen(400_000, "longruns", 9)

@@ -29,13 +29,27 @@ def _strip_framing(stream):
 class OracleEngine:
     def __init__(self, oracle, data, level, cap):
         self.o, self.data, self.level, self.cap = oracle, data, level, cap
+        self.n = len(data)
+        self.min_block = (100000 * level - 1) * 4 // 5
         self.stream = None
-
-    def plan(self):
         _, infos = self.o.encode(self.data, self.level, want_blocks=True)
-        self.blocks = [(int(b.in_off), int(b.in_len), int(b.rle_len), int(b.crc)) for b in infos]
-        # like the device engine, hand out the cuts without CRCs: a rank only knows the CRCs of its own blocks
-        return [(o, ln, r, 0) for o, ln, r, _ in self.blocks]
+        self.full = [(int(b.in_off), int(b.in_len), int(b.rle_len), int(b.crc)) for b in infos]
+
+    def plan(self, prefix):
+        """what a splitter that only sees data[:prefix] can know: the blocks that end inside the prefix are
+        exact; whatever is left forms one more block whose cut is still open.  Like the device engine, hand
+        out the cuts without CRCs (a rank only knows the CRCs of the blocks it encodes)."""
+        if prefix >= self.n:
+            self.blocks = list(self.full)
+            return [(o, ln, r, 0) for o, ln, r, _ in self.blocks], [False] * len(self.blocks)
+        self.blocks = [b for b in self.full if b[0] + b[1] <= prefix]
+        flags = [False] * len(self.blocks)
+        end = self.blocks[-1][0] + self.blocks[-1][1] if self.blocks else 0
+        out = [(o, ln, r, 0) for o, ln, r, _ in self.blocks]
+        if end < prefix:
+            out.append((end, prefix - end, 0, 0))
+            flags.append(True)
+        return out, flags
 
     def crcs(self, b0, b1):
         return [b[3] for b in self.blocks[b0:b1]]
@@ -68,6 +82,7 @@ def _worker(rank, world, port, data, level, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from banzai_amd import sharded
     from oracle import pyoracle
+    sharded.MARGIN = 30_000  # small look-ahead: forces prefix plans and, on long runs, the margin to grow
     eng = OracleEngine(pyoracle, data, level, cap=len(data) + 4096)
     n = sharded.encode_sharded(eng, dist, rank, world)
     if rank == 0:
@@ -99,6 +114,27 @@ def test_two_ranks_reproduce_single_stream(oracle, mode, n):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert n_out == len(want) and stream == want
+
+
+def test_offset_ownership_covers_every_block_once(oracle):
+    """own_blocks over all ranks, each from its own prefix plan, tiles the whole-input plan exactly"""
+    from banzai_amd import sharded
+    old = sharded.MARGIN
+    sharded.MARGIN = 20_000
+    try:
+        for mode, n in (("text", 1_234_567), ("longruns", 900_000), ("same", 400_000), ("random", 50)):
+            data = cases.gen(n, mode, 5)
+            eng = OracleEngine(oracle, data, 1, cap=16)
+            for world in (1, 2, 3, 5, 8):
+                b = sharded.offsets(n, world)
+                assert b[0] == 0 and b[-1] == n and all(b[k] <= b[k + 1] for k in range(world))
+                got = []
+                for r in range(world):
+                    blocks, b0, b1 = sharded.own_blocks(eng, r, world)
+                    got += [blk[:3] for blk in blocks[b0:b1]]
+                assert got == [blk[:3] for blk in eng.full], (mode, world)
+    finally:
+        sharded.MARGIN = old
 
 
 def test_block_range_partition():
