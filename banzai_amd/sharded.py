@@ -31,6 +31,8 @@ exercised under gloo without a GPU.  An engine provides
 # rank r+1's range is this much shorter than rank r's, which evens out split + encode over the ranks
 PLAN_COST = 0.03
 MARGIN = 4 << 20  # bytes planned beyond the end of the own range; grown when the last own cut is still open
+# rank 0 also receives the gather and assembles the stream (~4 % of a step): its range is shortened by that much
+ROOT_DISCOUNT = 0.96
 
 
 def block_range(nblocks, rank, world):
@@ -42,6 +44,8 @@ def offsets(n, world):
     """Range boundaries B_0..B_world (bytes): geometric lengths, ratio 1/(1 + PLAN_COST)."""
     q = 1.0 / (1.0 + PLAN_COST)
     w = [q ** r for r in range(world)]
+    if world > 1:
+        w[0] *= ROOT_DISCOUNT
     tot = sum(w)
     out, acc = [0], 0.0
     for r in range(world - 1):
