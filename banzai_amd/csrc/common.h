@@ -53,8 +53,8 @@ constexpr int SORT_THREADS = 256;
 constexpr int DB_STRIDE = 1280; // digit-base entries per block: up to 5 digits x 256 values
 constexpr int SORT_ITEMS = 16;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS; // 4096 elements per workgroup
-static_assert(SORT_THREADS == 256 && SORT_ITEMS == 16, "the radix / refine kernels are written and validated for 256 x 16 tiles "
-                                                       "(a 512-thread build hangs in the look-back at full size)");
+static_assert(SORT_TILE == 4096, "bt.hist gives every sort tile 2 KiB; tail_finish keeps one status word per 2048-slot "
+                                 "tail tile at a 1 KiB stride inside it, i.e. it assumes exactly two tail tiles per sort tile");
 constexpr uint32_t RANK_RESOLVED = 0x80000000u;      // suffix is alone in its group
 
 struct BlockDesc { // device-side description of one planned block (mirrors bzh_block + restart info)
