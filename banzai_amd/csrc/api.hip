@@ -94,7 +94,7 @@ static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
     carve(p, bt.gateR, 3 * NB); // radix gates, tail gates, depth of every TAIL block
     bt.gateT = bt.gateR + NB;
     carve(p, bt.errflag, 64);
-    carve(p, bt.alive, NB * ((S + 2047) / 2048));
+    carve(p, bt.alive, 2 * NB * ((S + 2047) / 2048)); // one 64-bit status word per tail tile
     carve(p, bt.mtfpos, NB * S);
     carve(p, bt.tilelist, NB * MT * 256);
     carve(p, bt.tinfo, NB * MT * 4);

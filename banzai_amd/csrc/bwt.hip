@@ -805,7 +805,7 @@ struct TailArgs {
     uint32_t *rank;      // [B][S]
     uint32_t *sa;        // [B][S]
     uint32_t *nact_next; // [B]
-    u64 *stat;           // tile status words of tail_finish's look-back (inside the block's hist rows)
+    u64 *stat;           // [B][TT] tile status words of tail_finish's look-back
     uint32_t pass;       // pass id in those words
     uint32_t *err;       // [1] precondition violations
     const uint32_t *hb;  // [B] depth h of each block (TAIL blocks advance on their own: x4 while the radix path doubles)
@@ -1102,13 +1102,13 @@ __global__ void __launch_bounds__(256) tail_finish(TailArgs a)
             wc[q] = tot;
             tot += c;
         }
-        u64 *st = a.stat + ((size_t)b * a.TT) * 128 + 96; // one word per tail tile inside the block's hist rows
+        u64 *st = a.stat + (size_t)b * a.TT; // one word per tail tile
         uint32_t acc = 0, spins = 0;
         if (tile > 0) {
-            __hip_atomic_store(st + (size_t)tile * 128, look_word(a.pass, LOOK_LOCAL, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(st + tile, look_word(a.pass, LOOK_LOCAL, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int t = (int)tile - 1;
             while (t >= 0) {
-                const u64 w = __hip_atomic_load(st + (size_t)t * 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const u64 w = __hip_atomic_load(st + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t state = (uint32_t)(w >> 30) & 3u;
                 if ((uint32_t)(w >> 32) != a.pass || state == 0) {
                     if (++spins > (1u << 26)) {
@@ -1123,7 +1123,7 @@ __global__ void __launch_bounds__(256) tail_finish(TailArgs a)
                 t--;
             }
         }
-        __hip_atomic_store(st + (size_t)tile * 128, look_word(a.pass, LOOK_GLOBAL, acc + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(st + tile, look_word(a.pass, LOOK_GLOBAL, acc + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         tpre = acc;
         if (r0 + TAIL_T >= len) a.nact_next[b] = acc + tot; // last tile: unresolved suffixes of the block after this round
     }
@@ -1308,6 +1308,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     a.pass = 0;
     HIP_TRY(ctx, hipMemsetAsync(bt.errflag, 0, sizeof(uint32_t), st));
     HIP_TRY(ctx, hipMemsetAsync(a.look, 0, (size_t)B * bt.TPB * NBMAX * sizeof(u64), st));
+    HIP_TRY(ctx, hipMemsetAsync(bt.alive, 0, (size_t)B * ((bt.S + TAIL_T - 1) / TAIL_T) * sizeof(u64), st));
     HIP_TRY(ctx, hipMemsetAsync(bt.dtot, 0, (size_t)B * DB_STRIDE * sizeof(uint32_t), st));
     byte_count<<<dim3(BYTE_SEGS, B), 1024, 0, st>>>(bt.rle, bt.n, bt.dtot, bt.S);
     active_bases<<<dim3(B), 256, 0, st>>>(bt.dtot, bt.dbase, bt.n, 1);
@@ -1382,7 +1383,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     ta.rank = bt.rank;
     ta.sa = bt.sa;
     ta.err = bt.errflag;
-    ta.stat = reinterpret_cast<u64 *>(bt.hist);
+    ta.stat = reinterpret_cast<u64 *>(bt.alive);
     ta.S = bt.S;
     ta.TT = (bt.S + TAIL_T - 1) / TAIL_T; // <= 512 (S <= 2^20)
     for (int round = 0; round < 48; round++) {

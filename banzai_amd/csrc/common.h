@@ -53,8 +53,6 @@ constexpr int SORT_THREADS = 256;
 constexpr int DB_STRIDE = 1280; // digit-base entries per block: up to 5 digits x 256 values
 constexpr int SORT_ITEMS = 16;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS; // 4096 elements per workgroup
-static_assert(SORT_TILE == 4096, "bt.hist gives every sort tile 2 KiB; tail_finish keeps one status word per 2048-slot "
-                                 "tail tile at a 1 KiB stride inside it, i.e. it assumes exactly two tail tiles per sort tile");
 constexpr uint32_t RANK_RESOLVED = 0x80000000u;      // suffix is alone in its group
 
 struct BlockDesc { // device-side description of one planned block (mirrors bzh_block + restart info)
@@ -93,7 +91,7 @@ struct Batch {
     uint32_t *gateT; // [B] per-round gate of the tail kernels (frozen list slots, 0 = skip)
     uint32_t *maxgrp; // [B] largest refined group of the last radix round
     uint32_t *errflag; // [1]
-    uint32_t *alive;   // [B][S/2048] tail-mode tile states
+    uint32_t *alive;   // [B][S/2048] x 64 bit: status words of tail_finish's look-back
     // MTF / RLE2
     uint8_t *mtfpos;   // [B][S]   MTF position of every BWT byte
     uint8_t *tilelist; // [B][MT][256] recency list at each MTF tile entry
