@@ -53,6 +53,7 @@ constexpr int SORT_THREADS = 256;
 constexpr int DB_STRIDE = 1280; // digit-base entries per block: up to 5 digits x 256 values
 constexpr int SORT_ITEMS = 16;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS; // 4096 elements per workgroup
+static_assert(SORT_TILE == 4096, "only the 256 x 16 tile is validated: a 512-thread build was tried and hangs at full size");
 constexpr uint32_t RANK_RESOLVED = 0x80000000u;      // suffix is alone in its group
 
 struct BlockDesc { // device-side description of one planned block (mirrors bzh_block + restart info)
