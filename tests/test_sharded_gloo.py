@@ -99,14 +99,15 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("mode,n", [("text", 450_000), ("longruns", 700_001), ("random", 99_000)])
-def test_two_ranks_reproduce_single_stream(oracle, mode, n):
+@pytest.mark.parametrize("mode,n,world", [("text", 450_000, 2), ("longruns", 700_001, 2), ("random", 99_000, 2),
+                                          ("shortruns", 1_000_003, 3)])
+def test_ranks_reproduce_single_stream(oracle, mode, n, world):
     data = cases.gen(n, mode, 11)
     want = oracle.encode(data, 1)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, data, 1, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, data, 1, q)) for r in range(world)]
     for p in procs:
         p.start()
     n_out, stream = q.get(timeout=120)
