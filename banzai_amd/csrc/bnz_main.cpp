@@ -1,7 +1,9 @@
 // bnz_main.cpp -- `bnzhip`: command-line front end over libbzhip.so with the interface of the
 // reference's `bnz` (reference bnz/src/main.rs:32-59 usage, :173-257 argument grammar, :259-285 I/O
 // plumbing, :292-309 keep/remove policy, :11-14 exit codes).  SURVEY.md section 8(f) row f1.
-// No compression logic lives here: one bzh_encode call on the whole input.
+// No compression logic lives here: the input is fed to bzh_stream_feed in 16 MiB reads (like
+// the reference's BufRead loop, memory stays bounded, pipes and inputs larger than memory work, and reading
+// overlaps with the GPU passes) and the stream bytes are written as they become final.
 #include <cstdio>
 #include <cstdlib>
 #include <cerrno>
@@ -52,13 +54,6 @@ const char *VERSION = "version alpha 0.3.1-hip";
     exit(SUCCESS);
 }
 
-bool read_all(FILE *f, std::vector<uint8_t> &buf)
-{
-    uint8_t tmp[1 << 16];
-    size_t k;
-    while ((k = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + k);
-    return !ferror(f);
-}
 } // namespace
 
 int main(int argc, char **argv)
@@ -123,11 +118,8 @@ int main(int argc, char **argv)
     }
     if (!have_in) die(ERR_ARGS, "An input must be specified");
 
-    std::vector<uint8_t> data;
     FILE *inf = in_stdin ? stdin : fopen(in_path.c_str(), "rb");
     if (!inf) die(ERR_FILESYSTEM, "[filesystem error] cannot open " + in_path + ": " + strerror(errno));
-    if (!read_all(inf, data)) die(ERR_OUTPUT, "error during compression: read failed");
-    if (!in_stdin) fclose(inf);
 
     FILE *outf = stdout;
     if (have_out && !out_stdout) {
@@ -143,17 +135,31 @@ int main(int argc, char **argv)
     bzh_ctx *ctx = nullptr;
     int st = bzh_create(&ctx, devs ? atoi(devs) : 0, level, 0);
     if (st != BZH_OK) die(ERR_OUTPUT, std::string("error during compression: ") + bzh_strerror(st));
-    const size_t cap = data.size() + data.size() / 4 + (data.size() / 70000 + 2) * 4096 + 65536;
-    std::vector<uint8_t> out(cap);
-    size_t out_len = 0, consumed = 0;
-    st = bzh_encode(ctx, data.data(), data.size(), out.data(), cap, &out_len, &consumed);
-    if (st != BZH_OK) {
-        const std::string msg = std::string("error during compression: ") + bzh_strerror(st) + ": " + bzh_last_error(ctx);
+    auto fail = [&](const std::string &what) {
+        const std::string msg = "error during compression: " + what;
         bzh_destroy(ctx);
         die(ERR_OUTPUT, msg);
+    };
+    st = bzh_stream_begin(ctx);
+    if (st != BZH_OK) fail(bzh_strerror(st));
+    const size_t CHUNK = (size_t)16 << 20;
+    std::vector<uint8_t> in(CHUNK), out;
+    for (bool eof = false; !eof;) {
+        const size_t k = fread(in.data(), 1, CHUNK, inf);
+        if (k < CHUNK) {
+            if (ferror(inf)) fail("read failed");
+            eof = true;
+        }
+        const size_t cap = bzh_stream_bound(ctx, k); // depends on what is pending and in flight: ask every time
+        if (out.size() < cap) out.resize(cap);
+        size_t got = 0;
+        st = bzh_stream_feed(ctx, in.data(), k, eof ? 1 : 0, out.data(), out.size(), &got);
+        if (st != BZH_OK) fail(std::string(bzh_strerror(st)) + ": " + bzh_last_error(ctx));
+        if (got && fwrite(out.data(), 1, got, outf) != got) fail("write failed");
     }
     bzh_destroy(ctx);
-    if (fwrite(out.data(), 1, out_len, outf) != out_len || fflush(outf) != 0) die(ERR_OUTPUT, "error during compression: write failed");
+    if (!in_stdin) fclose(inf);
+    if (fflush(outf) != 0) die(ERR_OUTPUT, "error during compression: write failed");
     if (outf != stdout) fclose(outf);
 
     const bool keep_input = keep >= 0 ? keep == 1 : have_out; // bnz/src/main.rs:292-300
