@@ -57,3 +57,7 @@ def test_cli_end_to_end(cli, oracle, tmp_path):
     # -k with default output name
     f.write_bytes(d)
     assert run(cli, "-k", str(f)).returncode == 0 and f.exists()
+    # an input of several 16 MiB reads (the CLI feeds the streaming API), through a pipe
+    big = cases.gen(20_000_000, "shortruns", 3) + cases.gen(17_000_000, "text", 3)
+    r = run(cli, "-c", "-", stdin=big)
+    assert r.returncode == 0 and r.stdout == oracle.encode(big, 9)
