@@ -19,7 +19,7 @@
 
 constexpr int RLE_THREADS = 256;
 constexpr int RLE_ITEMS = 16;
-constexpr int RLE_TILE = RLE_THREADS * RLE_ITEMS; // == SORT_TILE, so bt.TPB tiles per block
+constexpr int RLE_TILE = RLE_THREADS * RLE_ITEMS; // S is a multiple of it: S / RLE_TILE tiles per block
 
 __device__ __forceinline__ uint32_t run_digits(uint32_t z) // symbols emitted for a zero run of length z
 {
@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(RLE_THREADS) rle_tiles(Batch bt, RleTile *rt)
         t.last_nz = ex[RLE_THREADS - 1];
         t.cnt = tot;
         t.off = 0;
-        rt[(size_t)b * bt.TPB + tile] = t;
+        rt[(size_t)b * (bt.S / RLE_TILE) + tile] = t;
     }
 }
 
@@ -335,12 +335,12 @@ __global__ void __launch_bounds__(1024) rle_block(Batch bt, RleTile *rt)
 {
     const uint32_t b = blockIdx.x;
     const uint32_t n = bt.n[b];
-    const uint32_t ntile = (n + RLE_TILE - 1) / RLE_TILE; // <= TPB <= 1024
+    const uint32_t ntile = (n + RLE_TILE - 1) / RLE_TILE; // <= S / RLE_TILE <= 1024
     const uint32_t t = threadIdx.x;
     uint32_t *freqs = bt.freqs + (size_t)b * 258;
     for (uint32_t k = t; k < 258; k += 1024) freqs[k] = 0;
     RleTile me{-1, -1, 0, 0};
-    if (t < ntile) me = rt[(size_t)b * bt.TPB + t];
+    if (t < ntile) me = rt[(size_t)b * (bt.S / RLE_TILE) + t];
     __shared__ int lm[16];
     __shared__ int incl[1024];
     incl[t] = block_incl_max(me.last_nz, lm);
@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(1024) rle_block(Batch bt, RleTile *rt)
     if (t < ntile) {
         me.last_nz = carry;
         me.off = off;
-        rt[(size_t)b * bt.TPB + t] = me;
+        rt[(size_t)b * (bt.S / RLE_TILE) + t] = me;
     }
     if (t == 0) {
         const int lastnz = incl[1023];
@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(RLE_THREADS) rle_emit(Batch bt, const RleTile 
     const uint32_t b = blockIdx.y, tile = blockIdx.x;
     const uint32_t n = bt.n[b];
     if (tile * RLE_TILE >= n) return;
-    const RleTile me = rt[(size_t)b * bt.TPB + tile];
+    const RleTile me = rt[(size_t)b * (bt.S / RLE_TILE) + tile];
     const uint8_t *r = bt.mtfpos + (size_t)b * bt.S;
     const uint32_t q0 = tile * RLE_TILE + threadIdx.x * RLE_ITEMS;
     uint32_t v[4];
@@ -457,7 +457,7 @@ int mtf_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax)
     hipStream_t st = ctx->stream;
     const uint32_t MT = (bt.S + MTF_TILE - 1) / MTF_TILE;
     int32_t *tlast = reinterpret_cast<int32_t *>(bt.listA);  // B*MT*256*4 <= B*S*8
-    RleTile *rt = reinterpret_cast<RleTile *>(bt.listB);     // B*TPB*16
+    RleTile *rt = reinterpret_cast<RleTile *>(bt.listB);     // B*(S/RLE_TILE)*16 bytes
     const uint32_t mt = (nmax + MTF_TILE - 1) / MTF_TILE;
     const uint32_t rtiles = (nmax + RLE_TILE - 1) / RLE_TILE;
     mtf_tile_last<<<dim3(mt, B), 256, 0, st>>>(bt, tlast, MT);
