@@ -48,6 +48,7 @@ class Stats(ctypes.Structure):
 SIGNATURES = {
     "bzh_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "bzh_destroy": (None, [ctypes.c_void_p]),
+    "bzh_arch_supported": (ctypes.c_int, [ctypes.c_char_p]),
     "bzh_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "bzh_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
     "bzh_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
@@ -256,6 +257,14 @@ class Context:
         self.check(lib().bzh_encode(self._h, ptr(a), n, ptr(out), cap, ctypes.byref(olen), ctypes.byref(used)))
         assert used.value == n
         return out[:olen.value].tobytes()
+
+    def encode_host_ptr(self, in_ptr, n, out_ptr, cap):
+        """bzh_encode on raw host addresses (e.g. pinned buffers): H2D + encode + D2H.  -> stream length."""
+        olen = ctypes.c_size_t(0)
+        used = ctypes.c_size_t(0)
+        self.check(lib().bzh_encode(self._h, ctypes.cast(in_ptr, u8p), n, ctypes.cast(out_ptr, u8p), cap,
+                                    ctypes.byref(olen), ctypes.byref(used)))
+        return int(olen.value)
 
     def encode_device(self, d_in, n, d_out, cap):
         """Device-resident encode; d_in/d_out are integer device addresses.  -> stream length."""

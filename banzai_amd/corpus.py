@@ -139,3 +139,37 @@ def workload(n=100_000_000, segment=0):
         if data.size >= n:
             return data[:n].copy(), "enwik8"
     return enwik_synthetic(n, seed=20061 + segment), "enwik8-synthetic"
+
+
+# ---- real (non-synthetic) bytes that ship with the image: the same files exist on every box ----------------
+IMAGE_SETS = {
+    "python-sources": (["/usr/lib/python3.10/**/*.py", "/usr/lib/python3/dist-packages/**/*.py"], 60_000_000),
+    "shared-libs": (["/usr/lib/x86_64-linux-gnu/*.so*"], 60_000_000),
+}
+
+
+def image_corpus(name):
+    """Concatenation of the image's files matching IMAGE_SETS[name], in sorted order, cut at the limit.
+    -> uint8 array (possibly short or empty when the files are not there)"""
+    import glob
+    patterns, limit = IMAGE_SETS[name]
+    buf = bytearray()
+    for pat in patterns:
+        for f in sorted(glob.glob(pat, recursive=True)):
+            try:
+                if os.path.isfile(f):  # symlinked names repeat their target's bytes (as round 1's script did)
+                    with open(f, "rb") as fh:
+                        buf += fh.read()
+            except OSError:
+                pass
+            if len(buf) >= limit:
+                return np.frombuffer(bytes(buf[:limit]), dtype=np.uint8)
+    return np.frombuffer(bytes(buf), dtype=np.uint8)
+
+
+def c5_parts(n=100_000_000):
+    """The four quarters of the C5 workload as separate inputs: [(name, uint8 array)]"""
+    data = pathological(n)
+    q = n // 4
+    names = ["c5-zeros", "c5-tile1024", "c5-abab", "c5-cycling-runs"]
+    return [(names[k], data[k * q:(k + 1) * q if k < 3 else n]) for k in range(4)]

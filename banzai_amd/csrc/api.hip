@@ -10,19 +10,53 @@
 #include <algorithm>
 #include <future>
 #include <memory>
+#include <mutex>
+#include <new>
 #include <thread>
 
 #include "common.h"
 
 static void stream_join(bzh_ctx *ctx); // waits for a streaming pass in flight (defined with bzh_stream_*)
 
+// The error text has two writers while a streaming pass is in flight (the caller's thread and the pass's
+// worker thread), so it is guarded; readers get a private copy (bzh_last_error).
 void bzh_set_error(bzh_ctx *ctx, const char *fmt, ...)
 {
     if (!ctx) return;
+    std::lock_guard<std::mutex> g(ctx->err_mu);
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
     va_end(ap);
+}
+
+// Nothing unwinds across the C ABI (include/bzhip.h): every entry point runs inside this guard.  The
+// reference's convention is the same -- errors are values (io::Result, lib/lib.rs:84-92), panics never
+// cross the boundary.
+template <typename F>
+static int bzh_guard(bzh_ctx *ctx, F &&body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        bzh_set_error(ctx, "host allocation failed");
+        return BZH_E_NOMEM;
+    } catch (const std::exception &e) {
+        bzh_set_error(ctx, "internal error: %s", e.what());
+        return BZH_E_STATE;
+    } catch (...) {
+        bzh_set_error(ctx, "internal error");
+        return BZH_E_STATE;
+    }
+}
+
+// Only gfx950 code objects are in the library: "gfx950", optionally followed by feature flags
+// (hipDeviceProp_t::gcnArchName reads e.g. "gfx950:sramecc+:xnack-").
+extern "C" int bzh_arch_supported(const char *gcn_arch_name)
+{
+    if (!gcn_arch_name) return 0;
+    if (strncmp(gcn_arch_name, "gfx950", 6) != 0) return 0;
+    return gcn_arch_name[6] == 0 || gcn_arch_name[6] == ':';
 }
 
 hipEvent_t bzh_event(bzh_ctx *ctx)
@@ -48,7 +82,14 @@ extern "C" const char *bzh_strerror(int status)
     }
 }
 
-extern "C" const char *bzh_last_error(const bzh_ctx *ctx) { return ctx ? ctx->err : "no context"; }
+extern "C" const char *bzh_last_error(const bzh_ctx *cctx)
+{
+    if (!cctx) return "no context";
+    bzh_ctx *ctx = const_cast<bzh_ctx *>(cctx);
+    std::lock_guard<std::mutex> g(ctx->err_mu);
+    memcpy(ctx->err_out, ctx->err, sizeof ctx->err_out);
+    return ctx->err_out;
+}
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -117,11 +158,14 @@ static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
 
 extern "C" int bzh_create(bzh_ctx **out, int device, int level, int max_batch)
 {
+    return bzh_guard(nullptr, [&]() -> int {
     if (!out || level < 1 || level > 9 || max_batch < 0) return BZH_E_ARG;
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return BZH_E_HIP;
     if (hipSetDevice(device) != hipSuccess) return BZH_E_HIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess || !bzh_arch_supported(prop.gcnArchName)) return BZH_E_HIP;
     bzh_ctx *ctx = new (std::nothrow) bzh_ctx();
     if (!ctx) return BZH_E_NOMEM;
     ctx->device = device;
@@ -152,11 +196,18 @@ extern "C" int bzh_create(bzh_ctx **out, int device, int level, int max_batch)
     }
     *out = ctx;
     return BZH_OK;
+    });
 }
 
 extern "C" void bzh_destroy(bzh_ctx *ctx)
 {
     if (!ctx) return;
+    // a streaming pass in flight keeps launching kernels on the arena and the staging buffers: it ends
+    // first, then the device drains, and only then is anything freed
+    try {
+        if (ctx->strm.worker.joinable()) ctx->strm.worker.join();
+    } catch (...) {
+    }
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
     for (hipEvent_t e : ctx->evpool) hipEventDestroy(e);
@@ -172,7 +223,6 @@ extern "C" void bzh_destroy(bzh_ctx *ctx)
     if (ctx->d_stage_out) hipFree(ctx->d_stage_out);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
     if (ctx->d_crctab) hipFree(ctx->d_crctab);
-    if (ctx->strm.worker.joinable()) ctx->strm.worker.join();
     for (int k = 0; k < 2; k++)
         if (ctx->strm.d_buf[k]) hipFree(ctx->strm.d_buf[k]);
     if (ctx->strm.h_out) hipHostFree(ctx->strm.h_out);
@@ -182,32 +232,40 @@ extern "C" void bzh_destroy(bzh_ctx *ctx)
 
 extern "C" int bzh_set_stream(bzh_ctx *ctx, void *hip_stream)
 {
+    return bzh_guard(ctx, [&]() -> int {
     if (ctx) stream_join(ctx);
     if (!ctx) return BZH_E_ARG;
     ctx->stream = (hipStream_t)hip_stream;
     return BZH_OK;
+    });
 }
 
 extern "C" int bzh_set_lanes(bzh_ctx *ctx, int lanes)
 {
+    return bzh_guard(ctx, [&]() -> int {
     if (ctx) stream_join(ctx);
     if (!ctx || (lanes != 1 && lanes != 2)) return BZH_E_ARG;
     ctx->nlanes = lanes;
     return BZH_OK;
+    });
 }
 
 extern "C" int bzh_set_profiling(bzh_ctx *ctx, int enabled)
 {
+    return bzh_guard(ctx, [&]() -> int {
     if (!ctx) return BZH_E_ARG;
     ctx->profiling = enabled ? 1 : 0;
     return BZH_OK;
+    });
 }
 
 extern "C" int bzh_get_stats(const bzh_ctx *ctx, bzh_stats *out)
 {
+    return bzh_guard(const_cast<bzh_ctx *>(ctx), [&]() -> int {
     if (!ctx || !out) return BZH_E_ARG;
     *out = ctx->stats;
     return BZH_OK;
+    });
 }
 
 static void stats_begin(bzh_ctx *ctx)
@@ -246,6 +304,7 @@ static int ensure_stage(bzh_ctx *ctx, uint8_t *&buf, size_t &cur, size_t need)
 extern "C" int bzh_bwt_batch(bzh_ctx *ctx, const uint8_t *in, const uint64_t *offs, const uint32_t *lens,
                              size_t nblk, uint8_t *bwt_out, uint32_t *ptr, uint8_t *has_byte)
 {
+    return bzh_guard(ctx, [&]() -> int {
     if (ctx) stream_join(ctx);
     if (!ctx || !in || !offs || !lens || !bwt_out || !ptr || !has_byte) return BZH_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -278,11 +337,13 @@ extern "C" int bzh_bwt_batch(bzh_ctx *ctx, const uint8_t *in, const uint64_t *of
     }
     if (ctx->profiling) stats_collect_sort(ctx);
     return BZH_OK;
+    });
 }
 
 extern "C" int bzh_bwt(bzh_ctx *ctx, const uint8_t *in, size_t n, uint8_t *bwt_out, uint32_t *ptr,
                        uint8_t *has_byte)
 {
+    return bzh_guard(ctx, [&]() -> int {
     if (ctx) stream_join(ctx);
     if (!ctx || !ptr || !has_byte) return BZH_E_ARG;
     if (n == 0) { // lib/bwt.rs:535-541
@@ -294,12 +355,14 @@ extern "C" int bzh_bwt(bzh_ctx *ctx, const uint8_t *in, size_t n, uint8_t *bwt_o
     uint64_t off = 0;
     uint32_t len = (uint32_t)n;
     return bzh_bwt_batch(ctx, in, &off, &len, 1, bwt_out, ptr, has_byte);
+    });
 }
 
 // ---- stage seam: MTF + RLE2 ---------------------------------------------------------------------------
 extern "C" int bzh_mtf(bzh_ctx *ctx, const uint8_t *bwt, size_t n, const uint8_t *has_byte, uint16_t *syms,
                        size_t *m, uint32_t *freqs, uint32_t *num_syms)
 {
+    return bzh_guard(ctx, [&]() -> int {
     if (ctx) stream_join(ctx);
     if (!ctx || !bwt || !has_byte || !syms || !m || !freqs || !num_syms || n == 0 || n > ctx->M) return BZH_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -324,6 +387,7 @@ extern "C" int bzh_mtf(bzh_ctx *ctx, const uint8_t *bwt, size_t n, const uint8_t
     HIP_TRY(ctx, bzh_stream_wait(st));
     *m = m32;
     return BZH_OK;
+    });
 }
 
 // ---- stage seam: Huffman ----------------------------------------------------------------------------------
@@ -334,6 +398,7 @@ extern "C" int bzh_huffman(bzh_ctx *ctx, const uint16_t *syms, size_t m, uint32_
                            uint8_t *bits_out, size_t cap, uint64_t *nbits, uint8_t *code_lengths,
                            uint32_t *num_tables)
 {
+    return bzh_guard(ctx, [&]() -> int {
     if (ctx) stream_join(ctx);
     if (!ctx || !syms || !freqs || !bits_out || !nbits || m == 0 || m > (size_t)ctx->M + 1 || num_syms < 3 ||
         num_syms > 258)
@@ -380,6 +445,7 @@ extern "C" int bzh_huffman(bzh_ctx *ctx, const uint16_t *syms, size_t m, uint32_
     }
     if (pay % 8) bits_out[need - 1] &= (uint8_t)(0xFF << (8 - pay % 8));
     return BZH_OK;
+    });
 }
 
 // ================================================================================================
@@ -576,8 +642,17 @@ static int encode_range(bzh_ctx *ctx, size_t b0, size_t b1, uint8_t *d_out, size
         }
     };
     std::vector<std::thread> threads;
-    if (NL > 1)
-        for (size_t k = 0; k < NL; k++) threads.emplace_back(worker, (int)k);
+    if (NL > 1) {
+        try {
+            threads.reserve(NL);
+            for (size_t k = 0; k < NL; k++) threads.emplace_back(worker, (int)k);
+        } catch (...) { // no thread to be had: release the workers that did start, then report
+            for (auto &jp : jobs) jp->packed.set_value();
+            for (auto &t : threads) t.join();
+            bzh_set_error(ctx, "could not start the lane threads");
+            return BZH_E_NOMEM;
+        }
+    }
 
     const uint64_t cap_words = cap / 4;
     uint64_t zeroed_upto = bit_base / 32; // first word not yet known to be zero
@@ -692,42 +767,53 @@ static int plan_device(bzh_ctx *ctx, const void *d_in, size_t n, size_t *nblocks
 
 extern "C" int bzh_plan_device(bzh_ctx *ctx, const void *d_in, size_t n, size_t *nblocks)
 {
+    return bzh_guard(ctx, [&]() -> int {
     return plan_device(ctx, d_in, n, nblocks, true);
+    });
 }
 
 extern "C" int bzh_plan_device_nocrc(bzh_ctx *ctx, const void *d_in, size_t n, size_t *nblocks)
 {
+    return bzh_guard(ctx, [&]() -> int {
     return plan_device(ctx, d_in, n, nblocks, false);
+    });
 }
 
 extern "C" int bzh_plan_crc_range(bzh_ctx *ctx, size_t b0, size_t b1)
 {
+    return bzh_guard(ctx, [&]() -> int {
     if (ctx) stream_join(ctx);
     if (!ctx || b0 > b1) return BZH_E_ARG;
     if (b1 > ctx->plan_blocks.size()) return BZH_E_STATE;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return rle1_plan_crc(ctx, b0, b1);
+    });
 }
 
 extern "C" int bzh_plan_open(const bzh_ctx *ctx, uint8_t *out, size_t max_blocks)
 {
+    return bzh_guard(const_cast<bzh_ctx *>(ctx), [&]() -> int {
     if (!ctx || !out) return BZH_E_ARG;
     if (max_blocks < ctx->plan_open.size()) return BZH_E_CAP;
     for (size_t k = 0; k < ctx->plan_open.size(); k++) out[k] = ctx->plan_open[k];
     return BZH_OK;
+    });
 }
 
 extern "C" int bzh_plan_blocks(const bzh_ctx *ctx, bzh_block *out, size_t max_blocks)
 {
+    return bzh_guard(const_cast<bzh_ctx *>(ctx), [&]() -> int {
     if (!ctx || !out) return BZH_E_ARG;
     if (max_blocks < ctx->plan_blocks.size()) return BZH_E_CAP;
     for (size_t k = 0; k < ctx->plan_blocks.size(); k++) out[k] = ctx->plan_blocks[k];
     return BZH_OK;
+    });
 }
 
 extern "C" int bzh_encode_range_device(bzh_ctx *ctx, size_t b0, size_t b1, void *d_out, size_t cap,
                                        uint64_t *nbits)
 {
+    return bzh_guard(ctx, [&]() -> int {
     if (ctx) stream_join(ctx);
     if (!ctx || !d_out || !nbits || b0 > b1) return BZH_E_ARG;
     if (b1 > ctx->plan_blocks.size()) return BZH_E_STATE;
@@ -741,12 +827,14 @@ extern "C" int bzh_encode_range_device(bzh_ctx *ctx, size_t b0, size_t b1, void 
     if (b0 == b1) return BZH_OK;
     BZH_TRY(rle1_plan_crc(ctx, b0, b1)); // no-op unless the plan left the CRCs to the encoder
     return encode_range(ctx, b0, b1, (uint8_t *)d_out, cap, 0, nbits);
+    });
 }
 
 extern "C" int bzh_assemble_device(bzh_ctx *ctx, const void *const *d_segs, const uint64_t *seg_bits, size_t nseg,
                                    const uint32_t *block_crcs, size_t nblocks, void *d_out, size_t cap,
                                    size_t *out_len)
 {
+    return bzh_guard(ctx, [&]() -> int {
     if (ctx) stream_join(ctx);
     if (!ctx || !d_out || !out_len || (nseg && (!d_segs || !seg_bits)) || (nblocks && !block_crcs)) return BZH_E_ARG;
     if (((uintptr_t)d_out & 3u) != 0) return BZH_E_ARG;
@@ -773,11 +861,13 @@ extern "C" int bzh_assemble_device(bzh_ctx *ctx, const void *const *d_segs, cons
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, bzh_stream_wait(st));
     return BZH_OK;
+    });
 }
 
 extern "C" int bzh_encode_device(bzh_ctx *ctx, const void *d_in, size_t n, void *d_out, size_t cap, size_t *out_len,
                                  size_t *consumed)
 {
+    return bzh_guard(ctx, [&]() -> int {
     if (ctx) stream_join(ctx);
     if (!ctx || (!d_in && n) || !d_out || !out_len) return BZH_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -829,11 +919,13 @@ extern "C" int bzh_encode_device(bzh_ctx *ctx, const void *d_in, size_t n, void 
     }
     if (consumed) *consumed = n;
     return BZH_OK;
+    });
 }
 
 extern "C" int bzh_encode(bzh_ctx *ctx, const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len,
                           size_t *consumed)
 {
+    return bzh_guard(ctx, [&]() -> int {
     if (ctx) stream_join(ctx);
     if (!ctx || (!in && n) || !out || !out_len) return BZH_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -850,12 +942,14 @@ extern "C" int bzh_encode(bzh_ctx *ctx, const uint8_t *in, size_t n, uint8_t *ou
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_stage_out, len, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, bzh_stream_wait(st));
     return BZH_OK;
+    });
 }
 
 // ---- stage seams: RLE1 split and CRC -------------------------------------------------------------------------
 extern "C" int bzh_rle1_split(bzh_ctx *ctx, const uint8_t *in, size_t n, bzh_block *blocks, size_t max_blocks,
                               size_t *nblocks, uint8_t *rle_out, size_t rle_cap)
 {
+    return bzh_guard(ctx, [&]() -> int {
     if (ctx) stream_join(ctx);
     if (!ctx || (!in && n) || !blocks || !nblocks) return BZH_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -884,16 +978,19 @@ extern "C" int bzh_rle1_split(bzh_ctx *ctx, const uint8_t *in, size_t n, bzh_blo
         }
     }
     return BZH_OK;
+    });
 }
 
 extern "C" int bzh_crc32(bzh_ctx *ctx, const uint8_t *in, size_t n, uint32_t *crc)
 {
+    return bzh_guard(ctx, [&]() -> int {
     if (ctx) stream_join(ctx);
     if (!ctx || (!in && n) || !crc) return BZH_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     BZH_TRY(ensure_stage(ctx, ctx->d_stage_in, ctx->stage_in_size, n + 16));
     if (n) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage_in, in, n, hipMemcpyHostToDevice, ctx->stream));
     return crc_device(ctx, ctx->d_stage_in, n, crc);
+    });
 }
 
 
@@ -918,6 +1015,7 @@ static void stream_join(bzh_ctx *ctx)
 
 extern "C" int bzh_stream_begin(bzh_ctx *ctx)
 {
+    return bzh_guard(ctx, [&]() -> int {
     if (!ctx) return BZH_E_ARG;
     auto &s = ctx->strm;
     stream_join(ctx);
@@ -932,6 +1030,7 @@ extern "C" int bzh_stream_begin(bzh_ctx *ctx)
     s.stream_crc = 0;
     s.consumed = 0;
     return BZH_OK;
+    });
 }
 
 extern "C" size_t bzh_stream_bound(const bzh_ctx *ctx, size_t n)
@@ -949,9 +1048,11 @@ extern "C" size_t bzh_stream_consumed(const bzh_ctx *ctx) { return ctx ? ctx->st
 
 extern "C" int bzh_stream_set_chunk(bzh_ctx *ctx, size_t bytes)
 {
+    return bzh_guard(ctx, [&]() -> int {
     if (!ctx || bytes == 0 || bytes > ((size_t)1 << 30)) return BZH_E_ARG;
     ctx->strm.min_feed = bytes;
     return BZH_OK;
+    });
 }
 
 // Headroom kept in front of the fed bytes for the tail a pass leaves unconsumed (normally well below
@@ -993,7 +1094,7 @@ static void stream_pass(bzh_ctx *ctx)
     p.out_bytes = 0;
     p.lastw = 0;
     p.crcs.clear();
-    p.rc = [&]() -> int {
+    p.rc = bzh_guard(ctx, [&]() -> int {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         hipStream_t st = ctx->stream;
         const uint8_t *buf = s.d_buf[p.buf] + p.off;
@@ -1042,12 +1143,13 @@ static void stream_pass(bzh_ctx *ctx)
         }
         for (size_t k = 0; k < F; k++) p.crcs.push_back(ctx->plan_blocks[k].crc);
         return BZH_OK;
-    }();
+    });
 }
 
 extern "C" int bzh_stream_feed(bzh_ctx *ctx, const uint8_t *in, size_t n, int eof, uint8_t *out, size_t cap,
                                size_t *out_len)
 {
+    return bzh_guard(ctx, [&]() -> int {
     if (!ctx || (!in && n) || !out || !out_len) return BZH_E_ARG;
     auto &s = ctx->strm;
     if (!s.active) return BZH_E_STATE;
@@ -1168,4 +1270,5 @@ extern "C" int bzh_stream_feed(bzh_ctx *ctx, const uint8_t *in, size_t n, int eo
     }
     *out_len = opos;
     return BZH_OK;
+    });
 }

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -133,7 +134,9 @@ struct bzh_ctx {
     uint32_t max_batch = 0;
     hipStream_t stream = nullptr;
     int profiling = 0;
-    char err[512] = {0};
+    char err[512] = {0};      // last failure (guarded by err_mu: the streaming worker writes it too)
+    char err_out[512] = {0};  // copy handed out by bzh_last_error
+    std::mutex err_mu;
     // arena
     uint8_t *arena = nullptr;
     size_t arena_size = 0;

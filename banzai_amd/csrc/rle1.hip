@@ -808,6 +808,7 @@ int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n, bool with_crc)
 {
     hipStream_t st = ctx->stream;
     ctx->plan_blocks.clear();
+    ctx->plan_open.clear();
     ctx->plan_crc_ok.clear();
     ctx->plan_in = d_in;
     ctx->plan_n = n;

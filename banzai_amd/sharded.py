@@ -73,27 +73,44 @@ def own_blocks(engine, rank, world):
         margin *= 4
 
 
+class ShardError(RuntimeError):
+    """Raised on EVERY rank when any rank's plan / encode failed (nobody is left waiting in a collective)."""
+
+
 def encode_sharded(engine, dist=None, rank=0, world=1):
     """Run one sharded encode.  Returns the stream length on rank 0 (0 elsewhere)."""
     import torch
 
-    blocks, b0, b1 = own_blocks(engine, rank, world)
-    part, nbits = engine.encode_range(b0, b1)
-    own = engine.crcs(b0, b1)
+    # A rank that fails before the collectives must still take part in them, or the others wait for ever:
+    # the failure travels as a status word in the all-gathered meta row and every rank raises together.
+    err, part, nbits, own = None, None, 0, []
+    try:
+        blocks, b0, b1 = own_blocks(engine, rank, world)
+        part, nbits = engine.encode_range(b0, b1)
+        own = engine.crcs(b0, b1)
+    except Exception as e:  # noqa: BLE001 -- whatever it was, the other ranks have to hear about it
+        err = e
     if world == 1:
+        if err is not None:
+            raise err
         return engine.assemble([(part, nbits)], own)
-    # one small all-gather carries every rank's bit count, block count and block CRCs
+    device = part.device if part is not None else getattr(engine, "device", "cpu")
+    # one small all-gather carries every rank's bit count (or -1 = failed), block count and block CRCs
     bounds = offsets(engine.n, world)
     width = 2 + max(bounds[r + 1] - bounds[r] for r in range(world)) // max(1, engine.min_block) + 2
-    meta = torch.zeros(width, dtype=torch.int64, device=part.device)
-    meta[0] = nbits
-    meta[1] = len(own)
-    if own:
-        meta[2:2 + len(own)] = torch.tensor(own, dtype=torch.int64, device=part.device)
-    allmeta = torch.zeros(world * width, dtype=torch.int64, device=part.device)
+    row = [-1, 0] if err is not None else [nbits, len(own)] + list(own)
+    if len(row) > width:
+        err, row = ShardError(f"rank {rank}: {len(own)} blocks do not fit the meta row of {width} words"), [-1, 0]
+    meta = torch.zeros(width, dtype=torch.int64)
+    meta[:len(row)] = torch.tensor(row, dtype=torch.int64)
+    meta = meta.to(device)
+    allmeta = torch.zeros(world * width, dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(allmeta, meta)
     rows = allmeta.view(world, width).tolist()  # one read-back
     nb = [int(r[0]) for r in rows]
+    failed = [k for k in range(world) if nb[k] < 0]
+    if failed:
+        raise ShardError(f"sharded encode failed on rank(s) {failed}" + (f"; this rank: {err!r}" if err is not None else ""))
     # gather only as many bytes as the longest bit string needs (whole 32-bit words), not the slab capacity
     used = min(engine.cap, (max(nb) + 31) // 32 * 4)
     send = part[:used]
@@ -108,13 +125,34 @@ def encode_sharded(engine, dist=None, rank=0, world=1):
     return engine.assemble(segs, crcs)
 
 
-class DeviceEngine:
-    """libbzhip.so on this rank's GPU; input already resident in HBM (tensor d_in, n bytes)."""
+def resident_bytes(n, rank, world, margin=64 << 20):
+    """Input bytes rank `rank` has to hold: the prefix up to the end of its range plus the look-ahead the split
+    may ask for (own_blocks grows its margin 4 -> 16 -> 64 MiB); the last rank holds everything."""
+    if rank == world - 1:
+        return n
+    return min(n, offsets(n, world)[rank + 1] + margin)
 
-    def __init__(self, ctx, d_in, n, d_out, seg_cap):
+
+def worst_case_slab(n, world, level=9):
+    """Bytes that hold the bit string of any rank's range whatever the data: RLE1 expands by at most 5/4, the
+    Huffman stage by less than 17/8 bits per symbol is never reached (<= 1.02 n + tables in practice, 5/4 n is
+    safe), plus per-block headers and tables (< 4 KiB each)."""
+    b = offsets(n, world)
+    rng = max(b[r + 1] - b[r] for r in range(world))
+    blocks = rng // ((100000 * level - 1) * 4 // 5) + 2
+    return (rng + rng // 4 + blocks * 4096 + 65536 + 3) & ~3
+
+
+class DeviceEngine:
+    """libbzhip.so on this rank's GPU.  d_in holds the first `resident` bytes of the n-byte input (the rank's
+    prefix, see resident_bytes; default: all of it)."""
+
+    def __init__(self, ctx, d_in, n, d_out, seg_cap, resident=None):
         import torch
 
         self.ctx, self.d_in, self.n, self.d_out = ctx, d_in, n, d_out
+        self.resident = n if resident is None else resident
+        self.device = d_in.device
         self.cap = seg_cap
         self.part = torch.zeros(seg_cap, dtype=torch.uint8, device=d_in.device)
         # RLE1 expands by at most 5/4, so a block of M = 100000*level - 1 output bytes eats at least 0.8 M input
@@ -122,6 +160,8 @@ class DeviceEngine:
         self.min_block = (100000 * ctx.level - 1) * 4 // 5
 
     def plan(self, prefix):
+        if prefix > self.resident:
+            raise ShardError(f"the split needs {prefix} input bytes but only {self.resident} are resident on this rank")
         blocks = self.ctx.plan_device(self.d_in.data_ptr(), prefix, crc=False)
         return blocks, self.ctx.plan_open()
 

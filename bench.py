@@ -6,22 +6,30 @@ stream assembly) over the workload, inputs resident in HBM when the timed region
 finished .bz2 stream resident in HBM on rank 0 when it ends.
 
 N = 1: 100,000,000 bytes (BASELINE.json configs[2]) through bzh_encode_device.
-N > 1: weak scaling, N x 100,000,000 bytes as ONE stream: every rank holds the whole input
-(all-gathered once, untimed), runs the cheap sequential block split itself (replicated, no
-exchange), encodes its contiguous share of the blocks, and the encoded bit strings are gathered
-to rank 0 over RCCL (torch.distributed backend "nccl") and funnel-shifted into the stream there.
+N > 1: weak scaling, N x 100,000,000 bytes as ONE stream.  `python bench.py --gpus N` without a launcher
+starts its own ranks (a fresh `python -m torch.distributed.run` child, before this process touches
+the GPU); under a launcher (WORLD_SIZE set) it is one rank.  Rank r holds only the input prefix its
+split needs (sharded.resident_bytes), splits that prefix, encodes the blocks that start in its range;
+the encoded bit strings are gathered to rank 0 over RCCL (torch.distributed backend "nccl") and
+funnel-shifted into the stream there.
 
-Output: ONE JSON line on rank 0 (see the driver contract), with `roofline` for the dominant
-kernel (radix_scatter) and `cpu_baseline` (the oracle = single-thread C restatement of banzai's
-path, timed on a bounded sample of the same workload; also the bit-exactness check).
+Timed region: K steps with profiling OFF (the product's default path).  Stage timings, the radix-pass
+roofline (HIP events on the context's stream) and the counters of `roofline.path_frac` come from a
+second, untimed pass of the same K steps with profiling on.
+
+Output: ONE JSON line on rank 0 (see the driver contract) with `roofline` (dominant kernel class
+radix_scatter + the whole path by SURVEY 8(d)'s fixed accounting), `cpu_baseline` (the oracle =
+single-thread C restatement of banzai's path, timed on the same workload; also the bit-exactness
+check), `value_host_inclusive` (pinned host buffers through bzh_encode, PCIe inside the clock) and
+`extra_workloads` (real files of the image + the four C5 parts, each bit-exact vs the oracle).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -32,26 +40,53 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 SORT_BYTES_PER_ELEM = 16.0     # one radix pass moves an 8-byte (key, suffix) pair: read 8 + write 8
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--bytes", type=int, default=SEGMENT, help="bytes per GPU")
     ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="bytes of the workload timed on the CPU oracle")
-    ap.add_argument("--no-cpu", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-cpu", action="store_true", help="skip the oracle (no cpu_baseline, no bit-exactness checks)")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra_workloads and value_host_inclusive")
+    return ap.parse_args()
 
+
+def self_launch(args):
+    """--gpus N without a launcher: start N fresh ranks.  Nothing in this process has touched the GPU yet
+    (no torch.cuda / HIP call), and it never does: it only waits for the child and passes its exit code on."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def path_alg_bytes(st):
+    """B_alg = N_in + 97 n + 96 A + 6 m + 3 o (bytes), from the counters of one step."""
+    return (st["raw_bytes"] + 97 * st["rle_bytes"] + 96 * st["bwt_active_sum"] + 6 * st["mtf_syms"]
+            + 3 * ((st["out_bits"] + 7) // 8))
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     from banzai_amd import _native as nv
-    from banzai_amd import corpus
+    from banzai_amd import corpus, sharded
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -62,30 +97,32 @@ def main():
 
     seg_bytes = args.bytes
     total = seg_bytes * world
-    # ---- workload (untimed): each rank generates its own segment, ranks exchange once ----
+    # ---- workload (untimed): rank k generates segment k; every rank keeps only the prefix its split needs ----
     seg, wname = corpus.workload(seg_bytes, segment=rank)
-    d_seg = torch.from_numpy(seg).to(dev)
+    resident = sharded.resident_bytes(total, rank, world)
+    d_in = torch.zeros(resident + 16, dtype=torch.uint8, device=dev)
     if world > 1:
-        d_all = torch.empty(total + 16, dtype=torch.uint8, device=dev)
-        parts = [d_all[k * seg_bytes:(k + 1) * seg_bytes] for k in range(world)]
-        dist.all_gather(parts, d_seg)
-        d_in = d_all
+        scratch = torch.empty(seg_bytes, dtype=torch.uint8, device=dev)
+        for k in range(world):
+            if k == rank:
+                scratch.copy_(torch.from_numpy(seg))
+            dist.broadcast(scratch, src=k)
+            lo, hi = k * seg_bytes, min((k + 1) * seg_bytes, resident)
+            if hi > lo:
+                d_in[lo:hi] = scratch[:hi - lo]
+        del scratch
     else:
-        d_in = torch.empty(total + 16, dtype=torch.uint8, device=dev)
-        d_in[:total] = d_seg
-    del d_seg
-    out_cap = (total // 3 + total // 8 + (1 << 20)) & ~3
-    d_out = torch.zeros(out_cap, dtype=torch.uint8, device=dev)
+        d_in[:total] = torch.from_numpy(seg).to(dev)
+    out_cap = (total // 3 + total // 8 + (1 << 20)) & ~3 if world == 1 else (total + total // 4 + (1 << 20)) & ~3
+    d_out = torch.zeros(out_cap if rank == 0 else 16, dtype=torch.uint8, device=dev)
 
     ctx = nv.Context(local_rank, LEVEL, 128)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
 
-    from banzai_amd import sharded
     engine = None
     if world > 1:
-        seg_cap = (seg_bytes // 3 + seg_bytes // 8 + (1 << 20)) & ~3
-        engine = sharded.DeviceEngine(ctx, d_in, total, d_out, seg_cap)
+        engine = sharded.DeviceEngine(ctx, d_in, total, d_out, sharded.worst_case_slab(total, world, LEVEL), resident=resident)
 
     def step():
         """One pass of the hot path; returns the stream length on rank 0."""
@@ -98,23 +135,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    ctx.set_profiling(False)
     for _ in range(args.warmup):
         out_len = step()
-    # ---- timed region: exactly K steps, barrier + synchronize on both sides ----
-    ctx.set_profiling(True)
-    sort_ms = sort_launches = sort_elems = 0.0
-    stage = {}
+    # ---- timed region: exactly K steps, profiling off, barrier + synchronize on both sides ----
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out_len = step()
-        st = ctx.stats()
-        sort_ms += st["ms_bwt_sort"]
-        sort_launches += st["bwt_sort_launches"]
-        sort_elems += st["bwt_sort_elems"]
-        nblocks = st["blocks"]
-        for k in ("ms_plan", "ms_rle1", "ms_bwt", "ms_mtf", "ms_huff", "ms_pack"):
-            stage[k] = stage.get(k, 0.0) + st[k]
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -124,36 +152,68 @@ def main():
     ms_per_step = dt * 1e3 / args.steps
     value = total * args.steps / dt / 1e6
 
+    # ---- untimed: the same K steps with profiling on (HIP events on the context's stream) ----
+    ctx.set_profiling(True)
+    sort_ms = sort_launches = sort_elems = 0.0
+    stage, counters = {}, {}
+    barrier()
+    tp0 = time.perf_counter()
+    for _ in range(args.steps):
+        out_len = step()
+        st = ctx.stats()
+        sort_ms += st["ms_bwt_sort"]
+        sort_launches += st["bwt_sort_launches"]
+        sort_elems += st["bwt_sort_elems"]
+        nblocks = st["blocks"]
+        for k in ("ms_plan", "ms_rle1", "ms_bwt", "ms_mtf", "ms_huff", "ms_pack"):
+            stage[k] = stage.get(k, 0.0) + st[k]
+        counters = {k: st[k] for k in ("raw_bytes", "rle_bytes", "bwt_active_sum", "mtf_syms", "out_bits", "bwt_rounds")}
+    barrier()
+    ms_profiled = (time.perf_counter() - tp0) * 1e3 / args.steps
+    ctx.set_profiling(False)
+
+    # whole-path accounting needs every rank's counters
+    alg = float(path_alg_bytes(counters))
+    if world > 1:
+        t = torch.tensor([alg], dtype=torch.float64, device=dev)
+        dist.all_reduce(t)
+        alg = float(t.item())
+        # rank 0 also checks the sharded stream against one GPU encoding the whole input (untimed)
+        d_full = torch.zeros(total + 16, dtype=torch.uint8, device=dev) if rank == 0 else None
+        parts = [d_full[k * seg_bytes:(k + 1) * seg_bytes] for k in range(world)] if rank == 0 else None
+        dist.gather(torch.from_numpy(seg).to(dev), parts, dst=0)
+    else:
+        d_full = d_in
+
     result = None
     if rank == 0:
         stream_bytes = d_out[:out_len].cpu().numpy().tobytes()
-        # ---- correctness (untimed): libbz2 round trip of the full stream when small enough, and
-        # bit-exactness against the CPU oracle on the bounded sample that is also the cpu_baseline ----
         checks = {}
+        ref_in = None
         if total <= 200_000_000:
             import bz2
-            ref_in = d_in[:total].cpu().numpy().tobytes()
+            ref_in = d_full[:total].cpu().numpy().tobytes()
             checks["libbz2_roundtrip"] = bool(bz2.decompress(stream_bytes) == ref_in)
         if world > 1:
-            # the sharded stream must equal what one GPU produces for the whole input (untimed)
-            d_mono = torch.zeros(out_cap, dtype=torch.uint8, device=dev)
-            ctx.set_profiling(False)
-            mlen = ctx.encode_device(d_in.data_ptr(), total, d_mono.data_ptr(), out_cap)
+            mcap = (total // 3 + total // 8 + (1 << 20)) & ~3
+            d_mono = torch.zeros(mcap, dtype=torch.uint8, device=dev)
+            mlen = ctx.encode_device(d_full.data_ptr(), total, d_mono.data_ptr(), mcap)
             checks["sharded_equals_single_gpu"] = bool(mlen == out_len and torch.equal(d_mono[:mlen], d_out[:out_len]))
             del d_mono
         cpu = None
+        po = None
         if not args.no_cpu:
             from oracle import pyoracle as po
             sample_n = min(args.cpu_sample, seg_bytes)
-            sample = d_in[:sample_n].cpu().numpy()
+            sample = d_full[:sample_n].cpu().numpy()
             t1 = time.perf_counter()
             oracle_stream = po.encode(sample.tobytes(), LEVEL)
             cpu_dt = time.perf_counter() - t1
-            ctx.set_profiling(False)
             d_s_out = torch.zeros((sample_n // 2 + (1 << 20)) & ~3, dtype=torch.uint8, device=dev)
-            slen = ctx.encode_device(d_in.data_ptr(), sample_n, d_s_out.data_ptr(), d_s_out.numel())
+            slen = ctx.encode_device(d_full.data_ptr(), sample_n, d_s_out.data_ptr(), d_s_out.numel())
             checks["bit_exact_vs_oracle_sample"] = bool(d_s_out[:slen].cpu().numpy().tobytes() == oracle_stream)
-            if total <= 200_000_000:  # the in-repo strict decoder (oracle/bz2_decode.c) on the whole GPU stream
+            del d_s_out
+            if ref_in is not None:  # the in-repo strict decoder (oracle/bz2_decode.c) on the whole GPU stream
                 try:
                     checks["inrepo_decoder_roundtrip"] = bool(po.decode(stream_bytes, cap=total + 64) == ref_in)
                 except po.DecodeError:
@@ -161,7 +221,65 @@ def main():
             cpu = {"value": round(sample_n / cpu_dt / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": "port",
                    "sample": f"first {sample_n} bytes of the workload, level {LEVEL}, oracle/banzai_oracle.c -O2, "
                              f"1 thread of {os.cpu_count()} host cores"}
-        # roofline of the dominant kernel (radix_scatter): algorithmic bytes / HIP-event time, per launch
+
+        # ---- PCIe-inclusive rate: pinned host buffers through bzh_encode (H2D + encode + D2H inside the clock) ----
+        host_incl = None
+        extras = None
+        if world == 1 and not args.no_extra:
+            h_in = torch.from_numpy(seg).pin_memory()
+            h_out = torch.zeros(out_cap, dtype=torch.uint8).pin_memory()
+            hlen = ctx.encode_host_ptr(h_in.data_ptr(), total, h_out.data_ptr(), out_cap)
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            for _ in range(args.steps):
+                hlen = ctx.encode_host_ptr(h_in.data_ptr(), total, h_out.data_ptr(), out_cap)
+            torch.cuda.synchronize()
+            hdt = time.perf_counter() - th
+            checks["host_path_same_stream"] = bool(h_out[:hlen].numpy().tobytes() == stream_bytes)
+            host_incl = {"value": round(total * args.steps / hdt / 1e6, 1), "unit": "MB/s",
+                         "ms_per_step": round(hdt * 1e3 / args.steps, 3),
+                         "what": "bzh_encode on pinned host buffers: H2D of the input + encode + D2H of the stream inside the clock"}
+            del h_in, h_out
+
+            # ---- other inputs, each one whole stream on this GPU, bit-exact vs the oracle ----
+            extras = {}
+            sets = [(name, corpus.image_corpus(name)) for name in corpus.IMAGE_SETS] + corpus.c5_parts(100_000_000)
+            for name, data in sets:
+                n = int(data.size)
+                if n < 1_000_000:
+                    extras[name] = {"skipped": f"only {n} bytes found"}
+                    continue
+                d_x = torch.zeros(n + 16, dtype=torch.uint8, device=dev)
+                d_x[:n] = torch.from_numpy(np.ascontiguousarray(data)).to(dev)
+                xcap = (n + n // 4 + (1 << 20)) & ~3
+                d_y = torch.zeros(xcap, dtype=torch.uint8, device=dev)
+                ctx.set_profiling(False)
+                xlen = ctx.encode_device(d_x.data_ptr(), n, d_y.data_ptr(), xcap)  # warm-up
+                best = None
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    tx = time.perf_counter()
+                    xlen = ctx.encode_device(d_x.data_ptr(), n, d_y.data_ptr(), xcap)
+                    torch.cuda.synchronize()
+                    dx = time.perf_counter() - tx
+                    best = dx if best is None or dx < best else best
+                ctx.set_profiling(True)
+                ctx.encode_device(d_x.data_ptr(), n, d_y.data_ptr(), xcap)
+                xs = ctx.stats()
+                ctx.set_profiling(False)
+                rec = {"bytes": n, "MB/s": round(n / best / 1e6, 1), "ms": round(best * 1e3, 2),
+                       "rounds": int(xs["bwt_rounds"]), "A/n": round(xs["bwt_active_sum"] / max(1, xs["rle_bytes"]), 2),
+                       "ratio": round(xlen / n, 4)}
+                if po is not None:
+                    tc = time.perf_counter()
+                    want = po.encode(data.tobytes(), LEVEL)
+                    rec["oracle_MB/s"] = round(n / (time.perf_counter() - tc) / 1e6, 1)
+                    rec["bit_exact"] = bool(d_y[:xlen].cpu().numpy().tobytes() == want)
+                    checks[f"bit_exact_{name}"] = rec["bit_exact"]
+                extras[name] = rec
+                del d_x, d_y
+
+        # roofline of the dominant kernel class (radix_scatter): algorithmic bytes / HIP-event time, per launch
         achieved = (SORT_BYTES_PER_ELEM * sort_elems / (sort_ms * 1e-3) / 1e9) if sort_ms > 0 else None
         # HBM bytes per launch from the committed PMC passes of this same command (FETCH_SIZE / WRITE_SIZE in
         # separate rocprofv3 runs, corrected as MI355X_MICROARCH.md prescribes); null if not collected
@@ -173,6 +291,7 @@ def main():
                     traffic = round(json.load(f)["radix_scatter_all"]["hbm_bytes_per_launch"])
         except Exception:
             traffic = None
+        path_gbs = alg / (ms_per_step * 1e-3) / 1e9
         result = {
             "metric": "encode MB/s (input) at level 9, enwik8, 1/2/4/8 MI355X; bit-exact vs CPU",
             "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -181,14 +300,26 @@ def main():
             "config": {"workload": f"level {LEVEL} {wname}, {seg_bytes} bytes per GPU, {total} bytes in one stream, "
                                    "full RLE1->BWT->MTF->Huffman pipeline",
                        "blocks_on_rank0": int(nblocks),
-                       "parallelism": f"block-sharded x{world}"},
+                       "parallelism": f"block-sharded x{world}",
+                       "input_resident_on_rank0": int(resident)},
             "roofline": {"bound": "hbm", "kernel": "radix_scatter", "achieved": round(achieved, 1) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
                          "launches": int(sort_launches), "avg_launch_us": round(sort_ms * 1e3 / max(1, sort_launches), 2),
-                         "alg_bytes_per_launch": round(SORT_BYTES_PER_ELEM * sort_elems / max(1, sort_launches))},
+                         "alg_bytes_per_launch": round(SORT_BYTES_PER_ELEM * sort_elems / max(1, sort_launches)),
+                         "measured_in": "untimed second pass of the same K steps with profiling on "
+                                        f"({round(ms_profiled, 3)} ms per step there)",
+                         # the whole path by SURVEY 8(d)'s fixed accounting, over the TIMED region (all ranks)
+                         "path_alg_bytes_per_step": round(alg), "path_achieved": round(path_gbs, 1),
+                         "path_frac": round(path_gbs / (HBM_PEAK_GBS * world), 4),
+                         "path_A_convention": "A = unresolved suffixes entering each doubling round actually run "
+                                              "(depth 8 onwards: the 8-byte initial sort stands in for the h=4 round)"},
             "cpu_baseline": cpu,
+            "value_host_inclusive": host_incl,
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage.items()},
+            "bwt_rounds": int(counters.get("bwt_rounds", 0)),
+            "A_over_n": round(counters["bwt_active_sum"] / max(1, counters["rle_bytes"]), 3),
+            "extra_workloads": extras,
             "compressed_bytes": out_len, "checks": checks,
         }
         print(json.dumps(result), flush=True)

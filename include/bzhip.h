@@ -65,6 +65,10 @@ typedef struct {
 /* Create a context on HIP device `device` for block size `level` (1..9; lib/lib.rs:89).
  * max_batch = bzip2 blocks processed per kernel batch (0 = default). */
 BZH_API int bzh_create(bzh_ctx **ctx, int device, int level, int max_batch);
+/* 1 if a device whose hipDeviceProp_t::gcnArchName is `gcn_arch_name` can run this library (gfx950 only;
+ * e.g. "gfx950:sramecc+:xnack-"), else 0.  bzh_create applies it to the chosen device and fails with
+ * BZH_E_HIP otherwise. */
+BZH_API int bzh_arch_supported(const char *gcn_arch_name);
 BZH_API void bzh_destroy(bzh_ctx *ctx);
 BZH_API const char *bzh_strerror(int status);
 BZH_API const char *bzh_last_error(const bzh_ctx *ctx); /* detail of the last failure on this ctx   */

@@ -1,6 +1,8 @@
 // =-=-= lib.rs =-=-=
 // banzai's public surface over libbzhip.so (MI355X).  Signatures are those of the reference
 // crate (lib/lib.rs:84-88 and :141-153); every byte is produced by the HIP library.
+// NOTE: the build image has no Rust toolchain, so this crate has never been compiled or run; the same
+// calling pattern is exercised through the C ABI by banzai_amd/__init__.py and bnzhip.
 
 use std::convert;
 use std::ffi::CStr;
@@ -78,31 +80,47 @@ where
         return Err(to_io_error(ctx.0, status));
     }
 
-    // Pull from the reader as the reference does (fill_buf / consume, lib/rle.rs:43-91); the library
-    // buffers what it must and returns stream bytes as soon as they are final.
+    // Pull from the reader as the reference does (fill_buf / consume, lib/rle.rs:43-91).  A BufReader hands
+    // out 8 KiB slices by default (bnz/src/main.rs:263); every bzh_stream_feed call is one blocking H2D copy,
+    // so small slices are coalesced into a staging buffer of STAGE bytes and fed from there; slices of STAGE
+    // bytes or more go straight through.  The library buffers what it must and returns stream bytes as soon
+    // as they are final.
+    const STAGE: usize = 4 << 20;
+    let mut stage: Vec<u8> = Vec::with_capacity(STAGE);
     let mut out: Vec<u8> = Vec::new();
+    let mut feed = |chunk: &[u8], eof: bool, writer: &mut io::BufWriter<W>| -> io::Result<()> {
+        let cap = unsafe { bzh_stream_bound(ctx.0, chunk.len()) };
+        if out.len() < cap {
+            out.resize(cap, 0);
+        }
+        let mut out_len = 0usize;
+        let status = unsafe {
+            bzh_stream_feed(ctx.0, chunk.as_ptr(), chunk.len(), eof as c_int, out.as_mut_ptr(), out.len(), &mut out_len)
+        };
+        if status != 0 {
+            return Err(to_io_error(ctx.0, status));
+        }
+        writer.write_all(&out[..out_len])
+    };
     loop {
-        let (len, eof) = {
+        let len = {
             let buf = reader.fill_buf()?;
-            let eof = buf.is_empty();
-            let cap = unsafe { bzh_stream_bound(ctx.0, buf.len()) };
-            if out.len() < cap {
-                out.resize(cap, 0);
+            if buf.is_empty() {
+                feed(&stage, true, &mut writer)?; // end of input: whatever is staged, with the eof mark
+                break;
             }
-            let mut out_len = 0usize;
-            let status = unsafe {
-                bzh_stream_feed(ctx.0, buf.as_ptr(), buf.len(), eof as c_int, out.as_mut_ptr(), out.len(), &mut out_len)
-            };
-            if status != 0 {
-                return Err(to_io_error(ctx.0, status));
+            if stage.is_empty() && buf.len() >= STAGE {
+                feed(buf, false, &mut writer)?;
+            } else {
+                stage.extend_from_slice(buf);
+                if stage.len() >= STAGE {
+                    feed(&stage, false, &mut writer)?;
+                    stage.clear();
+                }
             }
-            writer.write_all(&out[..out_len])?;
-            (buf.len(), eof)
+            buf.len()
         };
         reader.consume(len);
-        if eof {
-            break;
-        }
     }
     writer.flush()?;
     Ok(unsafe { bzh_stream_consumed(ctx.0) })
@@ -118,5 +136,6 @@ where
 {
     let inf = fs::File::open(in_path.as_ref())?;
     let outf = fs::File::create(out_path.as_ref())?;
-    encode(io::BufReader::new(inf), io::BufWriter::new(outf), 9)
+    // large reads: each fill_buf slice becomes one H2D copy (see encode)
+    encode(io::BufReader::with_capacity(16 << 20, inf), io::BufWriter::new(outf), 9)
 }

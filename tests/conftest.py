@@ -12,6 +12,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
 
+def _gpu_present():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    """`gpu` tests are skipped (not failed) on a box without a device; every other test runs everywhere."""
+    if _gpu_present():
+        return
+    skip = pytest.mark.skip(reason="no MI355X visible (gpu-marked test)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import pyoracle

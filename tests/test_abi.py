@@ -46,6 +46,17 @@ def test_create_rejects_bad_arguments(native):
     assert L.bzh_create(None, 0, 9, 0) == -1
 
 
+def test_arch_gate(native):
+    """bzh_create refuses any device whose gcnArchName is not gfx950 (BZH_E_HIP): the gate it applies is
+    exported, so the wrong-arch path can be checked without such a device"""
+    L = native.lib()
+    assert L.bzh_arch_supported(b"gfx950") == 1
+    assert L.bzh_arch_supported(b"gfx950:sramecc+:xnack-") == 1
+    for bad in (b"gfx942", b"gfx942:sramecc+:xnack-", b"gfx90a", b"gfx9500", b"gfx95", b"", b"sm_90"):
+        assert L.bzh_arch_supported(bad) == 0, bad
+    assert L.bzh_arch_supported(None) == 0
+
+
 def _have_gpu():
     try:
         import torch

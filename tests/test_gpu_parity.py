@@ -440,6 +440,79 @@ def test_full_size_properties_config3(native, oracle):
     assert bz2.decompress(first) == data.tobytes() and oracle.decode(first) == data.tobytes()
 
 
+def test_full_size_config4_one_gigabyte_and_world8_simulation(native, oracle):
+    """BASELINE.json configs[3] (enwik9-sized: 1,000,000,000 bytes, ~1,112 blocks) on one GPU: the block table
+    tiles the input, two runs give identical bytes, the in-repo decoder reproduces the input (pins every
+    CRC, table and block cut), and the 8-rank protocol run rank by rank -- each rank restricted to the input
+    prefix bench.py would make resident on it -- assembles to the very same stream."""
+    import torch
+    from banzai_amd import corpus, sharded
+    seg, world = 100_000_000, 8
+    n = 1_000_000_000
+    dev = torch.device("cuda", 0)
+    d_in = torch.zeros(n + 16, dtype=torch.uint8, device=dev)
+    host = np.empty(n, dtype=np.uint8)
+    for k in range(n // seg):  # the segments bench.py's ranks would generate
+        host[k * seg:(k + 1) * seg] = corpus.workload(seg, segment=k)[0]
+        d_in[k * seg:(k + 1) * seg] = torch.from_numpy(host[k * seg:(k + 1) * seg]).to(dev)
+    cap = (n // 3 + n // 8 + (1 << 20)) & ~3
+    d_out = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    with native.Context(0, 9, 128) as ctx:
+        ln = ctx.encode_device(d_in.data_ptr(), n, d_out.data_ptr(), cap)
+        mono = d_out[:ln].clone()
+        blocks = ctx.plan_device(d_in.data_ptr(), n)
+        d_out.zero_()
+        ln2 = ctx.encode_device(d_in.data_ptr(), n, d_out.data_ptr(), cap)
+        assert ln2 == ln and torch.equal(d_out[:ln], mono)
+        assert sum(b[1] for b in blocks) == n and all(0 < b[2] <= 899_999 for b in blocks)
+        assert all(blocks[k][0] + blocks[k][1] == blocks[k + 1][0] for k in range(len(blocks) - 1))
+        assert 1100 <= len(blocks) <= 1130
+        # world = 8, rank by rank; a rank may only plan inside its resident prefix
+        slab = sharded.worst_case_slab(n, world, 9)
+        segs, keep, crcs, nblk = [], [], [], 0
+        for r in range(world):
+            eng = sharded.DeviceEngine(ctx, d_in, n, d_out, slab, resident=sharded.resident_bytes(n, r, world))
+            _, b0, b1 = sharded.own_blocks(eng, r, world)
+            part, nbits = eng.encode_range(b0, b1)
+            keep.append(part[:(nbits + 31) // 32 * 4 + 4].clone())
+            segs.append((keep[-1], nbits))
+            crcs += eng.crcs(b0, b1)
+            nblk += b1 - b0
+            del eng
+        assert nblk == len(blocks) and crcs == [b[3] for b in blocks]
+        d_out.zero_()
+        eng = sharded.DeviceEngine(ctx, d_in, n, d_out, 16)
+        ln3 = eng.assemble(segs, crcs)
+        assert ln3 == ln and torch.equal(d_out[:ln], mono)
+    stream = mono.cpu().numpy().tobytes()
+    assert stream[:4] == b"BZh9"
+    assert oracle.decode(stream, cap=n + 64) == host.tobytes()
+
+
+def test_two_lanes_level9_several_batches(oracle, native):
+    """bzh_set_lanes(2) at level 9 with more than two batches per lane (max_batch 4 -> lanes of 2 blocks)"""
+    from banzai_amd import corpus
+    d = corpus.enwik_synthetic(9_300_000, seed=41).tobytes() + cases.gen(400_000, "longruns", 2)
+    want = oracle.encode(d, 9)
+    with native.Context(0, 9, 4) as ctx:
+        ctx.set_lanes(2)
+        assert ctx.encode(d) == want
+        assert ctx.encode(d) == want
+
+
+def test_empty_plan_after_a_non_empty_one(native):
+    """plan state is reset for n = 0 as well (blocks, open flags)"""
+    import torch
+    dev = torch.device("cuda", 0)
+    d_in = torch.zeros(300_016, dtype=torch.uint8, device=dev)
+    d_in[:300_000] = torch.from_numpy(np.frombuffer(cases.gen(300_000, "text", 1), dtype=np.uint8).copy()).to(dev)
+    with native.Context(0, 1, 4) as ctx:
+        assert len(ctx.plan_device(d_in.data_ptr(), 300_000)) >= 3
+        assert len(ctx.plan_open()) >= 3
+        assert ctx.plan_device(d_in.data_ptr(), 0) == []
+        assert ctx.plan_open() == []
+
+
 # ---- streaming (SURVEY 8f row f2) --------------------------------------------------------------------------
 def _stream(ctx, data, cuts, chunk_bytes):
     ctx.stream_begin(chunk_bytes)

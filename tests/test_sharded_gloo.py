@@ -117,6 +117,53 @@ def test_ranks_reproduce_single_stream(oracle, mode, n, world):
     assert n_out == len(want) and stream == want
 
 
+def _failing_worker(rank, world, port, data, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from banzai_amd import sharded
+    from oracle import pyoracle
+    eng = OracleEngine(pyoracle, data, 1, cap=len(data) + 4096)
+    if rank == 1:  # this rank's encode fails (as BZH_E_CAP / a plan error would on a GPU)
+        def boom(b0, b1):
+            raise RuntimeError("slab too small")
+        eng.encode_range = boom
+    try:
+        sharded.encode_sharded(eng, dist, rank, world)
+        q.put((rank, "returned"))
+    except sharded.ShardError as e:
+        q.put((rank, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_failure_on_one_rank_raises_on_all(oracle):
+    """a rank that fails before the collectives reports through the status word: nobody hangs, everybody raises"""
+    data = cases.gen(450_000, "text", 3)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, data, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert "rank(s) [1]" in got[0] and "rank(s) [1]" in got[1] and "slab too small" in got[1]
+
+
+def test_resident_prefix_and_slab_sizes():
+    from banzai_amd import sharded
+    n = 800_000_000
+    b = sharded.offsets(n, 8)
+    for r in range(8):
+        res = sharded.resident_bytes(n, r, 8)
+        assert res == n if r == 7 else res == min(n, b[r + 1] + (64 << 20))
+    assert sharded.resident_bytes(n, 0, 8) < n // 4  # rank 0 holds its own range + look-ahead, not the stream
+    assert sharded.worst_case_slab(n, 8) >= (max(b[k + 1] - b[k] for k in range(8)) * 5) // 4
+
+
 def test_offset_ownership_covers_every_block_once(oracle):
     """own_blocks over all ranks, each from its own prefix plan, tiles the whole-input plan exactly"""
     from banzai_amd import sharded
