@@ -121,19 +121,25 @@ static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
     carve(p, bt.headp, NB * S);
     carve(p, bt.listA, NB * S);
     carve(p, bt.listB, NB * S);
+    carve(p, bt.listC, NB * S);
+    carve(p, bt.listD, NB * S);
     carve(p, bt.hist, NB * 512 * bt.TPB);
     carve(p, bt.dbase, NB * DB_STRIDE);
     carve(p, bt.dtot, NB * DB_STRIDE);
     carve(p, bt.flg, NB * S);
     carve(p, bt.tagg, NB * bt.TPB);
-    // per-round state: three rotating {unresolved counts[NB], largest group[NB]} pairs, each pair
-    // contiguous so one copy / one memset moves it; the two gate arrays likewise
-    carve(p, bt.nactA, 6 * NB);
-    bt.nactB = bt.nactA + 2 * NB;
-    bt.nactC = bt.nactA + 4 * NB;
-    bt.maxgrp = nullptr; // = count array + NB, see bwt_run
-    carve(p, bt.gateR, 3 * NB); // radix gates, tail gates, depth of every TAIL block
-    bt.gateT = bt.gateR + NB;
+    { // round state of the suffix sort: 21 words per block, contiguous (one memset clears it)
+        uint32_t *rs = nullptr;
+        const size_t oA = (21 * NB + 8 + SUMMARY_WORDS + 1) & ~(size_t)1; // 64-bit counter: even word index
+        carve(p, rs, oA + 4);
+        uint32_t **f[21] = {&bt.st_mode, &bt.st_h, &bt.st_nbig, &bt.st_ntail, &bt.c_big, &bt.c_small, &bt.c_tail,
+                            &bt.c_prog, &bt.gateS, &bt.gateA, &bt.gateR, &bt.gateT, &bt.actS, &bt.actA, &bt.actR,
+                            &bt.actT, &bt.actQ, nullptr, nullptr, nullptr, nullptr};
+        for (int k = 0; k < 17; k++) *f[k] = rs ? rs + (size_t)k * NB : nullptr;
+        bt.nlist = rs ? rs + 21 * NB : nullptr;
+        bt.summary = rs ? rs + 21 * NB + 8 : nullptr;
+        bt.stat_A = rs ? reinterpret_cast<unsigned long long *>(rs + oA) : nullptr;
+    }
     carve(p, bt.errflag, 64);
     carve(p, bt.alive, 2 * NB * ((S + 2047) / 2048)); // one 64-bit status word per tail tile
     carve(p, bt.mtfpos, NB * S);
@@ -189,7 +195,7 @@ extern "C" int bzh_create(bzh_ctx **out, int device, int level, int max_batch)
     }
     layout_batch(ctx->bt, ctx->arena, ctx->max_batch, ctx->M);
     ctx->S = ctx->bt.S;
-    if (hipHostMalloc((void **)&ctx->h_pinned, sizeof(uint32_t) * (ctx->max_batch * 8 + 64)) != hipSuccess) {
+    if (hipHostMalloc((void **)&ctx->h_pinned, sizeof(uint32_t) * (ctx->max_batch * 8 + 64 + MAX_ROUNDS * SUMMARY_WORDS)) != hipSuccess) {
         hipFree(ctx->arena);
         delete ctx;
         return BZH_E_NOMEM;
@@ -533,7 +539,7 @@ static int ensure_lanes(bzh_ctx *ctx)
         layout_batch(l->bt, ctx->arena + (size_t)k * half, lane_mb, ctx->M);
         l->S = l->bt.S;
         if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess ||
-            hipHostMalloc((void **)&l->h_pinned, sizeof(uint32_t) * (lane_mb * 8 + 64)) != hipSuccess) {
+            hipHostMalloc((void **)&l->h_pinned, sizeof(uint32_t) * (lane_mb * 8 + 64 + MAX_ROUNDS * SUMMARY_WORDS)) != hipSuccess) {
             delete l;
             return BZH_E_NOMEM;
         }

@@ -56,6 +56,8 @@ constexpr int SORT_ITEMS = 16;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS; // 8192 elements per workgroup (512 x 16: halves the look-back /
                                                      // scan overhead per element against 256 x 16, -7 % on the bench)
 constexpr uint32_t RANK_RESOLVED = 0x80000000u;      // suffix is alone in its group
+constexpr int SUMMARY_WORDS = 16; // round summary: see round_begin (bwt.hip)
+constexpr int MAX_ROUNDS = 64;
 
 struct BlockDesc { // device-side description of one planned block (mirrors bzh_block + restart info)
     uint64_t in_off;
@@ -79,19 +81,28 @@ struct Batch {
     uint32_t *rank; // [B][S]
     uint32_t *sa;   // [B][S]
     uint32_t *headp; // [B][S] group rank by SA position (SWEEP rounds read it instead of gathering)
-    uint2 *listA;   // [B][S] (key, suffix)
+    uint2 *listA;   // [B][S] sort elements (ping-pong of the radix passes; the big-group list between rounds)
     uint2 *listB;   // [B][S]
+    uint2 *listC;   // [B][S] small-group (TAIL) list of the block
+    uint2 *listD;   // [B][S] TAIL records of the round in flight
     uint32_t *hist; // [B][TPB][512]: 2 KiB per sort tile -- look-back status words (256 x u64) or refine digit rows
     uint32_t *dbase; // [B][DB_STRIDE] digit bases of the look-back passes
     uint32_t *dtot;  // [B][DB_STRIDE] digit totals of an ACTIVE round (5 digits x 256)
     uint8_t *flg;   // [B][S]
-    int2 *tagg;     // [B][TPB] tile aggregates (last group start, last boundary)
-    uint32_t *nactA; // [B]
-    uint32_t *nactB; // [B]
-    uint32_t *nactC; // [B]
-    uint32_t *gateR; // [B] per-round gate of the radix kernels (unresolved count, 0 = skip)
-    uint32_t *gateT; // [B] per-round gate of the tail kernels (frozen list slots, 0 = skip)
-    uint32_t *maxgrp; // [B] largest refined group of the last radix round
+    int4 *tagg;     // [B][TPB] tile carries: last group start / last boundary before the tile, first boundary after it
+    // Round state of the suffix sort, all [B] unless noted.  The rounds are driven from the device: round_begin
+    // turns the counters of the round before into this round's work lists, the host only sizes the launches
+    // from a summary it reads one round late.
+    uint32_t *st_mode;  // 0: whole block on the radix path, SA-order enumeration (SWEEP); 1: groups routed by size (SPLIT)
+    uint32_t *st_h;     // depth of the block's next round
+    uint32_t *st_nbig;  // records in the big-group list (SPLIT) / unresolved suffixes (SWEEP)
+    uint32_t *st_ntail; // records in the small-group list
+    uint32_t *c_big, *c_small, *c_tail, *c_prog; // produced by a round: list lengths, "some group was refined"
+    uint32_t *gateS, *gateA, *gateR, *gateT;     // this round: sorted-list length per path (0 = not on that path)
+    uint32_t *actS, *actA, *actR, *actT, *actQ;  // this round: ids of the blocks on each path (Q: TAIL at depth x4)
+    uint32_t *nlist;    // [8] lengths of those lists (S, A, R, T, Q)
+    uint32_t *summary;  // [SUMMARY_WORDS] what the host reads, one round late
+    unsigned long long *stat_A; // [1] sum over rounds of the unresolved suffixes entering them
     uint32_t *errflag; // [1]
     uint32_t *alive;   // [B][S/2048] x 64 bit: status words of tail_finish's look-back
     // MTF / RLE2
@@ -281,6 +292,28 @@ __device__ __forceinline__ void block_incl_max2(int &a, int &b, int *lds)
     a = max(ia, ca);
     b = max(ib, cb);
     __syncthreads();
+}
+
+// Workgroup EXCLUSIVE suffix-min: result = min of v over all threads with a higher index (INT32_MAX for the
+// last thread).  `lds` needs (threads/64) ints.
+__device__ __forceinline__ int block_excl_min_rev(int v, int *lds)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    int inc = v; // inclusive suffix-min inside the wavefront
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_down(inc, d, 64);
+        if (lane + d < 64) inc = min(inc, t);
+    }
+    if (lane == 0) lds[wave] = inc;
+    __syncthreads();
+    int carry = INT32_MAX;
+    for (int w = wave + 1; w < nw; w++) carry = min(carry, lds[w]);
+    int ex = __shfl_down(inc, 1, 64);
+    if (lane == 63) ex = INT32_MAX;
+    const int res = min(ex, carry);
+    __syncthreads();
+    return res;
 }
 
 // ---- stage entry points (host side, defined in the stage files) ---------------------------------

@@ -933,7 +933,7 @@ int crc_device(bzh_ctx *ctx, const uint8_t *d_in, size_t n, uint32_t *crc_out)
     BZH_TRY(crc_tables(ctx, &ct));
     BlockDesc d{0, n, 0, 0};
     BlockDesc *dd = ctx->bt.desc;        // scratch
-    uint32_t *acc = ctx->bt.nactA;       // scratch
+    uint32_t *acc = ctx->bt.c_big;       // scratch
     HIP_TRY(ctx, hipMemcpyAsync(dd, &d, sizeof d, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemsetAsync(acc, 0, 4, st));
     const uint32_t ctiles = (uint32_t)((n + CRC_TILE - 1) / CRC_TILE);

@@ -1,19 +1,17 @@
+"""Timeline of the last BWT step in a rocprofv3 kernel trace (newest *kernel_trace.csv under the given directory)."""
 import csv, glob, os, sys
-f = max(glob.glob(sys.argv[1] + '/*/*kernel_trace.csv'), key=os.path.getmtime)  # newest trace
-thr = float(sys.argv[2]) if len(sys.argv) > 2 else 100
+d = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/prof_q'
+f = max(glob.glob(os.path.join(d, '*', '*kernel_trace.csv')), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('plan_starts')]
-seq = rows[idx[-1]:]
-t0 = int(seq[0]['Start_Timestamp'])
-tot = {}
-for r in seq:
-    name = r['Kernel_Name'].split('(')[0].replace('void ', '')[:28]
-    dur = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-    st = (int(r['Start_Timestamp']) - t0) / 1e3
-    tot[name] = tot.get(name, 0) + dur
-    if dur > thr:
-        print(f"{st:10.1f}us {name:30s} {dur:9.1f}us grid={r['Grid_Size_X']}")
-print("---- totals (last step)")
-for k, v in sorted(tot.items(), key=lambda x: -x[1])[:14]:
-    print(f"{k:30s} {v/1e3:8.2f} ms")
+idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('byte_count')]
+start = idx[-1]
+t0 = int(rows[start]['Start_Timestamp'])
+prev_end = t0
+for r in rows[start:start + 400]:
+    s = int(r['Start_Timestamp']); e = int(r['End_Timestamp'])
+    name = r['Kernel_Name'].split('(')[0].replace('void ', '')[:34]
+    print(f"{(s-t0)/1e3:9.1f} us  gap {(s-prev_end)/1e3:7.1f}  dur {(e-s)/1e3:8.1f}  {name}  wgs={int(r['Grid_Size_X'])//int(r['Workgroup_Size_X'])}")
+    prev_end = e
+    if name.startswith('bwt_emit'):
+        break
