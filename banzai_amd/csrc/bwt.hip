@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(1024) byte_count(const uint8_t *blk, const uin
 // Big-list round, step 1: re-key the block's big list ONCE (one gather of rank[i+h] per listed suffix;
 // the suffix's own group rank is in the record) into dst, same slot, and count all five 8-bit digits of
 // the new keys (bits 20..59) into the block's totals, from which active_bases makes the bases of the
-// five look-back passes that follow.  The totals are cleared by round_begin.
+// five look-back passes that follow (which also clears the totals again).
 __global__ void __launch_bounds__(SORT_THREADS) active_gen(SortArgs a, uint32_t *dtot)
 {
     uint32_t b, tile;
@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(SORT_THREADS) active_gen(SortArgs a, uint32_t 
 }
 
 // One workgroup per listed block: exclusive scan inside each of the ndig digit groups of dtot.
-__global__ void __launch_bounds__(256) active_bases(const uint32_t *dtot, uint32_t *dbase, Lst lst, int ndig)
+__global__ void __launch_bounds__(256) active_bases(uint32_t *dtot, uint32_t *dbase, Lst lst, int ndig)
 {
     const uint32_t k = blockIdx.x;
     if (k >= (lst.ids ? *lst.cnt : lst.B)) return;
@@ -297,6 +297,7 @@ __global__ void __launch_bounds__(256) active_bases(const uint32_t *dtot, uint32
 #pragma unroll 1
     for (int p = 0; p < ndig; p++) {
         const uint32_t v = dtot[(size_t)b * DB_STRIDE + p * 256 + threadIdx.x];
+        dtot[(size_t)b * DB_STRIDE + p * 256 + threadIdx.x] = 0; // consumed: clean for the next round's counting
         uint32_t tot;
         const uint32_t ex = block_excl_add(v, ls, &tot);
         dbase[(size_t)b * DB_STRIDE + p * 256 + threadIdx.x] = ex;
@@ -1217,11 +1218,6 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
     for (int k = 0; k < 6; k++) {
         const uint32_t off = block_excl_add(fl[k], ls, &tot[k]);
         if (fl[k]) dst[k][off] = b;
-    }
-    __syncthreads(); // the lists are complete (workgroup scope)
-    for (uint32_t k = 0; k < tot[L_A]; k++) { // digit totals of the big-list passes (active_gen adds to them)
-        uint32_t *t = bt.dtot + (size_t)bt.actA[k] * DB_STRIDE;
-        for (uint32_t w = threadIdx.x; w < (uint32_t)DB_STRIDE; w += blockDim.x) t[w] = 0;
     }
     if (valid) {
         atomicMax(&accmax[0], gS);

@@ -12,7 +12,7 @@
 //   * code lengths from the reference's own binary heap, operation for operation (:165-298)
 //
 // Kernels: huff_init (ranges), huff_segments (segment classification + per-table histograms),
-// huff_build (exact heap, one wavefront per table, lane 0 drives, heap in LDS), huff_header
+// huff_build (exact heap in LDS, one wavefront per table working in lock step), huff_header
 // (block header, symbol map, coding tables as a bit string; canonical codes; bit totals),
 // block_scan, pack_tilebits / pack_tilescan / pack_symbols (prefix-sum placed parallel pack through
 // an LDS word buffer), pack_headers.
@@ -112,115 +112,157 @@ __global__ void __launch_bounds__(256) huff_segments(Batch bt, const uint32_t *r
 }
 
 // ---- exact heap (lib/huffman.rs:161-298) ---------------------------------------------------------------
+// The reference's binary heap decides, through the positions at which equal priorities happen to sit,
+// which symbol gets which length, so it is replayed operation for operation -- but by a whole
+// wavefront in lock step instead of one lane chasing pointers through LDS:
+//   insert  (:196-222): every ancestor slot idx>>1, idx>>2, ... of the new leaf is known up front, so the
+//           lanes fetch all of them at once, a ballot says how far the new priority rises, and the passed
+//           ancestors drop one level in a single store -- one LDS round trip per insert;
+//   extract (:225-267): 30 lanes fetch the four levels below the hole (2 + 4 + 8 + 16 slots) at once; each
+//           compares with its sibling (right child only if strictly smaller), two ballots describe the
+//           preferred children and where the moved element stops, the path is walked in scalar registers
+//           and the path's slots rise one level in a single store -- one round trip per four levels.
+// Control flow is uniform across the wavefront; the heap itself stays in LDS.
 struct HeapMem {
     // one word per heap slot: ((weight << 8 | depth) << 10) | node id.  The reference orders by the
     // lexicographic Priority(usize, u8) alone -- ids never take part in a comparison (they are shifted
-    // out) -- so a slot moves with one LDS access instead of two.
+    // out).  weight <= 4 m + 258 < 2^22, so a priority fits 32 bits.
     uint64_t key[HUF_SYMS + 2];
-    int16_t lch[2 * HUF_SYMS], rch[2 * HUF_SYMS];
-    int16_t depth[2 * HUF_SYMS];
+    int16_t par[2 * HUF_SYMS]; // parent of every tree node (root = 0)
     uint32_t fr[HUF_SYMS];
 };
 constexpr int HEAP_ID_BITS = 10; // node ids < 2 * 258
+#define HEAP_ORDER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-__device__ void heap_insert(HeapMem &h, uint32_t &len, uint16_t sym, uint64_t pr) // :196-222
+__device__ __forceinline__ void heap_insert(HeapMem &h, uint32_t &len, uint32_t id, uint32_t pr, uint32_t lane) // :196-222
 {
-    const uint32_t init_idx = len + 1;
-    const uint64_t mine = (pr << HEAP_ID_BITS) | sym;
-    h.key[init_idx] = mine;
+    const uint32_t idx = len + 1;
     len++;
-    if (init_idx == 1) return;
-    uint32_t this_idx = init_idx;
-    for (;;) {
-        const uint32_t above = this_idx >> 1;
-        const uint64_t ak = h.key[above];
-        if (pr < (ak >> HEAP_ID_BITS)) {
-            h.key[this_idx] = ak;
-            this_idx = above;
-            if (this_idx == 1) break;
-        } else {
-            break;
-        }
-    }
-    if (this_idx != init_idx) h.key[this_idx] = mine;
+    const uint32_t k = lane + 1;   // lane 0 looks at the parent, lane 1 at the grandparent, ...
+    const uint32_t anc = k < 16 ? idx >> k : 0u; // 0: no such ancestor
+    const uint64_t ak = anc ? h.key[anc] : 0ull;
+    const bool lt = anc && pr < (uint32_t)(ak >> HEAP_ID_BITS);
+    const uint64_t m = __ballot(lt);
+    const uint32_t d = (uint32_t)__builtin_ctzll(~m); // levels the new entry rises (uniform)
+    if (k <= d) h.key[idx >> (k - 1)] = ak;          // the passed ancestors drop one level
+    if (lane == 0) h.key[idx >> d] = ((uint64_t)pr << HEAP_ID_BITS) | id;
+    HEAP_ORDER();
 }
 
-__device__ void heap_extract(HeapMem &h, uint32_t &len, uint16_t &osym, uint64_t &oprio) // :225-267
+__device__ __forceinline__ void heap_extract(HeapMem &h, uint32_t &len, uint32_t &oid, uint32_t &opr, uint32_t lane) // :225-267
 {
     const uint64_t lk = h.key[len];
-    const uint64_t lpr = lk >> HEAP_ID_BITS;
     len--;
     if (len == 0) {
-        osym = (uint16_t)(lk & ((1u << HEAP_ID_BITS) - 1u));
-        oprio = lpr;
+        oid = (uint32_t)lk & ((1u << HEAP_ID_BITS) - 1u);
+        opr = (uint32_t)(lk >> HEAP_ID_BITS);
         return;
     }
     const uint64_t top = h.key[1];
-    osym = (uint16_t)(top & ((1u << HEAP_ID_BITS) - 1u));
-    oprio = top >> HEAP_ID_BITS;
-    uint32_t this_idx = 1;
+    oid = (uint32_t)top & ((1u << HEAP_ID_BITS) - 1u);
+    opr = (uint32_t)(top >> HEAP_ID_BITS);
+    const uint32_t lpr = (uint32_t)(lk >> HEAP_ID_BITS);
+    // lane -> slot of the subtree below the hole: level 1 = lanes 0-1, 2 = 2-5, 3 = 6-13, 4 = 14-29
+    const uint32_t lvl = lane < 2 ? 1u : lane < 6 ? 2u : lane < 14 ? 3u : 4u;
+    const uint32_t off = lane - ((1u << lvl) - 2u);
+    uint32_t hole = 1;
     for (;;) {
-        const uint32_t left = this_idx << 1;
-        if (left > len) break;
-        const uint32_t right = left + 1;
-        uint32_t below = left;
-        uint64_t bk = h.key[left];
-        if (right <= len) {
-            const uint64_t rk = h.key[right];
-            if ((rk >> HEAP_ID_BITS) < (bk >> HEAP_ID_BITS)) {
-                below = right;
-                bk = rk;
+        const uint32_t node = (hole << lvl) + off;
+        const bool ex = lane < 30 && node <= len;
+        const uint64_t k = ex ? h.key[node] : 0ull;
+        const uint32_t pr = ex ? (uint32_t)(k >> HEAP_ID_BITS) : 0xFFFFFFFFu;
+        const uint32_t spr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pr, 0xB1, 0xF, 0xF, false); // sibling: quad_perm [1,0,3,2]
+        const bool chosen = (off & 1u) ? (pr < spr) : !(spr < pr);  // right child only if strictly smaller
+        const bool cont = ex && !(lpr < pr);                        // the moved element passes this slot
+        const uint64_t cm = __ballot(chosen), gm = __ballot(cont);
+        // the path of preferred children, level by level (scalar)
+        const uint32_t a1 = (cm & 1ull) ? 0u : 1u;
+        const uint32_t l2 = 2u + 2u * a1, a2 = ((cm >> l2) & 1ull) ? l2 : l2 + 1u;
+        const uint32_t l3 = 6u + 2u * (a2 - 2u), a3 = ((cm >> l3) & 1ull) ? l3 : l3 + 1u;
+        const uint32_t l4 = 14u + 2u * (a3 - 6u), a4 = ((cm >> l4) & 1ull) ? l4 : l4 + 1u;
+        uint32_t d = 0;
+        uint64_t pm = 0; // path slots that rise one level
+        uint32_t nh = hole;
+        if ((gm >> a1) & 1ull) {
+            d = 1, pm |= 1ull << a1, nh = (hole << 1) + a1;
+            if ((gm >> a2) & 1ull) {
+                d = 2, pm |= 1ull << a2, nh = (hole << 2) + (a2 - 2u);
+                if ((gm >> a3) & 1ull) {
+                    d = 3, pm |= 1ull << a3, nh = (hole << 3) + (a3 - 6u);
+                    if ((gm >> a4) & 1ull) d = 4, pm |= 1ull << a4, nh = (hole << 4) + (a4 - 14u);
+                }
             }
         }
-        if (lpr < (bk >> HEAP_ID_BITS)) break;
-        h.key[this_idx] = bk;
-        this_idx = below;
+        if ((pm >> lane) & 1ull) h.key[node >> 1] = k;
+        hole = nh;
+        HEAP_ORDER();
+        if (d < 4) break;
     }
-    h.key[this_idx] = lk;
+    if (lane == 0) h.key[hole] = lk;
+    HEAP_ORDER();
 }
 
-__device__ void build_lengths(HeapMem &h, uint32_t nsyms, uint8_t *out) // :271-298
+// all 64 lanes of one wavefront; out = code lengths of the table
+__device__ void build_lengths(HeapMem &h, uint32_t nsyms, uint8_t *out, uint32_t lane) // :271-298
 {
-    uint32_t scaling = 1;
+    uint32_t sh = 0; // scaling = 1 << sh
     for (;;) {
         uint32_t nnodes = nsyms + 1, len = 0;
-        for (uint32_t s = 0; s < nsyms; s++) heap_insert(h, len, (uint16_t)(s + 1), ((uint64_t)(h.fr[s] / scaling + 1)) << 8);
+        for (uint32_t s = 0; s < nsyms; s++) heap_insert(h, len, s + 1, ((h.fr[s] >> sh) + 1u) << 8, lane);
         for (;;) {
-            uint16_t a, c;
-            uint64_t pa, pc;
-            heap_extract(h, len, a, pa);
-            heap_extract(h, len, c, pc);
+            uint32_t a, c, pa, pc;
+            heap_extract(h, len, a, pa, lane);
+            heap_extract(h, len, c, pc, lane);
             if (nnodes == 2 * nsyms - 1) { // Tree::tie :60-74 -- last tie hangs off the root (id 0)
-                h.lch[0] = (int16_t)a;
-                h.rch[0] = (int16_t)c;
+                if (lane == 0) {
+                    h.par[a] = 0;
+                    h.par[c] = 0;
+                }
                 break;
             }
             const uint32_t parent = nnodes++;
-            h.lch[parent] = (int16_t)a;
-            h.rch[parent] = (int16_t)c;
-            const uint64_t da = pa & 0xFF, dc = pc & 0xFF;
-            const uint64_t pr = (((pa >> 8) + (pc >> 8)) << 8) | ((da > dc ? da : dc) + 1); // :147-158
-            heap_insert(h, len, (uint16_t)parent, pr);
+            if (lane == 0) {
+                h.par[a] = (int16_t)parent;
+                h.par[c] = (int16_t)parent;
+            }
+            const uint32_t da = pa & 0xFFu, dc = pc & 0xFFu;
+            const uint32_t pr = (((pa >> 8) + (pc >> 8)) << 8) | ((da > dc ? da : dc) + 1u); // :147-158
+            heap_insert(h, len, parent, pr, lane);
         }
-        // leaf depths (:78-102): inner node ids grow with creation time, a parent is always newer
-        h.depth[h.lch[0]] = 1;
-        h.depth[h.rch[0]] = 1;
-        for (uint32_t idn = nnodes - 1; idn > nsyms; idn--) {
-            const int16_t d = h.depth[idn];
-            h.depth[h.lch[idn]] = (int16_t)(d + 1);
-            h.depth[h.rch[idn]] = (int16_t)(d + 1);
-        }
+        HEAP_ORDER();
+        // leaf depths (:78-102): every lane walks a few leaves up to the root
+        uint32_t dep[(HUF_SYMS + 63) / 64];
         int maxlen = 0;
-        for (uint32_t s = 0; s < nsyms; s++) maxlen = max(maxlen, (int)h.depth[s + 1]);
+#pragma unroll
+        for (int q = 0; q < (HUF_SYMS + 63) / 64; q++) {
+            const uint32_t s = q * 64 + lane;
+            dep[q] = 0;
+            if (s < nsyms) {
+                uint32_t x = s + 1, dd = 0;
+                do {
+                    x = (uint32_t)h.par[x];
+                    dd++;
+                } while (x != 0);
+                dep[q] = dd;
+                maxlen = max(maxlen, (int)dd);
+            }
+        }
+#pragma unroll
+        for (int s2 = 32; s2 > 0; s2 >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, s2, 64));
         if (maxlen <= HUF_MAXLEN) {
-            for (uint32_t s = 0; s < nsyms; s++) out[s] = (uint8_t)h.depth[s + 1];
+#pragma unroll
+            for (int q = 0; q < (HUF_SYMS + 63) / 64; q++) {
+                const uint32_t s = q * 64 + lane;
+                if (s < nsyms) out[s] = (uint8_t)dep[q];
+            }
             return;
         }
-        scaling <<= 1;
+        sh++; // scaling <<= 1 (:293-296), redo from the original frequencies
+        HEAP_ORDER();
     }
 }
 
-// One wavefront per table (3 per workgroup); lane 0 walks the heap held in LDS.
+// One wavefront per table (3 per workgroup), all lanes in lock step; the heap lives in LDS.
 __global__ void __launch_bounds__(192) huff_build(Batch bt)
 {
     const uint32_t b = blockIdx.x;
@@ -231,9 +273,8 @@ __global__ void __launch_bounds__(192) huff_build(Batch bt)
     const uint32_t *tf = bt.tfreq + ((size_t)b * 3 + t) * HUF_SYMS;
     const uint32_t *F = bt.freqs + (size_t)b * HUF_SYMS;
     for (uint32_t s = lane; s < nsyms; s += 64) hm[t].fr[s] = tf[s] + (t == 0 ? 3u * F[s] : 0u);
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    if (lane == 0) build_lengths(hm[t], nsyms, bt.lens + ((size_t)b * 3 + t) * HUF_SYMS);
+    HEAP_ORDER();
+    build_lengths(hm[t], nsyms, bt.lens + ((size_t)b * 3 + t) * HUF_SYMS, lane);
 }
 
 // ---- header bit string + canonical codes + bit totals ----------------------------------------------------
