@@ -882,7 +882,7 @@ struct TailArgs {
     Lst lst;
 };
 
-// record: [resolved:1 @60][new rank:20 @40][0:20][suffix:20 @0]
+// record: [unchanged:1 @61][resolved:1 @60][new rank:20 @40][0:20][suffix:20 @0]
 template <bool QUAD>
 __global__ void __launch_bounds__(TAIL_THREADS) tail_sort(TailArgs a)
 {
@@ -1004,7 +1004,8 @@ __global__ void __launch_bounds__(TAIL_THREADS) tail_sort(TailArgs a)
             const uint32_t u = less + eq_before;
             const bool single = eq == 1;
             moved |= less != 0;
-            const u64 rec = ((u64)(single ? 1u : 0u) << 60) | ((u64)(r + less) << 40) | ci[j];
+            // bit 60: resolved; bit 61: rank unchanged and still unresolved (nothing to store for this suffix)
+            const u64 rec = ((u64)(single ? 1u : (less == 0u ? 2u : 0u)) << 60) | ((u64)(r + less) << 40) | ci[j];
             out[s_lo + g + u] = rec; // the u-th smallest member takes the slot of the u-th member
         }
     }
@@ -1044,9 +1045,9 @@ __global__ void __launch_bounds__(256) tail_finish(TailArgs a)
         if (x[k] != LIST_INVALID) {
             const uint32_t i = (uint32_t)(x[k] & SUF_MASK);
             const uint32_t nr = (uint32_t)(x[k] >> 40) & 0xFFFFFu;
-            const bool res = (x[k] >> 60) & 1ull;
+            const bool res = (x[k] >> 60) & 1ull, same = (x[k] >> 61) & 1ull;
             // (the last column is emitted from the ranks, so nothing but the rank is stored per suffix)
-            rank[i] = res ? (nr | RANK_RESOLVED) : nr;
+            if (!same) rank[i] = res ? (nr | RANK_RESOLVED) : nr;
             if (res) x[k] = LIST_INVALID;
         }
         const u64 m = __ballot(x[k] != LIST_INVALID);
@@ -1091,7 +1092,7 @@ __global__ void __launch_bounds__(256) tail_finish(TailArgs a)
     const uint32_t pre = tpre;
 #pragma unroll
     for (int k = 0; k < PER; k++)
-        if (x[k] != LIST_INVALID) dst[pre + wc[k * NWV + wave] + lo[k]] = x[k] & ~(1ull << 60);
+        if (x[k] != LIST_INVALID) dst[pre + wc[k * NWV + wave] + lo[k]] = x[k] & ~(3ull << 60);
 }
 
 // ---- last column ---------------------------------------------------------------------------------
