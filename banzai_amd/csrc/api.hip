@@ -134,8 +134,9 @@ static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
         carve(p, rs, oA + 4);
         uint32_t **f[21] = {&bt.st_mode, &bt.st_h, &bt.st_nbig, &bt.st_ntail, &bt.c_big, &bt.c_small, &bt.c_tail,
                             &bt.c_prog, &bt.gateS, &bt.gateA, &bt.gateR, &bt.gateT, &bt.actS, &bt.actA, &bt.actR,
-                            &bt.actT, &bt.actQ, nullptr, nullptr, nullptr, nullptr};
-        for (int k = 0; k < 17; k++) *f[k] = rs ? rs + (size_t)k * NB : nullptr;
+                            &bt.actT, &bt.actQ, nullptr, &bt.c_nolist, nullptr, nullptr}; // row 17: sixth list (bwt.hip)
+        for (int k = 0; k < 21; k++)
+            if (f[k]) *f[k] = rs ? rs + (size_t)k * NB : nullptr;
         bt.nlist = rs ? rs + 21 * NB : nullptr;
         bt.summary = rs ? rs + 21 * NB + 8 : nullptr;
         bt.stat_A = rs ? reinterpret_cast<unsigned long long *>(rs + oA) : nullptr;

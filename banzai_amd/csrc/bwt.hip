@@ -132,6 +132,13 @@ static inline uint32_t xcd_grid(uint32_t tiles, uint32_t NB)
     return (tiles & WG_SPREAD) ? (tiles & ~WG_SPREAD) * NB : 8u * ((NB + 7u) / 8u) * tiles;
 }
 
+// Where the rank of suffix i lives inside the block's rank array.  Periodic blocks visit suffixes at a
+// power-of-two stride (a 1024-byte tile repeated: members of a group sit 1024 suffixes = 4 KiB apart), which
+// would keep hitting the same few cache sets; folding bits 10..14 into bits 5..9 spreads such walks over 32
+// times as many lines.  Bits 0..4 are untouched: 32 consecutive suffixes still share one 128-byte line.
+// A bijection on every aligned 1024-block, so slots stay below the array stride.
+__device__ __forceinline__ uint32_t rslot(uint32_t i) { return i ^ (((i >> 10) & 31u) << 5); }
+
 // 4 bytes of the cyclic text starting at position i (big-endian), i < n.
 __device__ __forceinline__ uint32_t text4(const uint8_t *s, uint32_t i, uint32_t n)
 {
@@ -169,14 +176,14 @@ __device__ __forceinline__ bool gen_elem(const SortArgs &a, uint32_t b, uint32_t
         if (h < n) { // suffix j = sa[e] is the e-th smallest; i = j - h has it as its second half
             const uint32_t j = a.sa[base + e];
             i = j >= h ? j - h : j + n - h;
-            const uint32_t r = a.rank[base + i];
+            const uint32_t r = a.rank[base + rslot(i)];
             if (r & RANK_RESOLVED) return false;
             k2 = a.headp[base + e]; // = rank[j] without the gather
             v = ((u64)r << 40) | ((u64)k2 << 20) | i;
             return true;
         }
         i = n - 1 - e; // identical rotations: larger index first; e doubles as a distinct key2
-        const uint32_t r = a.rank[base + i];
+        const uint32_t r = a.rank[base + rslot(i)];
         if (r & RANK_RESOLVED) return false;
         v = ((u64)r << 40) | ((u64)e << 20) | i;
         return true;
@@ -255,7 +262,7 @@ __global__ void __launch_bounds__(SORT_THREADS) active_gen(SortArgs a, uint32_t 
             if (h < n) {
                 uint32_t i2 = i + h;
                 if (i2 >= n) i2 -= n;
-                k2 = rank[i2] & RANK_MASK;
+                k2 = rank[rslot(i2)] & RANK_MASK;
             } else {
                 k2 = n - 1 - i;
             }
@@ -479,6 +486,8 @@ struct RefineArgs {
     uint32_t *dig;       // [B][TPB][512]: per tile, counts of the three 7-bit digits of the new rank over the suffixes
                          // left unresolved (bases of the next SWEEP round's look-back passes; SWEEP-mode blocks only)
     uint32_t *c_big, *c_small, *c_prog; // [B] results: list lengths, "a group was refined"
+    uint32_t *c_nolist;  // [B] result: the lists were not written (see refine)
+    const uint32_t *nbig_in; // [B] suffixes in large groups when the round began
     uint32_t S, TPB;
     int init;
     uint32_t T;
@@ -633,6 +642,9 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
     // a block that may enumerate SA positions next round needs SA / group heads at EVERY position and the
     // digit counts of its unresolved ranks; a SPLIT-mode block only needs the final SA entries
     const bool sweep = a.mode[b] == 0u;
+    // A SWEEP-mode block that entered the round with most of its suffixes in large groups stays in SWEEP mode
+    // (which reads no list), so its lists are not written; round_begin keeps such a block from changing mode.
+    const bool nolist = sweep && !a.init && (uint64_t)a.nbig_in[b] * 2u >= a.n[b];
     const size_t base = (size_t)b * a.S;
     const uint32_t tile0 = tile * SORT_TILE;
     __shared__ u64 lds[STAGE_SLOTS];
@@ -742,6 +754,7 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
         if (tile == ntile - 1) { // the block's list lengths after this round
             a.c_small[b] = accS + totS;
             a.c_big[b] = accB + totB;
+            if (nolist) a.c_nolist[b] = 1u;
         }
     }
     __syncthreads(); // cpre*, and stage_tile's stores before the blocked reads below
@@ -776,7 +789,7 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
                 const uint32_t pos = gbase + q;
                 const uint32_t head = gbase + (uint32_t)cd;
                 const bool single = c == CLS_SINGLE;
-                rank[i] = single ? (head | RANK_RESOLVED) : head;
+                rank[rslot(i)] = single ? (head | RANK_RESOLVED) : head;
                 outv[k] = ((u64)c << 62) | ((u64)pos << 40) | ((u64)head << 20) | i;
                 if (sweep && !single) {
                     // heads rise with q, so a thread's 16 entries share their upper digits (and, inside
@@ -828,6 +841,8 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
     }
     // the ranked records of the unresolved suffixes leave through LDS as well: the tile's small-group records at
     // [0, totS), its large-group records behind them, then coalesced copies to the two lists
+    if (__ballot(progress) && (threadIdx.x & 63) == 0) a.c_prog[b] = 1u; // same value from everyone
+    if (nolist) return;
     {
         uint32_t wS = offS, wB = totS + offB;
 #pragma unroll
@@ -847,7 +862,6 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
         for (uint32_t e = threadIdx.x; e < totS; e += SORT_THREADS) ts[e] = lds[e];
         for (uint32_t e = threadIdx.x; e < totB; e += SORT_THREADS) bs[e] = lds[totS + e];
     }
-    if (__ballot(progress) && (threadIdx.x & 63) == 0) a.c_prog[b] = 1u; // same value from everyone
 }
 
 // ---- small groups: sorted locally ---------------------------------------------------------------------
@@ -961,14 +975,14 @@ __global__ void __launch_bounds__(TAIL_THREADS) tail_sort(TailArgs a)
                 if (h < n) {
                     uint32_t i2 = i + h;
                     if (i2 >= n) i2 -= n;
-                    k2 = rank[i2] & RANK_MASK;
+                    k2 = rank[rslot(i2)] & RANK_MASK;
                     if (QUAD) { // two more h-blocks of the (cyclic) rotation
                         uint32_t i3 = i2 + h;
                         if (i3 >= n) i3 -= n;
                         uint32_t i4 = i3 + h;
                         if (i4 >= n) i4 -= n;
-                        k3 = rank[i3] & RANK_MASK;
-                        k4 = rank[i4] & RANK_MASK;
+                        k3 = rank[rslot(i3)] & RANK_MASK;
+                        k4 = rank[rslot(i4)] & RANK_MASK;
                     }
                 } else {
                     k2 = n - 1 - i; // identical rotations: larger index first
@@ -1047,7 +1061,7 @@ __global__ void __launch_bounds__(256) tail_finish(TailArgs a)
             const uint32_t nr = (uint32_t)(x[k] >> 40) & 0xFFFFFu;
             const bool res = (x[k] >> 60) & 1ull, same = (x[k] >> 61) & 1ull;
             // (the last column is emitted from the ranks, so nothing but the rank is stored per suffix)
-            if (!same) rank[i] = res ? (nr | RANK_RESOLVED) : nr;
+            if (!same) rank[rslot(i)] = res ? (nr | RANK_RESOLVED) : nr;
             if (res) x[k] = LIST_INVALID;
         }
         const u64 m = __ballot(x[k] != LIST_INVALID);
@@ -1118,14 +1132,14 @@ __global__ void __launch_bounds__(256) bwt_emit(Batch bt, uint32_t T, uint32_t B
         uint32_t r[4];
         uint8_t c[4];
         const uint32_t m = min(4u, n - i0);
-        if (m == 4) {
-            const uint4 rv = *reinterpret_cast<const uint4 *>(rank + i0);
+        if (m == 4) { // (4 | i0, and rslot keeps the low five bits: the four slots are adjacent)
+            const uint4 rv = *reinterpret_cast<const uint4 *>(rank + rslot(i0));
             r[0] = rv.x;
             r[1] = rv.y;
             r[2] = rv.z;
             r[3] = rv.w;
         } else {
-            for (uint32_t k = 0; k < m; k++) r[k] = rank[i0 + k];
+            for (uint32_t k = 0; k < m; k++) r[k] = rank[rslot(i0 + k)];
         }
         c[0] = s[i0 ? i0 - 1 : n - 1];
         for (uint32_t k = 1; k < m; k++) c[k] = s[i0 + k - 1];
@@ -1178,7 +1192,7 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
         }
         // SWEEP mode pays a sweep of all n positions + 3 passes, the big-list path ~6 passes over the large
         // groups only: leave SWEEP mode, for good, once those hold less than a third of the block
-        if (mode == 0u && (uint64_t)nbig * 3u < n) mode = 1u;
+        if (mode == 0u && (uint64_t)nbig * 3u < n && !bt.c_nolist[b]) mode = 1u;
         const uint32_t unres = nbig + ntail;
         if (mode == 0u) {
             gS = unres;
@@ -1197,6 +1211,7 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
         bt.c_small[b] = 0;
         bt.c_tail[b] = 0;
         bt.c_prog[b] = 0;
+        bt.c_nolist[b] = 0;
         atomicAdd(&acc64[0], (unsigned long long)(gS + gA + gT));
         atomicAdd(&acc64[1], (unsigned long long)gS);
         atomicAdd(&acc64[2], (unsigned long long)gA);
@@ -1426,6 +1441,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     r.c_big = bt.c_big;
     r.c_small = bt.c_small;
     r.c_prog = bt.c_prog;
+    r.c_nolist = bt.c_nolist;
+    r.nbig_in = bt.st_nbig;
     r.S = bt.S;
     r.TPB = bt.TPB;
     r.init = 1;

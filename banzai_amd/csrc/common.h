@@ -98,6 +98,7 @@ struct Batch {
     uint32_t *st_nbig;  // records in the big-group list (SPLIT) / unresolved suffixes (SWEEP)
     uint32_t *st_ntail; // records in the small-group list
     uint32_t *c_big, *c_small, *c_tail, *c_prog; // produced by a round: list lengths, "some group was refined"
+    uint32_t *c_nolist; // produced by a round: refine did not write the block's lists (SWEEP mode, mostly large groups)
     uint32_t *gateS, *gateA, *gateR, *gateT;     // this round: sorted-list length per path (0 = not on that path)
     uint32_t *actS, *actA, *actR, *actT, *actQ;  // this round: ids of the blocks on each path (Q: TAIL at depth x4)
     uint32_t *nlist;    // [8] lengths of those lists (S, A, R, T, Q)
