@@ -76,6 +76,8 @@ SIGNATURES = {
                                       szp, u8p, ctypes.c_size_t]),
     "bzh_crc32": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_size_t, u32p]),
     "bzh_bwt_batch": (ctypes.c_int, [ctypes.c_void_p, u8p, u64p, u32p, ctypes.c_size_t, u8p, u32p, u8p]),
+    "bzh_unbwt_batch": (ctypes.c_int, [ctypes.c_void_p, u8p, u64p, u32p, u32p, ctypes.c_size_t, u8p]),
+    "bzh_bwt_roundtrip_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, u64p]),
     "bzh_bwt": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_size_t, u8p, u32p, u8p]),
     "bzh_mtf": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_size_t, u8p, u16p, szp, u32p, u32p]),
     "bzh_huffman": (ctypes.c_int, [ctypes.c_void_p, u16p, ctypes.c_size_t, ctypes.c_uint32, u32p, u8p,
@@ -194,6 +196,24 @@ class Context:
             o = int(offs[k])
             res.append((out[o:o + int(lens[k])].tobytes(), int(ptrs[k]), hb[k * 256:(k + 1) * 256].copy()))
         return res
+
+    def unbwt_batch(self, blocks):
+        """blocks: [(bwt bytes, ptr)] -> [original bytes], computed on the GPU (bzh_unbwt_batch)"""
+        lens = np.array([len(b) for b, _ in blocks], dtype=np.uint32)
+        ptrs = np.array([p for _, p in blocks], dtype=np.uint32)
+        offs = np.zeros(len(blocks), dtype=np.uint64)
+        offs[1:] = np.cumsum(lens[:-1], dtype=np.uint64)
+        cat = np.frombuffer(b"".join(bytes(b) for b, _ in blocks), dtype=np.uint8).copy()
+        out = np.zeros_like(cat)
+        self.check(lib().bzh_unbwt_batch(self._h, ptr(cat), ptr(offs, u64p), ptr(lens, u32p), ptr(ptrs, u32p),
+                                         len(blocks), ptr(out)))
+        return [out[int(offs[k]):int(offs[k]) + int(lens[k])].tobytes() for k in range(len(blocks))]
+
+    def bwt_roundtrip_device(self, b0, b1):
+        """forward + inverse BWT of plan blocks [b0, b1) on the device -> number of mismatching bytes"""
+        bad = ctypes.c_uint64(0)
+        self.check(lib().bzh_bwt_roundtrip_device(self._h, b0, b1, ctypes.byref(bad)))
+        return int(bad.value)
 
     def mtf(self, bwt_bytes, has_byte):
         a = np.frombuffer(bytes(bwt_bytes), dtype=np.uint8).copy()

@@ -365,6 +365,74 @@ extern "C" int bzh_bwt(bzh_ctx *ctx, const uint8_t *in, size_t n, uint8_t *bwt_o
     });
 }
 
+// ---- verification tooling: inverse BWT -----------------------------------------------
+extern "C" int bzh_unbwt_batch(bzh_ctx *ctx, const uint8_t *bwt, const uint64_t *offs, const uint32_t *lens,
+                               const uint32_t *ptr, size_t nblk, uint8_t *out)
+{
+    return bzh_guard(ctx, [&]() -> int {
+    if (ctx) stream_join(ctx);
+    if (!ctx || !bwt || !offs || !lens || !ptr || !out) return BZH_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Batch &bt = ctx->bt;
+    for (size_t k0 = 0; k0 < nblk; k0 += ctx->max_batch) {
+        const uint32_t B = (uint32_t)std::min<size_t>(ctx->max_batch, nblk - k0);
+        uint32_t nmax = 0;
+        for (uint32_t b = 0; b < B; b++) {
+            const uint32_t n = lens[k0 + b];
+            if (n == 0 || n > ctx->M || ptr[k0 + b] >= n) {
+                bzh_set_error(ctx, "block %zu: length %u / pointer %u out of range", k0 + b, n, ptr[k0 + b]);
+                return BZH_E_ARG;
+            }
+            nmax = std::max(nmax, n);
+            HIP_TRY(ctx, hipMemcpyAsync(bt.bwt + (size_t)b * bt.S, bwt + offs[k0 + b], n, hipMemcpyHostToDevice, ctx->stream));
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(bt.n, lens + k0, B * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(bt.ptr, ptr + k0, B * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        BZH_TRY(unbwt_run(ctx, B, nmax));
+        for (uint32_t b = 0; b < B; b++)
+            HIP_TRY(ctx, hipMemcpyAsync(out + offs[k0 + b], bt.mtfpos + (size_t)b * bt.S, lens[k0 + b], hipMemcpyDeviceToHost,
+                                        ctx->stream));
+        HIP_TRY(ctx, bzh_stream_wait(ctx->stream));
+    }
+    return BZH_OK;
+    });
+}
+
+// Forward + inverse transform of plan blocks [b0, b1) entirely on the device: RLE1 bytes -> BWT -> inverse BWT,
+// compared with the RLE1 bytes.  *mismatches = differing bytes (0 for a correct transform).
+extern "C" int bzh_bwt_roundtrip_device(bzh_ctx *ctx, size_t b0, size_t b1, uint64_t *mismatches)
+{
+    return bzh_guard(ctx, [&]() -> int {
+    if (ctx) stream_join(ctx);
+    if (!ctx || !mismatches || b0 > b1) return BZH_E_ARG;
+    if (b1 > ctx->plan_blocks.size()) return BZH_E_STATE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    unsigned long long *d_acc = ctx->bt.stat_A; // (the forward sort has read it back by the time it is reused)
+    unsigned long long total = 0;
+    for (size_t k0 = b0; k0 < b1; k0 += ctx->max_batch) {
+        const uint32_t B = (uint32_t)std::min<size_t>(ctx->max_batch, b1 - k0);
+        uint32_t nmax = 0;
+        uint64_t ntotal = 0;
+        for (uint32_t b = 0; b < B; b++) {
+            nmax = std::max(nmax, ctx->plan_blocks[k0 + b].rle_len);
+            ntotal += ctx->plan_blocks[k0 + b].rle_len;
+        }
+        BZH_TRY(rle1_emit(ctx, k0, B));
+        BZH_TRY(bwt_run(ctx, B, nmax, ntotal));
+        BZH_TRY(unbwt_run(ctx, B, nmax));
+        HIP_TRY(ctx, hipMemsetAsync(d_acc, 0, sizeof(unsigned long long), st));
+        BZH_TRY(unbwt_compare(ctx, B, nmax, d_acc));
+        unsigned long long part = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&part, d_acc, sizeof part, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, bzh_stream_wait(st));
+        total += part;
+    }
+    *mismatches = total;
+    return BZH_OK;
+    });
+}
+
 // ---- stage seam: MTF + RLE2 ---------------------------------------------------------------------------
 extern "C" int bzh_mtf(bzh_ctx *ctx, const uint8_t *bwt, size_t n, const uint8_t *has_byte, uint16_t *syms,
                        size_t *m, uint32_t *freqs, uint32_t *num_syms)

@@ -61,7 +61,8 @@ typedef unsigned long long u64;
 enum GenMode : int {
     GEN_BYTES4 = 0, // element e is suffix e keyed by its 4-byte cyclic prefix
     GEN_SWEEP = 1,  // doubling round, SA-order enumeration
-    GEN_LIST = 3    // element e is src[e]
+    GEN_LIST = 3,   // element e is src[e]
+    GEN_LCOL = 4    // inverse BWT: element e is position e of the last column, keyed by its byte
 };
 
 constexpr u64 SUF_MASK = 0xFFFFFull;
@@ -186,6 +187,9 @@ __device__ __forceinline__ bool gen_elem(const SortArgs &a, uint32_t b, uint32_t
         const uint32_t r = a.rank[base + rslot(i)];
         if (r & RANK_RESOLVED) return false;
         v = ((u64)r << 40) | ((u64)e << 20) | i;
+        return true;
+    } else if (MODE == GEN_LCOL) {
+        v = ((u64)a.blk[base + e] << 32) | e;
         return true;
     } else {
         v = a.src[base + e];
@@ -1630,6 +1634,133 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     if (gx == 0) gx = 1;
     if (B < 8) gx |= WG_SPREAD;
     bwt_emit<<<dim3(xcd_grid(gx, B)), 256, 0, st>>>(bt, gx, B);
+    HIP_TRY(ctx, hipGetLastError());
+    return BZH_OK;
+}
+
+
+// ---- inverse transform (verification tooling) -------------------------------------------
+// The reference has no decoder (README.md:9); its fuzz target round-trips through libbz2
+// (fuzz/fuzz_targets/round_trip.rs:8-22).  This is the device-side counterpart for the dominant stage: given a
+// last column L and the origin pointer, rebuild the block.  One stable radix pass keyed on L's bytes (the same
+// radix_scatter as the forward sort) yields T = LF^-1 (row r -> row of the rotation one byte further on);
+// the walk X[i] = T^i(ptr) is then computed for all i at once by doubling: with X[0..m) and P = T^m known,
+// X[m+i] = P[X[i]] and T^2m = P o P -- log2 n rounds of gathers, no serial list traversal, and blocks made of
+// repeated words (several cycles in T) need no special care.  S[i] = L[X[i+1]].
+struct UnbwtArgs {
+    const uint8_t *L;    // [B][S] last column
+    const uint32_t *n;   // [B]
+    const uint32_t *ptr; // [B]
+    const u64 *list;     // [B][S] sorted (byte, position) pairs
+    uint32_t *P, *P2;    // [B][S] T^m and T^2m
+    uint32_t *X;         // [B][S] X[i] = T^i(ptr)
+    uint8_t *out;        // [B][S]
+    uint32_t S, m;
+};
+
+__global__ void __launch_bounds__(256) unbwt_init(UnbwtArgs a)
+{
+    const uint32_t b = blockIdx.y, n = a.n[b];
+    const size_t base = (size_t)b * a.S;
+    for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) a.P[base + r] = (uint32_t)(a.list[base + r] & 0xFFFFFFFFull);
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.X[base] = a.ptr[b];
+}
+
+__global__ void __launch_bounds__(256) unbwt_round(UnbwtArgs a)
+{
+    const uint32_t b = blockIdx.y, n = a.n[b], m = a.m;
+    if (m >= n) return;
+    const size_t base = (size_t)b * a.S;
+    const uint32_t *P = a.P + base;
+    const bool need_sq = 2u * m < n; // T^2m is only needed if another round follows
+    const uint32_t ext = min(m, n - m);
+    for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
+        if (need_sq) a.P2[base + r] = P[P[r]];
+        if (r < ext) a.X[base + m + r] = P[a.X[base + r]];
+    }
+}
+
+__global__ void __launch_bounds__(256) unbwt_emit(UnbwtArgs a)
+{
+    const uint32_t b = blockIdx.y, n = a.n[b];
+    const size_t base = (size_t)b * a.S;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t nx = i + 1 < n ? a.X[base + i + 1] : a.ptr[b];
+        a.out[base + i] = a.L[base + nx];
+    }
+}
+
+__global__ void __launch_bounds__(256) count_mismatch(const uint8_t *x, const uint8_t *y, const uint32_t *nn, uint32_t S, unsigned long long *acc)
+{
+    const uint32_t b = blockIdx.y, n = nn[b];
+    const size_t base = (size_t)b * S;
+    uint32_t bad = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) bad += x[base + i] != y[base + i];
+    bad = wave_reduce_add(bad);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(acc, (unsigned long long)bad);
+}
+
+// Inverse BWT of blocks 0..B-1 of the batch: reads bt.bwt / bt.ptr / bt.n, leaves the blocks in bt.mtfpos
+// (scratch of the forward path).  Uses the sort buffers and rank / sa / headp as work arrays.
+int unbwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax)
+{
+    Batch &bt = ctx->bt;
+    if (B == 0 || nmax == 0) return BZH_OK;
+    hipStream_t st = ctx->stream;
+    const Lst all{nullptr, nullptr, B};
+    u64 *bufA = reinterpret_cast<u64 *>(bt.listA);
+    SortArgs a{};
+    a.blk = bt.bwt;
+    a.n = bt.n;
+    a.cnt = bt.n;
+    a.lst = all;
+    a.S = bt.S;
+    a.TPB = bt.TPB;
+    a.shift = 32;
+    a.src = nullptr;
+    a.dst = bufA;
+    a.look = reinterpret_cast<u64 *>(bt.hist);
+    a.dbase = bt.dbase;
+    a.doff = 0;
+    a.err = bt.errflag;
+    a.pass = 0;
+    HIP_TRY(ctx, hipMemsetAsync(bt.errflag, 0, sizeof(uint32_t), st));
+    HIP_TRY(ctx, hipMemsetAsync(a.look, 0, (size_t)B * bt.TPB * NBMAX * sizeof(u64), st));
+    HIP_TRY(ctx, hipMemsetAsync(bt.dtot, 0, (size_t)B * DB_STRIDE * sizeof(uint32_t), st));
+    byte_count<<<dim3(BYTE_SEGS, B), 1024, 0, st>>>(bt.bwt, bt.n, bt.dtot, bt.S);
+    active_bases<<<dim3(B), 256, 0, st>>>(bt.dtot, bt.dbase, all, 1);
+    launch_pass<8, GEN_LCOL, false>(ctx, a, B, nmax);
+    UnbwtArgs u{};
+    u.L = bt.bwt;
+    u.n = bt.n;
+    u.ptr = bt.ptr;
+    u.list = bufA;
+    u.P = bt.rank;
+    u.P2 = bt.sa;
+    u.X = bt.headp;
+    u.out = bt.mtfpos;
+    u.S = bt.S;
+    const dim3 grid(std::min<uint32_t>((nmax + 1023) / 1024, 512), B);
+    unbwt_init<<<grid, 256, 0, st>>>(u);
+    for (uint32_t m = 1; m < nmax; m <<= 1) {
+        u.m = m;
+        unbwt_round<<<grid, 256, 0, st>>>(u);
+        uint32_t *t = u.P;
+        u.P = u.P2;
+        u.P2 = t;
+    }
+    unbwt_emit<<<grid, 256, 0, st>>>(u);
+    HIP_TRY(ctx, hipGetLastError());
+    return BZH_OK;
+}
+
+// mismatching bytes between bt.rle and the inverse transform's output over blocks 0..B-1 (added to *d_acc)
+int unbwt_compare(bzh_ctx *ctx, uint32_t B, uint32_t nmax, unsigned long long *d_acc)
+{
+    Batch &bt = ctx->bt;
+    if (B == 0 || nmax == 0) return BZH_OK;
+    const dim3 grid(std::min<uint32_t>((nmax + 1023) / 1024, 512), B);
+    count_mismatch<<<grid, 256, 0, ctx->stream>>>(bt.rle, bt.mtfpos, bt.n, bt.S, d_acc);
     HIP_TRY(ctx, hipGetLastError());
     return BZH_OK;
 }

@@ -319,6 +319,8 @@ __device__ __forceinline__ int block_excl_min_rev(int v, int *lds)
 
 // ---- stage entry points (host side, defined in the stage files) ---------------------------------
 int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal); // bwt.hip
+int unbwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax);               // bwt.hip: inverse transform, bt.bwt/ptr -> bt.mtfpos
+int unbwt_compare(bzh_ctx *ctx, uint32_t B, uint32_t nmax, unsigned long long *d_acc); // bwt.hip: bt.rle vs bt.mtfpos
 int mtf_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax);                 // mtf.hip
 int huff_prepare(bzh_ctx *ctx, uint32_t B, uint32_t mmax);            // huffman.hip: tables, header bits, bit totals
 int huff_pack(bzh_ctx *ctx, uint32_t B, uint32_t mmax, uint8_t *d_out, uint64_t bit_base); // huffman.hip

@@ -172,6 +172,18 @@ BZH_API int bzh_bwt_batch(bzh_ctx *ctx, const uint8_t *in, const uint64_t *offs,
                   uint8_t *bwt_out, uint32_t *ptr, uint8_t *has_byte);
 BZH_API int bzh_bwt(bzh_ctx *ctx, const uint8_t *in, size_t n, uint8_t *bwt_out, uint32_t *ptr, uint8_t *has_byte);
 
+/* Verification tooling.  The reference has no decoder (README.md:9); its fuzz
+ * target round-trips through libbz2 (fuzz/fuzz_targets/round_trip.rs:8-22).  bzh_unbwt_batch is the inverse of
+ * bzh_bwt_batch computed on the GPU (one radix pass for the LF mapping, then pointer doubling): block k is
+ * bwt[offs[k] .. offs[k]+lens[k]) with origin pointer ptr[k]; out receives the original bytes at the same offsets. */
+BZH_API int bzh_unbwt_batch(bzh_ctx *ctx, const uint8_t *bwt, const uint64_t *offs, const uint32_t *lens,
+                    const uint32_t *ptr, size_t nblk, uint8_t *out);
+
+/* The same check without leaving the device, at any size: for blocks [b0, b1) of the current plan
+ * (bzh_plan_device*), RLE1 bytes -> BWT -> inverse BWT, compared with the RLE1 bytes on the GPU.
+ * *mismatches = number of differing bytes (0 when the transform is correct). */
+BZH_API int bzh_bwt_roundtrip_device(bzh_ctx *ctx, size_t b0, size_t b1, uint64_t *mismatches);
+
 /* mtf::mtf_and_rle (lib/mtf.rs:14-121): syms must hold n+1 entries, freqs 258. */
 BZH_API int bzh_mtf(bzh_ctx *ctx, const uint8_t *bwt, size_t n, const uint8_t *has_byte, uint16_t *syms, size_t *m,
             uint32_t *freqs, uint32_t *num_syms);

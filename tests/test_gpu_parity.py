@@ -467,6 +467,7 @@ def test_full_size_config4_one_gigabyte_and_world8_simulation(native, oracle):
         assert sum(b[1] for b in blocks) == n and all(0 < b[2] <= 899_999 for b in blocks)
         assert all(blocks[k][0] + blocks[k][1] == blocks[k + 1][0] for k in range(len(blocks) - 1))
         assert 1100 <= len(blocks) <= 1130
+        assert ctx.bwt_roundtrip_device(0, len(blocks)) == 0  # every block: BWT -> inverse BWT on the device
         # world = 8, rank by rank; a rank may only plan inside its resident prefix
         slab = sharded.worst_case_slab(n, world, 9)
         segs, keep, crcs, nblk = [], [], [], 0
@@ -487,6 +488,41 @@ def test_full_size_config4_one_gigabyte_and_world8_simulation(native, oracle):
     stream = mono.cpu().numpy().tobytes()
     assert stream[:4] == b"BZh9"
     assert oracle.decode(stream, cap=n + 64) == host.tobytes()
+
+
+def test_gpu_inverse_bwt_round_trip(oracle, ctx9, ctx1):
+    """f3: the GPU inverse transform undoes the GPU BWT (and the oracle's): periodic blocks (several cycles in the
+    LF mapping), runs, text, random, n = 1, 2; and equals what the reference's KAT says"""
+    import random
+    rng = random.Random(12)
+    blocks = [cases.gen(n, mode, 3) for mode in ("text", "longruns", "shortruns", "random", "same")
+              for n in (1, 2, 3, 255, 4096, 70_001)]
+    blocks += [b"ab" * 5000, b"abc" * 3333 + b"ab", bytes(rng.randrange(256) for _ in range(1024)) * 80, b"a" * 99_999,
+               cases.gen(899_999, "text", 4)]
+    fwd = ctx9.bwt_batch(blocks)
+    back = ctx9.unbwt_batch([(bw, p) for bw, p, _ in fwd])
+    assert back == [bytes(b) for b in blocks]
+    for blk in blocks[:12]:  # the oracle's transform is undone just the same
+        bw, p, _ = oracle.bwt(blk)
+        assert ctx1.unbwt_batch([(bw, p)]) == [bytes(blk)]
+    kat_in = b"If Peter Piper picked a peck of pickled peppers, where's the peck of pickled peppers Peter Piper picked?????"
+    bw, p, _ = ctx9.bwt(kat_in)
+    assert ctx9.unbwt_batch([(bw, p)]) == [kat_in]
+
+
+def test_bwt_round_trip_on_device_config3(native):
+    """BASELINE.json configs[2] at full size without leaving the GPU: every block's RLE1 bytes -> BWT -> inverse
+    BWT compare equal on the device (the reference's round_trip property for the dominant stage)"""
+    import torch
+    from banzai_amd import corpus
+    n = 100_000_000
+    data, _ = corpus.workload(n)
+    dev = torch.device("cuda", 0)
+    d_in = torch.zeros(n + 16, dtype=torch.uint8, device=dev)
+    d_in[:n] = torch.from_numpy(data).to(dev)
+    with native.Context(0, 9, 128) as ctx:
+        blocks = ctx.plan_device(d_in.data_ptr(), n)
+        assert ctx.bwt_roundtrip_device(0, len(blocks)) == 0
 
 
 def test_two_lanes_level9_several_batches(oracle, native):
