@@ -71,6 +71,22 @@ def main():
         r = ref_rle1.rle1(bytearray(d))
         rle_cases.append({"input_hex": d.hex(), "rle1_hex": bytes(r).hex()})
 
+    # multi-kilobyte RLE1 vectors (255 / 256 / 510 / 765-runs back to back): inputs come from the deterministic
+    # generators of stream_cases.py, so only digests are stored
+    import hashlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from tests.golden import stream_cases
+    large = {}
+    for name, make in stream_cases.RLE1_LARGE.items():
+        d = make()
+        r = bytes(ref_rle1.rle1(bytearray(d)))
+        large[name] = {"input_len": len(d), "input_sha256": hashlib.sha256(d).hexdigest(), "rle1_len": len(r),
+                       "rle1_sha256": hashlib.sha256(r).hexdigest()}
+    with open(os.path.join(HERE, "ref_rle1_large.json"), "w") as f:
+        json.dump({"generator": "tests/golden/gen_fixtures.py", "source": "reference debug/rle1.py on the inputs of "
+                   "tests/golden/stream_cases.py:RLE1_LARGE", "cases": large}, f, indent=1)
+    print(len(large), "large rle1 cases")
+
     with open(os.path.join(HERE, "ref_debug_vectors.json"), "w") as f:
         json.dump({"generator": "tests/golden/gen_fixtures.py", "source": "reference debug/bwt.py + debug/rle1.py",
                    "bwt": bwt_cases, "rle1": rle_cases}, f, indent=0)

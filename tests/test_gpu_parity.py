@@ -186,6 +186,38 @@ def test_golden_streams(ctx1, ctx9):
         assert ctx.encode(data).hex() == c["stream_hex"], c["name"]
 
 
+def test_model_streams_on_gpu(native):
+    """the HIP path against the digests of the independent Python model (tests/golden/model_streams.json)"""
+    import hashlib
+    from tests.golden import stream_cases
+    v = json.load(open(os.path.join(GOLDEN, "model_streams.json")))["cases"]
+    ctxs = {}
+    try:
+        for name, c in v.items():
+            level, data = stream_cases.CASES[name]()
+            assert hashlib.sha256(data).hexdigest() == c["input_sha256"], name
+            ctx = ctxs.setdefault(level, native.Context(0, level, 8))
+            got = ctx.encode(data)
+            assert len(got) == c["stream_len"] and hashlib.sha256(got).hexdigest() == c["stream_sha256"], name
+            infos, _ = ctx.rle1_split(data, want_bytes=False)
+            assert [(i[1], i[2]) for i in infos] == [tuple(x) for x in c["blocks_consumed_rle"]], name
+    finally:
+        for ctx in ctxs.values():
+            ctx.close()
+
+
+def test_rle1_large_reference_vectors_on_gpu(ctx9):
+    import hashlib
+    from tests.golden import stream_cases
+    v = json.load(open(os.path.join(GOLDEN, "ref_rle1_large.json")))["cases"]
+    for name, c in v.items():
+        d = stream_cases.RLE1_LARGE[name]()
+        assert hashlib.sha256(d).hexdigest() == c["input_sha256"], name
+        infos, chunks = ctx9.rle1_split(d)
+        assert len(infos) == 1 and infos[0][1] == len(d)
+        assert len(chunks[0]) == c["rle1_len"] and hashlib.sha256(chunks[0]).hexdigest() == c["rle1_sha256"], name
+
+
 @pytest.mark.parametrize("mode", cases.MODES)
 def test_stream_bit_exact_level1(oracle, ctx1, mode):
     for n in cases.SIZES_L1:

@@ -122,3 +122,35 @@ def test_huffman_table_quirks(oracle):
         assert tables.shape[0] == (2 if ns <= 199 else 3)
         assert tables[:, :ns].min() >= 1 and tables[:, :ns].max() <= 17
         assert bits > 0
+
+
+def test_model_streams_pin_the_oracle(oracle):
+    """whole streams from the independent Python restatement (tests/golden/pymodel.py, run by gen_streams.py in the
+    build container): three tables, the `scaling <<= 1` loop (lib/huffman.rs:293-296), block cuts at M-1
+    (lib/rle.rs:179-203), 255-chunk runs back to back, identical rotations"""
+    import hashlib
+    from tests.golden import stream_cases
+    v = json.load(open(os.path.join(GOLDEN, "model_streams.json")))["cases"]
+    assert set(v) == set(stream_cases.CASES)
+    assert any(c["tables"] == 3 for c in v.values()) and any(c["rescaled_to"] > 1 for c in v.values())
+    assert any(r == 100_000 * c["level"] - 2 for c in v.values() for _, r in c["blocks_consumed_rle"][:-1])
+    for name, c in v.items():
+        level, data = stream_cases.CASES[name]()
+        assert level == c["level"] and len(data) == c["input_len"], name
+        assert hashlib.sha256(data).hexdigest() == c["input_sha256"], name
+        got, infos = oracle.encode(data, level, want_blocks=True)
+        assert len(got) == c["stream_len"] and hashlib.sha256(got).hexdigest() == c["stream_sha256"], name
+        assert [(int(b.in_len), int(b.rle_len)) for b in infos] == [tuple(x) for x in c["blocks_consumed_rle"]], name
+
+
+def test_reference_rle1_large_vectors(oracle):
+    """multi-kilobyte outputs of the reference's debug/rle1.py (digests; inputs from stream_cases.RLE1_LARGE)"""
+    import hashlib
+    from tests.golden import stream_cases
+    v = json.load(open(os.path.join(GOLDEN, "ref_rle1_large.json")))["cases"]
+    assert set(v) == set(stream_cases.RLE1_LARGE)
+    for name, c in v.items():
+        d = stream_cases.RLE1_LARGE[name]()
+        assert len(d) == c["input_len"] and hashlib.sha256(d).hexdigest() == c["input_sha256"], name
+        r, _, used = oracle.rle_one(d, 9)  # every output is shorter than a level-9 block: the bound never bites
+        assert used == len(d) and len(r) == c["rle1_len"] and hashlib.sha256(r).hexdigest() == c["rle1_sha256"], name
