@@ -26,19 +26,16 @@ void bzh_set_error(bzh_ctx *ctx, const char *fmt, ...);
         }                                                                                          \
     } while (0)
 
-// Waits for a stream by polling.  hipStreamSynchronize sleeps on an interrupt and wakes 25-50 us late;
-// the encode path waits ~15 times per batch for a few counters each, so it polls instead (one host core
-// spins while the GPU works) and falls back to the blocking call for long waits.
-#include <chrono>
+// Waits for a stream.  The suffix-sort rounds no longer wait for the host (bwt.hip), so a batch is left with a
+// handful of waits (block table, bit totals, end of the pack): a short poll catches the ones that are about to
+// complete, then the thread blocks in hipStreamSynchronize instead of spinning on a core.
 static inline hipError_t bzh_stream_wait(hipStream_t st)
 {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned it = 0;; it++) {
+    for (unsigned it = 0; it < 256u; it++) {
         const hipError_t e = hipStreamQuery(st);
         if (e != hipErrorNotReady) return e;
-        if ((it & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
-            return hipStreamSynchronize(st);
     }
+    return hipStreamSynchronize(st);
 }
 
 #define BZH_TRY(expr)                                                                              \

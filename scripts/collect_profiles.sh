@@ -1,12 +1,13 @@
 #!/bin/bash
 # Runs on the GPU box: bench line, rocprofv3 kernel stats of the same command, PMC traffic passes.
 cd $GRAFT_REPO_ROOT
-python3 bench.py --steps 5 --warmup 1 > gpurun_out/bench_final.log 2>&1
+python3 bench.py --steps 10 --warmup 2 > gpurun_out/bench_final.log 2>&1
 tail -1 gpurun_out/bench_final.log
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -- python3 bench.py --steps 5 --warmup 1 --no-cpu > gpurun_out/bench_final_prof.log 2>&1
+rm -rf gpurun_out/prof_final gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -- python3 bench.py --steps 5 --warmup 1 --no-cpu --no-extra > gpurun_out/bench_final_prof.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- python3 bench.py --steps 1 --warmup 1 --no-cpu > gpurun_out/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- python3 bench.py --steps 1 --warmup 1 --no-cpu --no-extra > gpurun_out/pmc_$c.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, collections, json
@@ -19,7 +20,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         k = r['Kernel_Name'].split('(')[0].replace('void ', '')
         agg[k][0] += 1; agg[k][1] += float(r['Counter_Value'])
     res[c] = agg
-out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 1 --no-cpu` (2 passes of the hot path); "
+out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 1 --no-cpu --no-extra` (3 passes of the hot path: warm-up, timed, profiled); "
                "values in KB as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reads half of wide streaming reads, "
                "MI355X_MICROARCH.md HBM section; 8-byte-per-lane accesses are uncalibrated)", "kernels": {}}
 names = set(res["FETCH_SIZE"]) | set(res["WRITE_SIZE"])
