@@ -54,6 +54,7 @@ SIGNATURES = {
     "bzh_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "bzh_set_profiling": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "bzh_set_lanes": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "bzh_set_mode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "bzh_get_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Stats)]),
     "bzh_encode": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_size_t, u8p, ctypes.c_size_t, szp, szp]),
     "bzh_encode_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
@@ -161,6 +162,10 @@ class Context:
 
     def set_profiling(self, on=True):
         self.check(lib().bzh_set_profiling(self._h, 1 if on else 0))
+
+    def set_mode(self, fixed):
+        """False: the reference's Huffman behaviour (default, bit-identical); True: the opt-in "fixed" mode"""
+        self.check(lib().bzh_set_mode(self._h, 1 if fixed else 0))
 
     def set_lanes(self, lanes):
         self.check(lib().bzh_set_lanes(self._h, lanes))

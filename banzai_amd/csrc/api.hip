@@ -160,6 +160,15 @@ static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
     carve(p, bt.bitoff, NB + 1);
     carve(p, bt.symbits, NB * PT);
     carve(p, bt.desc, NB);
+    { // "fixed" Huffman mode (optional)
+        const size_t selmax = (S + 64 + 49) / 50 + 2;
+        carve(p, bt.fx_tfreq, NB * FX_TABLES * 258);
+        carve(p, bt.fx_lens, NB * FX_TABLES * 258);
+        carve(p, bt.fx_codes, NB * FX_TABLES * 258);
+        carve(p, bt.fx_sel, NB * selmax);
+        carve(p, bt.fx_selbits, NB * align_up((selmax * 6 + 7) / 8 + 8, 64));
+        carve(p, bt.fx_hdr, NB * FX_HDR_BYTES);
+    }
     return (size_t)(p - base);
 }
 
@@ -253,6 +262,17 @@ extern "C" int bzh_set_lanes(bzh_ctx *ctx, int lanes)
     if (ctx) stream_join(ctx);
     if (!ctx || (lanes != 1 && lanes != 2)) return BZH_E_ARG;
     ctx->nlanes = lanes;
+    return BZH_OK;
+    });
+}
+
+extern "C" int bzh_set_mode(bzh_ctx *ctx, int mode)
+{
+    return bzh_guard(ctx, [&]() -> int {
+    if (ctx) stream_join(ctx);
+    if (!ctx || (mode != BZH_MODE_REFERENCE && mode != BZH_MODE_FIXED)) return BZH_E_ARG;
+    ctx->mode = mode;
+    for (bzh_ctx *l : ctx->lanes) l->mode = mode;
     return BZH_OK;
     });
 }
@@ -480,6 +500,12 @@ extern "C" int bzh_huffman(bzh_ctx *ctx, const uint16_t *syms, size_t m, uint32_
         return BZH_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     stats_begin(ctx);
+    struct ModeGuard { // the seam is the reference's huffman::encode whatever mode the context is in
+        bzh_ctx *c;
+        int keep;
+        ~ModeGuard() { c->mode = keep; }
+    } guard{ctx, ctx->mode};
+    ctx->mode = BZH_MODE_REFERENCE;
     Batch &bt = ctx->bt;
     hipStream_t st = ctx->stream;
     const uint32_t m32 = (uint32_t)m;
@@ -605,6 +631,7 @@ static int ensure_lanes(bzh_ctx *ctx)
         l->level = ctx->level;
         l->M = ctx->M;
         l->max_batch = lane_mb;
+        l->mode = ctx->mode;
         layout_batch(l->bt, ctx->arena + (size_t)k * half, lane_mb, ctx->M);
         l->S = l->bt.S;
         if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess ||

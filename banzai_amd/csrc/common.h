@@ -122,11 +122,21 @@ struct Batch {
     uint64_t *bitoff;  // [B+1] exclusive scan of bits
     uint32_t *symbits; // [B][PT] per pack tile bit counts
     BlockDesc *desc;   // [B]
+    // "fixed" Huffman mode only (bzh_set_mode) -- the default path never touches these
+    uint32_t *fx_tfreq;  // [B][6][258]
+    uint8_t *fx_lens;    // [B][6][258]
+    uint32_t *fx_codes;  // [B][6][258] (len << 24 | word)
+    uint8_t *fx_sel;     // [B][FX_SELMAX] table of every 50-symbol segment
+    uint8_t *fx_selbits; // [B][FX_SELBYTES] selectors, MTF + unary coded, as a bit string
+    uint8_t *fx_hdr;     // [B][FX_HDR_BYTES] block header .. selector count, then the delta-coded tables
 };
 
 constexpr uint32_t MTF_TILE = 2048;  // BWT bytes walked by one wavefront
 constexpr uint32_t HDR_BYTES = 4160; // 64 B block header/symbol map/counts + up to 3 delta-coded tables (< 25.6 kbit)
 constexpr uint32_t PACK_TILE = 4096; // MTF symbols packed by one workgroup
+constexpr uint32_t FX_TABLES = 6;         // lib/huffman.rs:319-326 allows 2..6 tables
+constexpr uint32_t FX_HDR_A = 64;         // bytes reserved for the part before the selectors
+constexpr uint32_t FX_HDR_BYTES = 64 + 6 * 1152; // + up to 6 delta-coded tables (<= 5 + 258 * 35 bits each)
 
 struct Timer {
     hipEvent_t a = nullptr, b = nullptr;
@@ -143,6 +153,7 @@ struct bzh_ctx {
     uint32_t max_batch = 0;
     hipStream_t stream = nullptr;
     int profiling = 0;
+    int mode = 0;                     // BZH_MODE_REFERENCE / BZH_MODE_FIXED (bzh_set_mode)
     char err[512] = {0};      // last failure (guarded by err_mu: the streaming worker writes it too)
     char err_out[512] = {0};  // copy handed out by bzh_last_error
     std::mutex err_mu;

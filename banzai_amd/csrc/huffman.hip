@@ -411,17 +411,22 @@ constexpr int PACK_THREADS = 256;
 constexpr int PACK_ITEMS = 16;
 static_assert(PACK_THREADS * PACK_ITEMS == PACK_TILE, "pack tile");
 
-__global__ void __launch_bounds__(PACK_THREADS) pack_tilebits(Batch bt, uint32_t PT)
+// FX: the "fixed" mode -- every 50-symbol segment has its own table (bt.fx_sel), codes of up to 6 tables
+template <bool FX>
+__global__ void __launch_bounds__(PACK_THREADS) pack_tilebits(Batch bt, uint32_t PT, uint32_t selmax)
 {
     const uint32_t b = blockIdx.y, tile = blockIdx.x;
     const uint32_t m = bt.m[b];
     if (tile * PACK_TILE >= m) return;
-    __shared__ uint32_t cl[HUF_SYMS];
-    const uint32_t *codes = bt.codes + (size_t)b * HUF_SYMS;
+    constexpr uint32_t NT = FX ? FX_TABLES : 1u;
+    __shared__ uint32_t cl[NT * HUF_SYMS];
+    const uint32_t *codes = FX ? bt.fx_codes + (size_t)b * NT * HUF_SYMS : bt.codes + (size_t)b * HUF_SYMS;
     const uint32_t nsyms = bt.nsyms[b];
-    for (uint32_t k = threadIdx.x; k < nsyms; k += PACK_THREADS) cl[k] = codes[k] >> 24;
+    const uint32_t ntab = FX ? bt.ntab[b] : 1u;
+    for (uint32_t k = threadIdx.x; k < ntab * HUF_SYMS; k += PACK_THREADS) cl[k] = (k % HUF_SYMS) < nsyms ? codes[k] >> 24 : 0u;
     __syncthreads();
     const uint16_t *s = bt.syms + (size_t)b * (bt.S + 64);
+    const uint8_t *sel = bt.fx_sel + (size_t)b * selmax;
     const uint32_t q0 = tile * PACK_TILE + threadIdx.x * PACK_ITEMS;
     uint32_t bits = 0;
     if (q0 < m) {
@@ -429,7 +434,10 @@ __global__ void __launch_bounds__(PACK_THREADS) pack_tilebits(Batch bt, uint32_t
         const uint32_t w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
         for (int k = 0; k < PACK_ITEMS; k++)
-            if (q0 + k < m) bits += cl[(w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu];
+            if (q0 + k < m) {
+                const uint32_t tab = FX ? sel[(q0 + k) / SEG] : 0u;
+                bits += cl[tab * HUF_SYMS + ((w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu)];
+            }
     }
     __shared__ uint32_t ls[PACK_THREADS / 64 + 2];
     uint32_t tot;
@@ -455,16 +463,20 @@ __device__ __forceinline__ void or_be32(uint32_t *out, uint64_t word_idx, uint32
     if (v) atomicOr(out + word_idx, __builtin_bswap32(v));
 }
 
-__global__ void __launch_bounds__(PACK_THREADS) pack_symbols(Batch bt, uint32_t PT, uint32_t *out, uint64_t bit_base)
+template <bool FX>
+__global__ void __launch_bounds__(PACK_THREADS) pack_symbols(Batch bt, uint32_t PT, uint32_t *out, uint64_t bit_base, uint32_t selmax)
 {
     const uint32_t b = blockIdx.y, tile = blockIdx.x;
     const uint32_t m = bt.m[b];
     if (tile * PACK_TILE >= m) return;
-    __shared__ uint32_t cw[HUF_SYMS];
+    constexpr uint32_t NT = FX ? FX_TABLES : 1u;
+    __shared__ uint32_t cw[NT * HUF_SYMS];
     __shared__ uint32_t buf[PACK_TILE * HUF_MAXLEN / 32 + 4];
-    const uint32_t *codes = bt.codes + (size_t)b * HUF_SYMS;
+    const uint32_t *codes = FX ? bt.fx_codes + (size_t)b * NT * HUF_SYMS : bt.codes + (size_t)b * HUF_SYMS;
     const uint32_t nsyms = bt.nsyms[b];
-    for (uint32_t k = threadIdx.x; k < nsyms; k += PACK_THREADS) cw[k] = codes[k];
+    const uint32_t ntab = FX ? bt.ntab[b] : 1u;
+    const uint8_t *sel = bt.fx_sel + (size_t)b * selmax;
+    for (uint32_t k = threadIdx.x; k < ntab * HUF_SYMS; k += PACK_THREADS) cw[k] = (k % HUF_SYMS) < nsyms ? codes[k] : 0u;
     for (uint32_t k = threadIdx.x; k < PACK_TILE * HUF_MAXLEN / 32 + 4; k += PACK_THREADS) buf[k] = 0;
     __syncthreads();
     const uint16_t *s = bt.syms + (size_t)b * (bt.S + 64);
@@ -477,7 +489,10 @@ __global__ void __launch_bounds__(PACK_THREADS) pack_symbols(Batch bt, uint32_t 
         w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
 #pragma unroll
         for (int k = 0; k < PACK_ITEMS; k++)
-            if (q0 + k < m) bits += cw[(w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu] >> 24;
+            if (q0 + k < m) {
+                const uint32_t tab = FX ? sel[(q0 + k) / SEG] : 0u;
+                bits += cw[tab * HUF_SYMS + ((w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu)] >> 24;
+            }
     }
     __shared__ uint32_t ls[PACK_THREADS / 64 + 2];
     uint32_t tot;
@@ -493,7 +508,8 @@ __global__ void __launch_bounds__(PACK_THREADS) pack_symbols(Batch bt, uint32_t 
 #pragma unroll
         for (int k = 0; k < PACK_ITEMS; k++) {
             if (q0 + k < m) {
-                const uint32_t c = cw[(w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu];
+                const uint32_t tab = FX ? sel[(q0 + k) / SEG] : 0u;
+                const uint32_t c = cw[tab * HUF_SYMS + ((w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu)];
                 const uint32_t L = c >> 24;
                 acc = (acc << L) | (c & 0xFFFFFFu);
                 nacc += L;
@@ -544,6 +560,234 @@ __global__ void __launch_bounds__(64) pack_headers(Batch bt, uint32_t *out, uint
     or_bits(out, pos + hb[0] + hb[1], hdr + HDR_A, hb[2], lane);
 }
 
+__global__ void __launch_bounds__(64) fx_pack_headers(Batch bt, uint32_t *out, uint64_t bit_base, uint32_t selbytes)
+{
+    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+    const uint32_t *hb = bt.hdrbits + (size_t)b * 4;
+    const uint8_t *hdr = bt.fx_hdr + (size_t)b * FX_HDR_BYTES;
+    const uint64_t pos = bit_base + bt.bitoff[b];
+    or_bits(out, pos, hdr, hb[0], lane);
+    or_bits(out, pos + hb[0], bt.fx_selbits + (size_t)b * selbytes, hb[1], lane);
+    or_bits(out, pos + hb[0] + hb[1], hdr + FX_HDR_A, hb[2], lane);
+}
+
+// ================================================================================================================
+// "Fixed" Huffman mode (bzh_set_mode(ctx, BZH_MODE_FIXED); never the default: it is not
+// bit-identical to the reference).  What the reference's huffman::encode was meant to do (lib/huffman.rs:313-575):
+// 2..6 tables -- chosen from the NUMBER OF SYMBOLS as libbz2 does, where the reference matches on the alphabet size
+// and so never gets beyond 3 (:318-326) --, the equal-frequency initial partition (:333-376), and four refinement
+// iterations that keep the tables between iterations and restart the frequency lists, where the reference zeroes the
+// tables (:402-409) and ends up with one effective table.  Code lengths come from the same exact heap as the default
+// mode (any valid length assignment decodes; this one is already here).
+// ================================================================================================================
+__global__ void __launch_bounds__(64) fx_init(Batch bt)
+{
+    const uint32_t b = blockIdx.x;
+    uint32_t *tf = bt.fx_tfreq + (size_t)b * FX_TABLES * HUF_SYMS;
+    for (uint32_t k = threadIdx.x; k < FX_TABLES * HUF_SYMS; k += 64) tf[k] = 0;
+    if (threadIdx.x != 0) return;
+    const uint32_t nsyms = bt.nsyms[b], m = bt.m[b];
+    const uint32_t *F = bt.freqs + (size_t)b * HUF_SYMS;
+    const uint32_t ntab = m < 200 ? 2 : m < 600 ? 3 : m < 1200 ? 4 : m < 2400 ? 5 : 6;
+    bt.ntab[b] = ntab;
+    uint8_t *lens = bt.fx_lens + (size_t)b * FX_TABLES * HUF_SYMS;
+    uint32_t remaining = m, left = 0;
+    for (uint32_t t = 0; t < ntab; t++) {
+        uint32_t right = left, acc = 0;
+        bool empty = left >= nsyms; // fewer symbols than tables: the table starts without a range of its own
+        if (!empty) {
+            const uint32_t target = remaining / (ntab - t);
+            for (;;) {
+                acc += F[right];
+                if (acc >= target || right + 1 == nsyms) break;
+                right++;
+            }
+            if (right > left && t != 0 && t != ntab - 1 && (t & 1u)) {
+                acc -= F[right];
+                right--;
+            }
+        }
+        for (uint32_t s = 0; s < nsyms; s++) lens[t * HUF_SYMS + s] = (!empty && s >= left && s <= right) ? 0 : 15;
+        if (!empty) {
+            left = right + 1;
+            remaining -= acc;
+        }
+    }
+}
+
+// one refinement iteration, first half: every segment goes to the table that codes it in the fewest bits
+// (first minimum), and adds its symbols to that table's frequency list
+__global__ void __launch_bounds__(256) fx_segments(Batch bt, uint32_t selmax)
+{
+    const uint32_t b = blockIdx.y;
+    const uint32_t m = bt.m[b];
+    const uint32_t nseg = (m + SEG - 1) / SEG;
+    const uint32_t seg0 = blockIdx.x * 256;
+    if (seg0 >= nseg) return;
+    __shared__ uint32_t h[FX_TABLES][HUF_SYMS];
+    __shared__ uint64_t cost[HUF_SYMS]; // the six code lengths of a symbol, 10 bits each: one add per symbol sums all tables
+    for (int k = threadIdx.x; k < (int)(FX_TABLES * HUF_SYMS); k += 256) (&h[0][0])[k] = 0;
+    const uint32_t ntab = bt.ntab[b], nsyms = bt.nsyms[b];
+    const uint8_t *lens = bt.fx_lens + (size_t)b * FX_TABLES * HUF_SYMS;
+    for (uint32_t sidx = threadIdx.x; sidx < nsyms; sidx += 256) {
+        uint64_t c = 0;
+        for (uint32_t t = 0; t < ntab; t++) c |= (uint64_t)lens[t * HUF_SYMS + sidx] << (10 * t);
+        cost[sidx] = c;
+    }
+    __syncthreads();
+    const uint32_t seg = seg0 + threadIdx.x;
+    if (seg < nseg) {
+        const uint16_t *s = bt.syms + (size_t)b * (bt.S + 64) + (size_t)seg * SEG;
+        const uint32_t len = m - seg * SEG < SEG ? m - seg * SEG : SEG;
+        uint32_t w[SEG / 2];
+#pragma unroll
+        for (int k = 0; k < SEG / 2; k++) w[k] = reinterpret_cast<const uint32_t *>(s)[k];
+        uint64_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < SEG; k++) {
+            const uint32_t v = (w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+            if ((uint32_t)k < len) sum += cost[v];
+        }
+        uint32_t best = 0, bc = (uint32_t)sum & 1023u;
+        for (uint32_t t = 1; t < ntab; t++) {
+            const uint32_t c = (uint32_t)(sum >> (10 * t)) & 1023u;
+            if (c < bc) {
+                bc = c;
+                best = t;
+            }
+        }
+        bt.fx_sel[(size_t)b * selmax + seg] = (uint8_t)best;
+#pragma unroll
+        for (int k = 0; k < SEG; k++) {
+            const uint32_t v = (w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+            if ((uint32_t)k < len) atomicAdd(&h[best][v], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t *tf = bt.fx_tfreq + (size_t)b * FX_TABLES * HUF_SYMS;
+    for (int k = threadIdx.x; k < (int)(FX_TABLES * HUF_SYMS); k += 256) {
+        const uint32_t v = (&h[0][0])[k];
+        if (v) atomicAdd(&tf[k], v);
+    }
+}
+
+// second half: rebuild every table from its frequency list; the lists restart for the next iteration (not after
+// the last one: the header needs them for the payload size)
+__global__ void __launch_bounds__(64 * FX_TABLES) fx_build(Batch bt, int last)
+{
+    const uint32_t b = blockIdx.x;
+    const uint32_t t = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t ntab = bt.ntab[b], nsyms = bt.nsyms[b];
+    __shared__ HeapMem hm[FX_TABLES];
+    if (t >= ntab) return;
+    uint32_t *tf = bt.fx_tfreq + ((size_t)b * FX_TABLES + t) * HUF_SYMS;
+    for (uint32_t s = lane; s < nsyms; s += 64) {
+        hm[t].fr[s] = tf[s];
+        if (!last) tf[s] = 0;
+    }
+    HEAP_ORDER();
+    build_lengths(hm[t], nsyms, bt.fx_lens + ((size_t)b * FX_TABLES + t) * HUF_SYMS, lane);
+}
+
+__global__ void __launch_bounds__(64) fx_header(Batch bt, uint32_t selmax, uint32_t selbytes)
+{
+    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+    const uint32_t ntab = bt.ntab[b], nsyms = bt.nsyms[b], m = bt.m[b];
+    const uint8_t *lens = bt.fx_lens + (size_t)b * FX_TABLES * HUF_SYMS;
+    const uint32_t *tf = bt.fx_tfreq + (size_t)b * FX_TABLES * HUF_SYMS; // of the last iteration: symbols per table
+    uint8_t *hdr = bt.fx_hdr + (size_t)b * FX_HDR_BYTES;
+    uint32_t pay = 0;
+    for (uint32_t t = 0; t < ntab; t++)
+        for (uint32_t s = lane; s < nsyms; s += 64) pay += tf[t * HUF_SYMS + s] * lens[t * HUF_SYMS + s];
+    pay = wave_reduce_add(pay);
+    // canonical codes, one table per lane (lib/huffman.rs:548-561)
+    if (lane < ntab) {
+        const uint8_t *tl = lens + (size_t)lane * HUF_SYMS;
+        uint32_t *codes = bt.fx_codes + ((size_t)b * FX_TABLES + lane) * HUF_SYMS;
+        uint32_t minl = 255, maxl = 0;
+        for (uint32_t s = 0; s < nsyms; s++) {
+            minl = min(minl, (uint32_t)tl[s]);
+            maxl = max(maxl, (uint32_t)tl[s]);
+        }
+        uint32_t word = 0;
+        for (uint32_t l = minl; l <= maxl; l++) {
+            for (uint32_t s = 0; s < nsyms; s++)
+                if (tl[s] == l) codes[s] = (l << 24) | word++;
+            word <<= 1;
+        }
+    }
+    const uint32_t nsel = (m + SEG - 1) / SEG;
+    uint32_t selbits = 0;
+    if (lane == 1) { // selectors: move-to-front over the table ids, position j as j ones and a zero (:473-505)
+        BitW w{bt.fx_selbits + (size_t)b * selbytes, 0, 0, 0};
+        const uint8_t *sel = bt.fx_sel + (size_t)b * selmax;
+        uint32_t order = 0x543210u; // recency list, 4 bits per entry
+        for (uint32_t k = 0; k < nsel; k++) {
+            const uint32_t want = sel[k];
+            uint32_t j = 0;
+            while (((order >> (4 * j)) & 15u) != want) j++;
+            w.put((1u << (j + 1)) - 2u, j + 1);
+            const uint32_t lowmask = (1u << (4 * j)) - 1u;
+            order = (order & ~((1u << (4 * (j + 1))) - 1u)) | ((order & lowmask) << 4) | want;
+        }
+        w.flush();
+        selbits = w.bits;
+    }
+    selbits = (uint32_t)__shfl((int)selbits, 1, 64);
+    if (lane != 0) return;
+    BitW a{hdr, 0, 0, 0};
+    a.put(0x314159, 24);
+    a.put(0x265359, 24);
+    const uint32_t crc = bt.desc[b].crc;
+    a.put(crc >> 16, 16);
+    a.put(crc & 0xFFFF, 16);
+    a.put(0, 1);
+    a.put(bt.ptr[b], 24);
+    {
+        const uint8_t *hb = bt.hasbyte + (size_t)b * 256;
+        uint32_t sector_map = 0, sectors[16], ns = 0;
+        for (uint32_t x = 0; x < 16; x++) {
+            uint32_t sec = 0;
+            for (uint32_t y = 0; y < 16; y++) sec = (sec << 1) | (hb[(x << 4) | y] ? 1u : 0u);
+            sector_map <<= 1;
+            if (sec) {
+                sector_map |= 1;
+                sectors[ns++] = sec;
+            }
+        }
+        a.put(sector_map, 16);
+        for (uint32_t k = 0; k < ns; k++) a.put(sectors[k], 16);
+    }
+    a.put(ntab, 3);
+    a.put(nsel, 15);
+    a.flush();
+    BitW c{hdr + FX_HDR_A, 0, 0, 0};
+    for (uint32_t t = 0; t < ntab; t++) {
+        const uint8_t *tl = lens + (size_t)t * HUF_SYMS;
+        c.put(tl[0], 5);
+        uint32_t acc = tl[0];
+        for (uint32_t s = 0; s < nsyms; s++) {
+            const uint32_t l = tl[s];
+            while (acc < l) {
+                c.put(2, 2);
+                acc++;
+            }
+            while (acc > l) {
+                c.put(3, 2);
+                acc--;
+            }
+            c.put(0, 1);
+        }
+    }
+    c.flush();
+    uint32_t *hb32 = bt.hdrbits + (size_t)b * 4;
+    hb32[0] = a.bits;
+    hb32[1] = selbits;
+    hb32[2] = c.bits;
+    hb32[3] = pay;
+    bt.bits[b] = (uint64_t)a.bits + selbits + c.bits + pay;
+}
+
 // ---- host drivers --------------------------------------------------------------------------------------------
 // Tables, header strings, per-block bit totals and bitoff[] for blocks 0..B-1 (needs bt.syms, bt.m,
 // bt.freqs, bt.nsyms, bt.ptr, bt.hasbyte, bt.desc[].crc).
@@ -556,12 +800,27 @@ int huff_prepare(bzh_ctx *ctx, uint32_t B, uint32_t mmax)
     const uint32_t nsegmax = (mmax + SEG - 1) / SEG;
     const uint32_t PT = (bt.S + 64 + PACK_TILE - 1) / PACK_TILE;
     const uint32_t ptiles = (mmax + PACK_TILE - 1) / PACK_TILE;
+    const uint32_t selmax = (bt.S + 64 + 49) / 50 + 2;
+    const uint32_t selbytes = (uint32_t)((((size_t)selmax * 6 + 7) / 8 + 8 + 63) / 64 * 64); // as laid out in api.hip
+    if (ctx->mode == BZH_MODE_FIXED) {
+        fx_init<<<dim3(B), 64, 0, st>>>(bt);
+        for (int it = 0; it < 4; it++) {
+            fx_segments<<<dim3((nsegmax + 255) / 256, B), 256, 0, st>>>(bt, selmax);
+            fx_build<<<dim3(B), 64 * FX_TABLES, 0, st>>>(bt, it == 3);
+        }
+        fx_header<<<dim3(B), 64, 0, st>>>(bt, selmax, selbytes);
+        block_scan<<<dim3(1), 1024, 0, st>>>(bt, B);
+        pack_tilebits<true><<<dim3(ptiles, B), PACK_THREADS, 0, st>>>(bt, PT, selmax);
+        pack_tilescan<<<dim3(B), 1024, 0, st>>>(bt, PT);
+        HIP_TRY(ctx, hipGetLastError());
+        return BZH_OK;
+    }
     huff_init<<<dim3(B), 64, 0, st>>>(bt, ranges);
     huff_segments<<<dim3((nsegmax + 255) / 256, B), 256, 0, st>>>(bt, ranges);
     huff_build<<<dim3(B), 192, 0, st>>>(bt);
     huff_header<<<dim3(B), 64, 0, st>>>(bt);
     block_scan<<<dim3(1), 1024, 0, st>>>(bt, B);
-    pack_tilebits<<<dim3(ptiles, B), PACK_THREADS, 0, st>>>(bt, PT);
+    pack_tilebits<false><<<dim3(ptiles, B), PACK_THREADS, 0, st>>>(bt, PT, selmax);
     pack_tilescan<<<dim3(B), 1024, 0, st>>>(bt, PT);
     HIP_TRY(ctx, hipGetLastError());
     return BZH_OK;
@@ -576,8 +835,15 @@ int huff_pack(bzh_ctx *ctx, uint32_t B, uint32_t mmax, uint8_t *d_out, uint64_t 
     const uint32_t PT = (bt.S + 64 + PACK_TILE - 1) / PACK_TILE;
     const uint32_t ptiles = (mmax + PACK_TILE - 1) / PACK_TILE;
     uint32_t *out = reinterpret_cast<uint32_t *>(d_out);
-    pack_symbols<<<dim3(ptiles, B), PACK_THREADS, 0, st>>>(bt, PT, out, bit_base);
-    pack_headers<<<dim3(B), 64, 0, st>>>(bt, out, bit_base);
+    const uint32_t selmax = (bt.S + 64 + 49) / 50 + 2;
+    if (ctx->mode == BZH_MODE_FIXED) {
+        const uint32_t selbytes = (uint32_t)((((size_t)selmax * 6 + 7) / 8 + 8 + 63) / 64 * 64);
+        pack_symbols<true><<<dim3(ptiles, B), PACK_THREADS, 0, st>>>(bt, PT, out, bit_base, selmax);
+        fx_pack_headers<<<dim3(B), 64, 0, st>>>(bt, out, bit_base, selbytes);
+    } else {
+        pack_symbols<false><<<dim3(ptiles, B), PACK_THREADS, 0, st>>>(bt, PT, out, bit_base, selmax);
+        pack_headers<<<dim3(B), 64, 0, st>>>(bt, out, bit_base);
+    }
     HIP_TRY(ctx, hipGetLastError());
     return BZH_OK;
 }

@@ -74,6 +74,13 @@ BZH_API const char *bzh_strerror(int status);
 BZH_API const char *bzh_last_error(const bzh_ctx *ctx); /* detail of the last failure on this ctx   */
 BZH_API int bzh_set_stream(bzh_ctx *ctx, void *hip_stream); /* hipStream_t to launch on (default 0) */
 BZH_API int bzh_set_profiling(bzh_ctx *ctx, int enabled);
+/* Huffman stage behaviour.  BZH_MODE_REFERENCE (default): bit-identical to banzai 0.3.1, including its table
+ * count rule (2 or 3 tables from the ALPHABET size, lib/huffman.rs:319-326) and the refinement loop that zeroes
+ * the tables (lib/huffman.rs:402-409), after which every segment uses table 0.  BZH_MODE_FIXED (SURVEY.md 8f row
+ * f4, opt-in, NOT bit-identical to the reference): 2..6 tables chosen from the number of symbols as libbz2 does,
+ * four real refinement iterations, per-segment selectors.  Every stream is a valid bzip2 stream either way. */
+enum { BZH_MODE_REFERENCE = 0, BZH_MODE_FIXED = 1 };
+BZH_API int bzh_set_mode(bzh_ctx *ctx, int mode);
 /* 1 (default): batches run one after the other on the context's stream.  2: two half-batch lanes on
  * internal streams and host threads overlap latency-bound phases (+2-3 % throughput on MI355X, but
  * concurrent kernels stretch each other's durations, so per-kernel timings no longer add up). */

@@ -557,6 +557,34 @@ def test_bwt_round_trip_on_device_config3(native):
         assert ctx.bwt_roundtrip_device(0, len(blocks)) == 0
 
 
+def test_fixed_huffman_mode(oracle, native):
+    """f4 (opt-in, bzh_set_mode): 2..6 tables from the symbol count, real refinement iterations, per-segment
+    selectors.  Not the reference's bits -- but every stream must decode (libbz2 and the strict in-repo decoder)
+    to the input, must not be larger than the default mode's (beyond tiny streams), and switching back restores the
+    reference's bytes."""
+    from banzai_amd import corpus
+    inputs = [b"", b"x", b"abab", cases.gen(60_000, "text", 1), cases.gen(250_000, "random", 2),
+              cases.gen(300_000, "longruns", 3), cases.gen(180_000, "shortruns", 4), cases.gen(99_999, "same", 5),
+              corpus.enwik_synthetic(2_700_000, seed=9).tobytes(), bytes([1, 2, 3, 2, 1] * 700)]
+    gains = []
+    for level in (1, 9):
+        with native.Context(0, level, 8) as ctx:
+            for d in inputs:
+                ref = ctx.encode(d)
+                assert ref == oracle.encode(d, level)
+                ctx.set_mode(True)
+                fx = ctx.encode(d)
+                ctx.set_mode(False)
+                assert bz2.decompress(fx) == d and oracle.decode(fx, cap=len(d) + 64) == d
+                # (six table headers and real selectors cost a few hundred bytes per block: a block of a few hundred
+                # symbols, or incompressible bytes, can lose that much -- as with libbz2)
+                assert len(fx) <= len(ref) + 16 + len(ref) // 200, (level, len(d), len(fx), len(ref))
+                assert ctx.encode(d) == ref  # the default path is untouched by the detour
+                if len(d) > 100_000:
+                    gains.append(len(fx) / len(ref))
+    assert min(gains) < 0.97  # several tables do pay on text-like data
+
+
 def test_two_lanes_level9_several_batches(oracle, native):
     """bzh_set_lanes(2) at level 9 with more than two batches per lane (max_batch 4 -> lanes of 2 blocks)"""
     from banzai_amd import corpus
