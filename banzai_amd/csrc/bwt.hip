@@ -1280,6 +1280,7 @@ static void launch_pass(bzh_ctx *ctx, SortArgs &a, uint32_t NB, uint32_t maxcnt)
     a.T = tiles | (NB < 8 ? WG_SPREAD : 0u);
     a.pass++;
     radix_scatter<BITS, MODE, REKEY><<<dim3(xcd_grid(a.T, NB)), SORT_THREADS, 0, ctx->stream>>>(a);
+    if (ctx->profiling) ctx->stats.bwt_sort_launches++; // every launch issued, also the ones that find their list empty
 }
 
 // Profiling: HIP events bracket each RUN of consecutive radix_scatter launches (the 8 initial passes,
@@ -1422,10 +1423,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         oth = t;
     }
     span_end(ctx, ev_init);
-    if (ctx->profiling) {
-        ctx->stats.bwt_sort_launches += 8;
-        ctx->stats.bwt_sort_elems += 8 * ntotal;
-    }
+    if (ctx->profiling) ctx->stats.bwt_sort_elems += 8 * ntotal;
 
     RefineArgs r{};
     r.n = bt.n;
@@ -1507,14 +1505,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             }
             ctx->stats.bwt_rounds = (uint64_t)round > ctx->stats.bwt_rounds ? (uint64_t)round : ctx->stats.bwt_rounds;
             if (ctx->profiling) {
-                if (s[1]) {
-                    ctx->stats.bwt_sort_launches += 3;
-                    ctx->stats.bwt_sort_elems += 3 * ((uint64_t)s[10] | ((uint64_t)s[11] << 32));
-                }
-                if (s[2]) {
-                    ctx->stats.bwt_sort_launches += 5;
-                    ctx->stats.bwt_sort_elems += 5 * ((uint64_t)s[12] | ((uint64_t)s[13] << 32));
-                }
+                if (s[1]) ctx->stats.bwt_sort_elems += 3 * ((uint64_t)s[10] | ((uint64_t)s[11] << 32));
+                if (s[2]) ctx->stats.bwt_sort_elems += 5 * ((uint64_t)s[12] | ((uint64_t)s[13] << 32));
             }
             // One round on: SWEEP blocks can only leave; their unresolved suffixes may turn up in the big or the
             // small lists; big lists shrink, small lists gain at most what the big lists lose.
