@@ -103,8 +103,9 @@ constexpr u64 LIST_INVALID = ~0ull; // list slot without an unresolved suffix
 // XCD-aware workgroup -> (bzip2 block, tile) map.  Workgroups are dealt round-robin over the 8
 // XCDs (observed dispatch behaviour, used for speed only): ids congruent mod 8 share an XCD and
 // its private 4 MiB L2.  All tiles of the k-th listed block get ids = k (mod 8).  Grid = 8*ceil(NB/8)*T.
-// With fewer than 8 blocks that would leave XCDs idle (a single block would run on 32 of the
-// 256 CUs): launches that expect few blocks set WG_SPREAD in T and get the plain
+// With few blocks that would leave XCDs idle or unevenly loaded (a single block would run on 32 of the
+// 256 CUs; 28 blocks give four XCDs a third more work than the others): launches that expect fewer than 32
+// blocks set WG_SPREAD in T and get the plain
 // mapping, consecutive workgroup ids = consecutive tiles of one block, i.e. every block on all XCDs.
 // Either way tile t-1 of a block has a lower workgroup id than tile t (the look-backs rely on it).
 constexpr uint32_t WG_SPREAD = 0x80000000u;
@@ -1277,7 +1278,7 @@ static void launch_pass(bzh_ctx *ctx, SortArgs &a, uint32_t NB, uint32_t maxcnt)
 {
     const uint32_t tiles = (maxcnt + SORT_TILE - 1) / SORT_TILE;
     if (tiles == 0 || NB == 0) return;
-    a.T = tiles | (NB < 8 ? WG_SPREAD : 0u);
+    a.T = tiles | (NB < 32 ? WG_SPREAD : 0u);
     a.pass++;
     radix_scatter<BITS, MODE, REKEY><<<dim3(xcd_grid(a.T, NB)), SORT_THREADS, 0, ctx->stream>>>(a);
     if (ctx->profiling) ctx->stats.bwt_sort_launches++; // every launch issued, also the ones that find their list empty
@@ -1340,7 +1341,7 @@ static void launch_refine(bzh_ctx *ctx, RefineArgs &r, uint32_t NB, uint32_t max
 {
     const uint32_t tiles = (maxcnt + SORT_TILE - 1) / SORT_TILE;
     if (tiles == 0 || NB == 0) return;
-    r.T = tiles | (NB < 8 ? WG_SPREAD : 0u);
+    r.T = tiles | (NB < 32 ? WG_SPREAD : 0u);
     flag_tiles<<<dim3(xcd_grid(r.T, NB)), SORT_THREADS, 0, ctx->stream>>>(r);
     flag_carry<<<dim3(NB), 1024, 0, ctx->stream>>>(r);
     refine<<<dim3(xcd_grid(r.T, NB)), SORT_THREADS, 0, ctx->stream>>>(r);
@@ -1552,7 +1553,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             a.dst = oth;
             const uint32_t gt = (maxA + SORT_TILE - 1) / SORT_TILE;
             if (gt) {
-                a.T = gt | (nA < 8 ? WG_SPREAD : 0u);
+                a.T = gt | (nA < 32 ? WG_SPREAD : 0u);
                 active_gen<<<dim3(xcd_grid(a.T, nA)), SORT_THREADS, 0, st>>>(a, bt.dtot);
                 active_bases<<<dim3(nA), 256, 0, st>>>(bt.dtot, bt.dbase, a.lst, 5);
                 u64 *c = oth, *o = cur;
@@ -1574,7 +1575,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         if (nT) {
             const uint32_t tt = (maxT + TAIL_T - 1) / TAIL_T;
             if (tt) {
-                ta.T = tt | (nT < 8 ? WG_SPREAD : 0u);
+                ta.T = tt | (nT < 32 ? WG_SPREAD : 0u);
                 ta.lst = Lst{actP, bt.nlist + L_P, B};
                 tail_sort<false><<<dim3(xcd_grid(ta.T, nT)), TAIL_THREADS, 0, st>>>(ta);
                 if (nQ) {
@@ -1583,7 +1584,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
                 }
                 ta.lst = Lst{bt.actT, bt.nlist + L_T, B};
                 ta.pass = ++a.pass;
-                ta.T = ((maxT + FIN_T - 1) / FIN_T) | (nT < 8 ? WG_SPREAD : 0u);
+                ta.T = ((maxT + FIN_T - 1) / FIN_T) | (nT < 32 ? WG_SPREAD : 0u);
                 tail_finish<<<dim3(xcd_grid(ta.T, nT)), 256, 0, st>>>(ta);
             }
         }
@@ -1624,7 +1625,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     uint32_t gx = (nmax + 1023) / 1024;
     if (gx > 256) gx = 256;
     if (gx == 0) gx = 1;
-    if (B < 8) gx |= WG_SPREAD;
+    if (B < 32) gx |= WG_SPREAD;
     bwt_emit<<<dim3(xcd_grid(gx, B)), 256, 0, st>>>(bt, gx, B);
     HIP_TRY(ctx, hipGetLastError());
     return BZH_OK;
