@@ -49,7 +49,8 @@ const char *VERSION = "version alpha 0.3.1-hip";
             "  notes:\n"
             "     '-' as input path reads standard in.  Without --output / --stdout the file\n"
             "     '<input_path>.bz2' is written and the input removed; with an explicit output the\n"
-            "     input is kept unless --remove is given.  GPU: $BZHIP_DEVICE (default 0).\n\n%s\n",
+            "     input is kept unless --remove is given.  GPU: $BZHIP_DEVICE (default 0);\n"
+            "     BZHIP_HUFFMAN=fixed: 2-6 Huffman tables with refinement (smaller, not banzai's exact bytes).\n\n%s\n",
             VERSION);
     exit(SUCCESS);
 }
@@ -140,6 +141,13 @@ int main(int argc, char **argv)
         bzh_destroy(ctx);
         die(ERR_OUTPUT, msg);
     };
+    // not a flag: the reference's option grammar stays as it is.  BZHIP_HUFFMAN=fixed selects the opt-in Huffman mode
+    // (2..6 tables, real refinement: smaller files that are no longer bit-identical to banzai's)
+    const char *hm = getenv("BZHIP_HUFFMAN");
+    if (hm && std::string(hm) == "fixed") {
+        st = bzh_set_mode(ctx, BZH_MODE_FIXED);
+        if (st != BZH_OK) fail(bzh_strerror(st));
+    }
     st = bzh_stream_begin(ctx);
     if (st != BZH_OK) fail(bzh_strerror(st));
     const size_t CHUNK = (size_t)16 << 20;

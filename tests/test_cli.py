@@ -61,3 +61,9 @@ def test_cli_end_to_end(cli, oracle, tmp_path):
     big = cases.gen(20_000_000, "shortruns", 3) + cases.gen(17_000_000, "text", 3)
     r = run(cli, "-c", "-", stdin=big)
     assert r.returncode == 0 and r.stdout == oracle.encode(big, 9)
+    # BZHIP_HUFFMAN=fixed: the opt-in Huffman mode -- a smaller, still valid stream
+    import bz2
+    import subprocess
+    env = dict(os.environ, BZHIP_HUFFMAN="fixed")
+    r2 = subprocess.run([cli, "-c", "-"], input=big, capture_output=True, env=env)
+    assert r2.returncode == 0 and len(r2.stdout) < len(r.stdout) and bz2.decompress(r2.stdout) == big
