@@ -202,79 +202,108 @@ __device__ __forceinline__ void heap_extract(HeapMem &h, uint32_t &len, uint32_t
     HEAP_ORDER();
 }
 
-// all 64 lanes of one wavefront; out = code lengths of the table
-__device__ void build_lengths(HeapMem &h, uint32_t nsyms, uint8_t *out, uint32_t lane) // :271-298
+// One attempt of build_table_from_freqs (:271-298) with scaling = 1 << sh, by all 64 lanes of one wavefront.
+// Returns the longest code (uniform); dep[q] = depth of symbol q * 64 + lane.
+__device__ int build_attempt(HeapMem &h, uint32_t nsyms, uint32_t sh, uint32_t lane, uint32_t (&dep)[(HUF_SYMS + 63) / 64])
 {
-    uint32_t sh = 0; // scaling = 1 << sh
+    uint32_t nnodes = nsyms + 1, len = 0;
+    for (uint32_t s = 0; s < nsyms; s++) heap_insert(h, len, s + 1, ((h.fr[s] >> sh) + 1u) << 8, lane);
     for (;;) {
-        uint32_t nnodes = nsyms + 1, len = 0;
-        for (uint32_t s = 0; s < nsyms; s++) heap_insert(h, len, s + 1, ((h.fr[s] >> sh) + 1u) << 8, lane);
-        for (;;) {
-            uint32_t a, c, pa, pc;
-            heap_extract(h, len, a, pa, lane);
-            heap_extract(h, len, c, pc, lane);
-            if (nnodes == 2 * nsyms - 1) { // Tree::tie :60-74 -- last tie hangs off the root (id 0)
-                if (lane == 0) {
-                    h.par[a] = 0;
-                    h.par[c] = 0;
-                }
-                break;
-            }
-            const uint32_t parent = nnodes++;
+        uint32_t a, c, pa, pc;
+        heap_extract(h, len, a, pa, lane);
+        heap_extract(h, len, c, pc, lane);
+        if (nnodes == 2 * nsyms - 1) { // Tree::tie :60-74 -- last tie hangs off the root (id 0)
             if (lane == 0) {
-                h.par[a] = (int16_t)parent;
-                h.par[c] = (int16_t)parent;
+                h.par[a] = 0;
+                h.par[c] = 0;
             }
-            const uint32_t da = pa & 0xFFu, dc = pc & 0xFFu;
-            const uint32_t pr = (((pa >> 8) + (pc >> 8)) << 8) | ((da > dc ? da : dc) + 1u); // :147-158
-            heap_insert(h, len, parent, pr, lane);
+            break;
         }
-        HEAP_ORDER();
-        // leaf depths (:78-102): every lane walks a few leaves up to the root
-        uint32_t dep[(HUF_SYMS + 63) / 64];
-        int maxlen = 0;
-#pragma unroll
-        for (int q = 0; q < (HUF_SYMS + 63) / 64; q++) {
-            const uint32_t s = q * 64 + lane;
-            dep[q] = 0;
-            if (s < nsyms) {
-                uint32_t x = s + 1, dd = 0;
-                do {
-                    x = (uint32_t)h.par[x];
-                    dd++;
-                } while (x != 0);
-                dep[q] = dd;
-                maxlen = max(maxlen, (int)dd);
-            }
+        const uint32_t parent = nnodes++;
+        if (lane == 0) {
+            h.par[a] = (int16_t)parent;
+            h.par[c] = (int16_t)parent;
         }
+        const uint32_t da = pa & 0xFFu, dc = pc & 0xFFu;
+        const uint32_t pr = (((pa >> 8) + (pc >> 8)) << 8) | ((da > dc ? da : dc) + 1u); // :147-158
+        heap_insert(h, len, parent, pr, lane);
+    }
+    HEAP_ORDER();
+    // leaf depths (:78-102): every lane walks a few leaves up to the root
+    int maxlen = 0;
 #pragma unroll
-        for (int s2 = 32; s2 > 0; s2 >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, s2, 64));
-        if (maxlen <= HUF_MAXLEN) {
-#pragma unroll
-            for (int q = 0; q < (HUF_SYMS + 63) / 64; q++) {
-                const uint32_t s = q * 64 + lane;
-                if (s < nsyms) out[s] = (uint8_t)dep[q];
-            }
-            return;
+    for (int q = 0; q < (HUF_SYMS + 63) / 64; q++) {
+        const uint32_t s = q * 64 + lane;
+        dep[q] = 0;
+        if (s < nsyms) {
+            uint32_t x = s + 1, dd = 0;
+            do {
+                x = (uint32_t)h.par[x];
+                dd++;
+            } while (x != 0);
+            dep[q] = dd;
+            maxlen = max(maxlen, (int)dd);
         }
-        sh++; // scaling <<= 1 (:293-296), redo from the original frequencies
-        HEAP_ORDER();
+    }
+#pragma unroll
+    for (int s2 = 32; s2 > 0; s2 >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, s2, 64));
+    HEAP_ORDER();
+    return maxlen;
+}
+
+__device__ __forceinline__ void store_lengths(uint8_t *out, uint32_t nsyms, uint32_t lane, const uint32_t (&dep)[(HUF_SYMS + 63) / 64])
+{
+#pragma unroll
+    for (int q = 0; q < (HUF_SYMS + 63) / 64; q++) {
+        const uint32_t s = q * 64 + lane;
+        if (s < nsyms) out[s] = (uint8_t)dep[q];
     }
 }
 
-// One wavefront per table (3 per workgroup), all lanes in lock step; the heap lives in LDS.
-__global__ void __launch_bounds__(192) huff_build(Batch bt)
+// the reference's loop: double `scaling` until no code is longer than 17 bits (:293-296), from scaling 1 << sh0 on
+__device__ void build_lengths(HeapMem &h, uint32_t nsyms, uint8_t *out, uint32_t lane, uint32_t sh0 = 0)
+{
+    uint32_t dep[(HUF_SYMS + 63) / 64];
+    for (uint32_t sh = sh0;; sh++) {
+        if (build_attempt(h, nsyms, sh, lane, dep) <= HUF_MAXLEN) {
+            store_lengths(out, nsyms, lane, dep);
+            return;
+        }
+    }
+}
+
+// One wavefront per (table, attempt): the attempts with scaling 1, 2, 4 and 8 are independent computations from the
+// same frequencies, so they run side by side and the first that fits is kept -- exactly the table the reference's
+// sequential loop ends with, in the time of one build instead of up to four (blocks with skewed 258-symbol
+// alphabets need two or three).  Should none fit, the loop carries on from scaling 16.  All lanes of a wavefront work
+// in lock step; the heaps live in LDS.
+constexpr int HB_TRIES = 4;
+__global__ void __launch_bounds__(64 * 3 * HB_TRIES) huff_build(Batch bt)
 {
     const uint32_t b = blockIdx.x;
-    const uint32_t t = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t t = w / HB_TRIES, a = w % HB_TRIES;
     const uint32_t ntab = bt.ntab[b], nsyms = bt.nsyms[b];
-    __shared__ HeapMem hm[3];
+    __shared__ HeapMem hm[3 * HB_TRIES];
+    __shared__ int mx[3][HB_TRIES];
+    uint32_t dep[(HUF_SYMS + 63) / 64];
+    int maxlen = 0;
+    if (t < ntab) {
+        const uint32_t *tf = bt.tfreq + ((size_t)b * 3 + t) * HUF_SYMS;
+        const uint32_t *F = bt.freqs + (size_t)b * HUF_SYMS;
+        for (uint32_t s = lane; s < nsyms; s += 64) hm[w].fr[s] = tf[s] + (t == 0 ? 3u * F[s] : 0u);
+        HEAP_ORDER();
+        maxlen = build_attempt(hm[w], nsyms, a, lane, dep);
+        if (lane == 0) mx[t][a] = maxlen;
+    }
+    __syncthreads();
     if (t >= ntab) return;
-    const uint32_t *tf = bt.tfreq + ((size_t)b * 3 + t) * HUF_SYMS;
-    const uint32_t *F = bt.freqs + (size_t)b * HUF_SYMS;
-    for (uint32_t s = lane; s < nsyms; s += 64) hm[t].fr[s] = tf[s] + (t == 0 ? 3u * F[s] : 0u);
-    HEAP_ORDER();
-    build_lengths(hm[t], nsyms, bt.lens + ((size_t)b * 3 + t) * HUF_SYMS, lane);
+    int first = HB_TRIES; // smallest scaling that fits
+    for (int k = HB_TRIES - 1; k >= 0; k--)
+        if (mx[t][k] <= HUF_MAXLEN) first = k;
+    uint8_t *out = bt.lens + ((size_t)b * 3 + t) * HUF_SYMS;
+    if (first == (int)a) store_lengths(out, nsyms, lane, dep);
+    if (first == HB_TRIES && a == 0) build_lengths(hm[w], nsyms, out, lane, HB_TRIES); // (never seen: weights < 2^22)
 }
 
 // ---- header bit string + canonical codes + bit totals ----------------------------------------------------
@@ -817,7 +846,7 @@ int huff_prepare(bzh_ctx *ctx, uint32_t B, uint32_t mmax)
     }
     huff_init<<<dim3(B), 64, 0, st>>>(bt, ranges);
     huff_segments<<<dim3((nsegmax + 255) / 256, B), 256, 0, st>>>(bt, ranges);
-    huff_build<<<dim3(B), 192, 0, st>>>(bt);
+    huff_build<<<dim3(B), 64 * 3 * HB_TRIES, 0, st>>>(bt);
     huff_header<<<dim3(B), 64, 0, st>>>(bt);
     block_scan<<<dim3(1), 1024, 0, st>>>(bt, B);
     pack_tilebits<false><<<dim3(ptiles, B), PACK_THREADS, 0, st>>>(bt, PT, selmax);
