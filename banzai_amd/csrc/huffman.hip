@@ -333,89 +333,129 @@ struct BitW { // MSB-first byte writer into global memory
     }
 };
 
-__global__ void __launch_bounds__(64) huff_header(Batch bt)
+__device__ void or_bits(uint32_t *out, uint64_t pos, const uint8_t *src, uint32_t nbits, uint32_t lane); // below
+
+// Three wavefronts share the work: 0 -- the delta-coded tables, one lane per table, each into its own LDS string;
+// 1 -- block header, symbol map, counts (lib/lib.rs:24-64, lib/huffman.rs:467-471) and the payload size;
+// 2 -- canonical codes of table 0 (:548-561) by ballots.  Then wavefront 0 joins the table strings bit by bit.
+constexpr uint32_t TB_BYTES = 1152; // one delta-coded table: <= 5 + 258 * 35 bits
+__global__ void __launch_bounds__(192) huff_header(Batch bt)
 {
-    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+    const uint32_t b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t ntab = bt.ntab[b], nsyms = bt.nsyms[b], m = bt.m[b];
     const uint8_t *lens = bt.lens + (size_t)b * 3 * HUF_SYMS;
     uint8_t *hdr = bt.hdr + (size_t)b * HDR_BYTES;
-    // payload bits = sum F[s] * len0[s]
-    const uint32_t *F = bt.freqs + (size_t)b * HUF_SYMS;
-    uint32_t pay = 0;
-    for (uint32_t s = lane; s < nsyms; s += 64) pay += F[s] * lens[s];
-    pay = wave_reduce_add(pay);
-
-    if (lane != 0) return;
-    // canonical codes of table 0 (lib/huffman.rs:548-561)
-    uint32_t *codes = bt.codes + (size_t)b * HUF_SYMS;
-    {
+    __shared__ __align__(16) uint8_t tb[3][TB_BYTES];
+    __shared__ uint32_t tbits[3], abits, paybits;
+    const uint32_t nsel = (m + SEG - 1) / SEG;
+    if (wave == 0) {
+        // part B will be ORed together below: clear it first
+        uint32_t *pb = reinterpret_cast<uint32_t *>(hdr + HDR_A);
+        for (uint32_t k = lane; k < (HDR_BYTES - HDR_A) / 4; k += 64) pb[k] = 0;
+        if (lane < ntab) { // delta-coded table (:509-545)
+            const uint8_t *tl = lens + (size_t)lane * HUF_SYMS;
+            BitW c{tb[lane], 0, 0, 0};
+            c.put(tl[0], 5);
+            uint32_t acc = tl[0];
+            for (uint32_t s2 = 0; s2 < nsyms; s2++) {
+                const uint32_t l = tl[s2];
+                while (acc < l) {
+                    c.put(2, 2);
+                    acc++;
+                }
+                while (acc > l) {
+                    c.put(3, 2);
+                    acc--;
+                }
+                c.put(0, 1);
+            }
+            c.flush();
+            tbits[lane] = c.bits;
+        }
+    } else if (wave == 1) {
+        // payload bits = sum F[s] * len0[s]
+        const uint32_t *F = bt.freqs + (size_t)b * HUF_SYMS;
+        uint32_t pay = 0;
+        for (uint32_t s2 = lane; s2 < nsyms; s2 += 64) pay += F[s2] * lens[s2];
+        pay = wave_reduce_add(pay);
+        if (lane == 0) {
+            paybits = pay;
+            // part A: block header (lib/lib.rs:24-36), symbol map (:39-64), table count, selector count
+            BitW a{hdr, 0, 0, 0};
+            a.put(0x314159, 24);
+            a.put(0x265359, 24);
+            const uint32_t crc = bt.desc[b].crc;
+            a.put(crc >> 16, 16);
+            a.put(crc & 0xFFFF, 16);
+            a.put(0, 1);
+            a.put(bt.ptr[b], 24);
+            const uint8_t *hb = bt.hasbyte + (size_t)b * 256;
+            uint32_t sector_map = 0, sectors[16], ns = 0;
+            for (uint32_t x = 0; x < 16; x++) {
+                uint32_t sec = 0;
+                for (uint32_t y = 0; y < 16; y++) sec = (sec << 1) | (hb[(x << 4) | y] ? 1u : 0u);
+                sector_map <<= 1;
+                if (sec) {
+                    sector_map |= 1;
+                    sectors[ns++] = sec;
+                }
+            }
+            a.put(sector_map, 16);
+            for (uint32_t k = 0; k < ns; k++) a.put(sectors[k], 16);
+            a.put(ntab, 3);  // lib/huffman.rs:467
+            a.put(nsel, 15); // :470-471
+            a.flush();
+            abits = a.bits;
+        }
+    } else {
+        // canonical codes of table 0: within a length, symbols in ascending order (ballot ranks); lengths ascending
+        uint32_t *codes = bt.codes + (size_t)b * HUF_SYMS;
+        uint32_t l5[(HUF_SYMS + 63) / 64];
         uint32_t minl = 255, maxl = 0;
-        for (uint32_t s = 0; s < nsyms; s++) {
-            minl = min(minl, (uint32_t)lens[s]);
-            maxl = max(maxl, (uint32_t)lens[s]);
+#pragma unroll
+        for (int q = 0; q < (HUF_SYMS + 63) / 64; q++) {
+            const uint32_t s2 = q * 64 + lane;
+            l5[q] = s2 < nsyms ? lens[s2] : 0xFFu;
+            if (s2 < nsyms) {
+                minl = min(minl, l5[q]);
+                maxl = max(maxl, l5[q]);
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            minl = min(minl, (uint32_t)__shfl_xor((int)minl, d, 64));
+            maxl = max(maxl, (uint32_t)__shfl_xor((int)maxl, d, 64));
         }
         uint32_t word = 0;
         for (uint32_t l = minl; l <= maxl; l++) {
-            for (uint32_t s = 0; s < nsyms; s++)
-                if (lens[s] == l) codes[s] = (l << 24) | word++;
+#pragma unroll
+            for (int q = 0; q < (HUF_SYMS + 63) / 64; q++) {
+                const bool has = l5[q] == l;
+                const unsigned long long mk = __ballot(has);
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                if (has) codes[q * 64 + lane] = (l << 24) | (word + below);
+                word += (uint32_t)__popcll(mk);
+            }
             word <<= 1;
         }
     }
-    // part A: block header (lib/lib.rs:24-36), symbol map (:39-64), table count, selector count
-    BitW a{hdr, 0, 0, 0};
-    a.put(0x314159, 24);
-    a.put(0x265359, 24);
-    const uint32_t crc = bt.desc[b].crc;
-    a.put(crc >> 16, 16);
-    a.put(crc & 0xFFFF, 16);
-    a.put(0, 1);
-    a.put(bt.ptr[b], 24);
-    {
-        const uint8_t *hb = bt.hasbyte + (size_t)b * 256;
-        uint32_t sector_map = 0, sectors[16], ns = 0;
-        for (uint32_t x = 0; x < 16; x++) {
-            uint32_t sec = 0;
-            for (uint32_t y = 0; y < 16; y++) sec = (sec << 1) | (hb[(x << 4) | y] ? 1u : 0u);
-            sector_map <<= 1;
-            if (sec) {
-                sector_map |= 1;
-                sectors[ns++] = sec;
-            }
-        }
-        a.put(sector_map, 16);
-        for (uint32_t k = 0; k < ns; k++) a.put(sectors[k], 16);
-    }
-    a.put(ntab, 3); // lib/huffman.rs:467
-    const uint32_t nsel = (m + SEG - 1) / SEG;
-    a.put(nsel, 15); // :470-471
-    a.flush();
+    __syncthreads();
+    if (wave != 0) return;
     // selectors: nsel single 0 bits (every selector is table 0, :483-505) -- left as zeros in the output
-    // part B: delta-coded tables (:509-545)
-    BitW c{hdr + HDR_A, 0, 0, 0};
+    // part B: the tables one after the other
+    uint32_t cbits = 0;
     for (uint32_t t = 0; t < ntab; t++) {
-        const uint8_t *tl = lens + (size_t)t * HUF_SYMS;
-        c.put(tl[0], 5);
-        uint32_t acc = tl[0];
-        for (uint32_t s = 0; s < nsyms; s++) {
-            const uint32_t l = tl[s];
-            while (acc < l) {
-                c.put(2, 2);
-                acc++;
-            }
-            while (acc > l) {
-                c.put(3, 2);
-                acc--;
-            }
-            c.put(0, 1);
-        }
+        or_bits(reinterpret_cast<uint32_t *>(hdr + HDR_A), cbits, tb[t], tbits[t], lane);
+        cbits += tbits[t];
     }
-    c.flush();
-    uint32_t *hb32 = bt.hdrbits + (size_t)b * 4;
-    hb32[0] = a.bits;
-    hb32[1] = nsel;
-    hb32[2] = c.bits;
-    hb32[3] = pay;
-    bt.bits[b] = (uint64_t)a.bits + nsel + c.bits + pay;
+    if (lane == 0) {
+        uint32_t *hb32 = bt.hdrbits + (size_t)b * 4;
+        hb32[0] = abits;
+        hb32[1] = nsel;
+        hb32[2] = cbits;
+        hb32[3] = paybits;
+        bt.bits[b] = (uint64_t)abits + nsel + cbits + paybits;
+    }
 }
 
 // Exclusive scan of block bit totals; bitoff[B] = sum.  B <= 1024.
@@ -847,7 +887,7 @@ int huff_prepare(bzh_ctx *ctx, uint32_t B, uint32_t mmax)
     huff_init<<<dim3(B), 64, 0, st>>>(bt, ranges);
     huff_segments<<<dim3((nsegmax + 255) / 256, B), 256, 0, st>>>(bt, ranges);
     huff_build<<<dim3(B), 64 * 3 * HB_TRIES, 0, st>>>(bt);
-    huff_header<<<dim3(B), 64, 0, st>>>(bt);
+    huff_header<<<dim3(B), 192, 0, st>>>(bt);
     block_scan<<<dim3(1), 1024, 0, st>>>(bt, B);
     pack_tilebits<false><<<dim3(ptiles, B), PACK_THREADS, 0, st>>>(bt, PT, selmax);
     pack_tilescan<<<dim3(B), 1024, 0, st>>>(bt, PT);
