@@ -52,7 +52,7 @@ typedef struct {
 typedef struct {
     double ms_plan, ms_rle1, ms_bwt, ms_mtf, ms_huff, ms_pack, ms_total;
     double ms_bwt_sort;           /* radix scatter+histogram kernels only (dominant kernel class) */
-    uint64_t bwt_sort_launches;   /* number of radix scatter launches timed in ms_bwt_sort       */
+    uint64_t bwt_sort_launches;   /* radix scatter launches issued in ms_bwt_sort (incl. ones that find no work) */
     uint64_t bwt_sort_elems;      /* elements moved by those launches                           */
     uint64_t raw_bytes, rle_bytes, mtf_syms, out_bits;
     uint64_t bwt_rounds;          /* prefix-doubling rounds run (max over blocks)               */
@@ -82,8 +82,8 @@ BZH_API int bzh_set_profiling(bzh_ctx *ctx, int enabled);
 enum { BZH_MODE_REFERENCE = 0, BZH_MODE_FIXED = 1 };
 BZH_API int bzh_set_mode(bzh_ctx *ctx, int mode);
 /* 1 (default): batches run one after the other on the context's stream.  2: two half-batch lanes on
- * internal streams and host threads overlap latency-bound phases (+2-3 % throughput on MI355X, but
- * concurrent kernels stretch each other's durations, so per-kernel timings no longer add up). */
+ * internal streams and host threads.  Since the suffix-sort rounds stopped waiting for the host the GPU is
+ * busy without it and 2 lanes measure the same throughput as 1; kept for experiments. */
 BZH_API int bzh_set_lanes(bzh_ctx *ctx, int lanes);
 BZH_API int bzh_get_stats(const bzh_ctx *ctx, bzh_stats *out);
 
