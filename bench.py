@@ -243,10 +243,13 @@ def main():
 
             # ---- other inputs, each one whole stream on this GPU, bit-exact vs the oracle ----
             extras = {}
-            sets = [(name, corpus.image_corpus(name)) for name in corpus.IMAGE_SETS] + corpus.c5_parts(100_000_000)
+            # BASELINE.json configs[1]: ONE 899,999-byte block of uniform-random bytes (xorshift64*): a latency case --
+            # one block cannot fill 256 CUs; `ms_bwt` of its record is the "BWT radix-sort kernel only" figure
+            sets = [("c2-one-random-block", corpus.xorshift_bytes(899_999))]
+            sets += [(name, corpus.image_corpus(name)) for name in corpus.IMAGE_SETS] + corpus.c5_parts(100_000_000)
             for name, data in sets:
                 n = int(data.size)
-                if n < 1_000_000:
+                if n < 500_000:
                     extras[name] = {"skipped": f"only {n} bytes found"}
                     continue
                 d_x = torch.zeros(n + 16, dtype=torch.uint8, device=dev)
@@ -268,6 +271,7 @@ def main():
                 xs = ctx.stats()
                 ctx.set_profiling(False)
                 rec = {"bytes": n, "MB/s": round(n / best / 1e6, 1), "ms": round(best * 1e3, 2),
+                       "ms_bwt": round(xs["ms_bwt"], 3),
                        "rounds": int(xs["bwt_rounds"]), "A/n": round(xs["bwt_active_sum"] / max(1, xs["rle_bytes"]), 2),
                        "ratio": round(xlen / n, 4)}
                 if po is not None:
