@@ -308,6 +308,27 @@ class Context:
         self._nblocks = nb.value
         return self.plan_blocks()
 
+    def plan_device_only(self, d_in, n, crc=True):
+        """bzh_plan_device[_nocrc] without turning the block table into Python objects -> number of blocks"""
+        nb = ctypes.c_size_t(0)
+        fn = lib().bzh_plan_device if crc else lib().bzh_plan_device_nocrc
+        self.check(fn(self._h, ctypes.c_void_p(d_in), n, ctypes.byref(nb)))
+        self._nblocks = nb.value
+        return int(nb.value)
+
+    def plan_blocks_np(self):
+        """the plan as one structured numpy array (fields in_off, in_len, rle_len, crc): no per-block Python objects"""
+        n = getattr(self, "_nblocks", 0)
+        blocks = (Block * max(1, n))()
+        self.check(lib().bzh_plan_blocks(self._h, blocks, max(1, n)))
+        return np.frombuffer(blocks, dtype=_BLOCK_DTYPE, count=n).copy()
+
+    def plan_open_np(self):
+        n = getattr(self, "_nblocks", 0)
+        flags = np.zeros(max(1, n), dtype=np.uint8)
+        self.check(lib().bzh_plan_open(self._h, ptr(flags), max(1, n)))
+        return flags[:n].astype(bool)
+
     def plan_blocks(self):
         n = getattr(self, "_nblocks", 0)
         blocks = (Block * max(1, n))()

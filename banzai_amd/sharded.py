@@ -56,7 +56,11 @@ def offsets(n, world):
 
 
 def own_blocks(engine, rank, world):
-    """Plan as far as needed and return (blocks, b0, b1): this rank's blocks are blocks[b0:b1] of that plan."""
+    """Plan as far as needed and return (blocks, b0, b1): this rank's blocks are blocks[b0:b1] of that plan.
+    `blocks` is whatever the engine's plan() returns: a list of (in_off, in_len, rle_len, crc) tuples or a structured
+    numpy array with those fields (DeviceEngine: a high rank's prefix plan has ~1000 blocks per step)."""
+    import numpy as np
+
     n = engine.n
     bounds = offsets(n, world)
     lo, hi = bounds[rank], bounds[rank + 1]
@@ -64,11 +68,13 @@ def own_blocks(engine, rank, world):
     while True:
         prefix = n if rank == world - 1 else min(n, hi + margin)
         blocks, is_open = engine.plan(prefix)
-        b0 = next((k for k, b in enumerate(blocks) if b[0] >= lo), len(blocks))
-        b1 = next((k for k, b in enumerate(blocks) if b[0] >= hi), len(blocks))
+        offs = blocks["in_off"] if isinstance(blocks, np.ndarray) else np.fromiter((b[0] for b in blocks), dtype=np.int64,
+                                                                                   count=len(blocks))
+        b0 = int(np.searchsorted(offs, lo, side="left"))  # first block that starts at or after lo
+        b1 = int(np.searchsorted(offs, hi, side="left"))
         # exact if the plan saw the whole input, or if a block starting at/after `hi` exists whose predecessor's
         # cut is final (a cut is final once its block is not open; the cuts before a final cut are final too)
-        if prefix == n or (b1 < len(blocks) and (b1 == 0 or not is_open[b1 - 1])):
+        if prefix == n or (b1 < len(blocks) and (b1 == 0 or not bool(is_open[b1 - 1]))):
             return blocks, b0, b1
         margin *= 4
 
@@ -162,15 +168,15 @@ class DeviceEngine:
     def plan(self, prefix):
         if prefix > self.resident:
             raise ShardError(f"the split needs {prefix} input bytes but only {self.resident} are resident on this rank")
-        blocks = self.ctx.plan_device(self.d_in.data_ptr(), prefix, crc=False)
-        return blocks, self.ctx.plan_open()
+        self.ctx.plan_device_only(self.d_in.data_ptr(), prefix, crc=False)
+        return self.ctx.plan_blocks_np(), self.ctx.plan_open_np()
 
     def encode_range(self, b0, b1):
         nbits = self.ctx.encode_range_device(b0, b1, self.part.data_ptr(), self.cap)
         return self.part, nbits
 
     def crcs(self, b0, b1):
-        return [b[3] for b in self.ctx.plan_blocks()[b0:b1]]  # encode_range_device computed them
+        return self.ctx.plan_blocks_np()["crc"][b0:b1].tolist()  # encode_range_device computed them
 
     def assemble(self, segments, crcs):
         segs = [(t.data_ptr(), nb) for t, nb in segments]
