@@ -27,9 +27,10 @@ exercised under gloo without a GPU.  An engine provides
     min_block                      -> least number of input bytes a block consumes (bounds blocks per range)
 """
 
-# cost of splitting one more input byte relative to encoding it (plan ~5 us/MB against ~160 us/MB):
-# rank r+1's range is this much shorter than rank r's, which evens out split + encode over the ranks
-PLAN_COST = 0.03
+# cost of splitting one more input byte relative to encoding it (round 2, one-GPU simulation of 8 ranks on 800 MB:
+# rank 7 plans its 800 MB prefix in 4.5 ms = 5.7 us/MB while encoding costs 136 us/MB): rank r+1's range is this
+# much shorter than rank r's, which evens out split + encode over the ranks
+PLAN_COST = 0.04
 MARGIN = 4 << 20  # bytes planned beyond the end of the own range; grown when the last own cut is still open
 # rank 0 also receives the gather and assembles the stream (~4 % of a step): its range is shortened by that much
 ROOT_DISCOUNT = 0.96

@@ -27,7 +27,7 @@ for it in range(3):
     segs = [(part, nbits)] * N
     crcs = eng.crcs(b0, b1) * N  # timing only: the other ranks' CRCs would arrive with the gather
     n_out = eng.assemble(segs, crcs); sync(); t3 = time.perf_counter()
-    print(f"N={N} rank {r}: planned {blocks[-1][0] + blocks[-1][1]} of {total} bytes, own blocks={b1-b0}  plan {1e3*(t1-t0):.2f} ms  encode_range {1e3*(t2-t1):.2f} ms  assemble({N} segs, {nbits//8/1e6:.1f} MB each) {1e3*(t3-t2):.2f} ms  total {1e3*(t3-t0):.2f}", flush=True)
+    print(f"N={N} rank {r}: planned {int(blocks[-1][0]) + int(blocks[-1][1])} of {total} bytes, own blocks={b1-b0}  plan {1e3*(t1-t0):.2f} ms  encode_range {1e3*(t2-t1):.2f} ms  assemble({N} segs, {nbits//8/1e6:.1f} MB each) {1e3*(t3-t2):.2f} ms  total {1e3*(t3-t0):.2f}", flush=True)
 for r in (0, N - 1):
     sync(); t0 = time.perf_counter()
     blocks, b0, b1 = sharded.own_blocks(eng, r, N); sync(); t1 = time.perf_counter()
