@@ -177,10 +177,10 @@ __device__ __forceinline__ bool gen_elem(const SortArgs &a, uint32_t b, uint32_t
         uint32_t i, k2;
         if (h < n) { // suffix j = sa[e] is the e-th smallest; i = j - h has it as its second half
             const uint32_t j = a.sa[base + e];
+            k2 = a.headp[base + e]; // = rank[j] without the gather (loaded next to sa[e], not behind the rank gather)
             i = j >= h ? j - h : j + n - h;
             const uint32_t r = a.rank[base + rslot(i)];
             if (r & RANK_RESOLVED) return false;
-            k2 = a.headp[base + e]; // = rank[j] without the gather
             v = ((u64)r << 40) | ((u64)k2 << 20) | i;
             return true;
         }
@@ -1164,7 +1164,8 @@ __global__ void __launch_bounds__(256) bwt_emit(Batch bt, uint32_t T, uint32_t B
 // round's work lists and gates, clears the counters and the digit totals of the blocks on the big-list
 // path, and writes the summary the host reads one round late.
 // summary words: 0 round, 1 nS, 2 nA, 3 nT, 4 nQ, 5 maxS, 6 maxA, 7 maxT, 8/9 total unresolved (lo/hi),
-//                10/11 sum of the S lists, 12/13 sum of the A lists, 14 error flag, 15 largest depth in use
+//                10/11 sum of the S lists, 12/13 sum of the A lists, 14 error flag, 15 largest depth in use,
+//                16 S blocks whose refine writes lists this round (the only ones that can leave SWEEP mode next round)
 constexpr uint32_t QUAD_BIT = 0x80000000u; // in st_ntail-derived gates: this round runs at depth x4
 enum ListId : int { L_S = 0, L_A = 1, L_R = 2, L_T = 3, L_Q = 4, L_P = 5 };
 
@@ -1174,9 +1175,10 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
     const bool valid = b < B;
     __shared__ uint32_t ls[1024 / 64 + 2];
     __shared__ unsigned long long acc64[3], ntot;
-    __shared__ uint32_t accmax[4];
+    __shared__ uint32_t accmax[4], sconv;
     if (threadIdx.x < 3) acc64[threadIdx.x] = 0;
     if (threadIdx.x < 4) accmax[threadIdx.x] = 0;
+    if (threadIdx.x == 0) sconv = 0;
     if (threadIdx.x == 0) ntot = 0;
     __syncthreads();
     uint32_t gS = 0, gA = 0, gT = 0, quad = 0, h = 0;
@@ -1201,6 +1203,7 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
         const uint32_t unres = nbig + ntail;
         if (mode == 0u) {
             gS = unres;
+            if (gS && (uint64_t)nbig * 2u < n) atomicAdd(&sconv, 1u); // (refine's `nolist` rule, negated)
         } else {
             gA = nbig;
             gT = ntail;
@@ -1267,6 +1270,7 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
         s[13] = (uint32_t)(acc64[2] >> 32);
         s[14] = *bt.errflag;
         s[15] = accmax[3];
+        s[16] = sconv;
         *bt.stat_A += acc64[0];
     }
 }
@@ -1511,14 +1515,15 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             }
             // One round on: SWEEP blocks can only leave; their unresolved suffixes may turn up in the big or the
             // small lists; big lists shrink, small lists gain at most what the big lists lose.
-            const uint32_t pS = s[1], pA = s[2], pT = s[3], mS = s[5], mA = s[6], mT = s[7];
+            // SWEEP blocks only leave that mode with lists in hand: cS of them wrote lists in the round before.
+            const uint32_t pS = s[1], pA = s[2], pT = s[3], mS = s[5], mA = s[6], mT = s[7], cS = s[16];
             nS = pS;
             maxS = mS;
-            nA = std::min(B, pA + pS);
-            maxA = std::max(mA, mS);
-            nT = std::min(B, pT + pA + pS);
+            nA = std::min(B, pA + cS);
+            maxA = std::max(mA, cS ? mS : 0u);
+            nT = std::min(B, pT + pA + cS);
             nQ = nT;
-            maxT = std::min(nmax, mT + std::max(mA, mS));
+            maxT = std::min(nmax, mT + std::max(mA, cS ? mS : 0u));
         }
 
         // -- blocks in SWEEP mode: three look-back passes; the last refine left the digit bases (sweep_bases)

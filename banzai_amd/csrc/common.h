@@ -53,7 +53,7 @@ constexpr int SORT_ITEMS = 16;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS; // 8192 elements per workgroup (512 x 16: halves the look-back /
                                                      // scan overhead per element against 256 x 16, -7 % on the bench)
 constexpr uint32_t RANK_RESOLVED = 0x80000000u;      // suffix is alone in its group
-constexpr int SUMMARY_WORDS = 16; // round summary: see round_begin (bwt.hip)
+constexpr int SUMMARY_WORDS = 20; // round summary: see round_begin (bwt.hip)
 constexpr int MAX_ROUNDS = 64;
 
 struct BlockDesc { // device-side description of one planned block (mirrors bzh_block + restart info)
