@@ -67,6 +67,20 @@ int main(int argc, char **argv)
     run("scatter + streams, XCD map", k<1, true>);
     run("scatter + streams, plain map", k<1, false>);
     run("streams only, XCD map", k<2, true>);
+    // fewer workgroups in flight per XCD (dynamic LDS as ballast): how many blocks share an L2 at a time?
+    for (uint32_t lds : {40000u, 60000u, 100000u}) {
+        auto runl = [&](const char *name, auto kern) {
+            hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 120000);
+            for (int it = 0; it < 2; it++) kern<<<grid, THREADS, lds>>>(perm, rank, src, dst, n, S, T, B);
+            hipEventRecord(e0);
+            for (int it = 0; it < 5; it++) kern<<<grid, THREADS, lds>>>(perm, rank, src, dst, n, S, T, B);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("%-34s %8.1f us per launch (%.1f G elements/s) with %u B of LDS per workgroup\n", name, ms * 1e3 / 5, (double)B * n / (ms / 5 * 1e-3) / 1e9, lds);
+        };
+        runl("scatter only, XCD map", k<0, true>);
+        runl("scatter + streams, XCD map", k<1, true>);
+    }
     // one block per XCD at a time: 15 launches of 8 blocks each
     auto run8 = [&](const char *name, auto kern) {
         const uint32_t g8 = 8 * T;
