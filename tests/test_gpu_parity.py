@@ -585,6 +585,35 @@ def test_fixed_huffman_mode(oracle, native):
     assert min(gains) < 0.97  # several tables do pay on text-like data
 
 
+def test_two_contexts_concurrently(oracle, native):
+    """include/bzhip.h: a context is single-threaded, distinct contexts may run concurrently -- two host threads,
+    one context each, same GPU, different inputs and levels, several encodes in a row"""
+    import threading
+    from banzai_amd import corpus
+    jobs = [(9, corpus.enwik_synthetic(5_000_000, seed=51).tobytes() + cases.gen(300_000, "longruns", 5)),
+            (1, cases.gen(2_000_000, "text", 6) + cases.repeats(800_000, 6) + cases.gen(300_000, "shortruns", 6))]
+    want = [oracle.encode(d, lv) for lv, d in jobs]
+    got, errs = [None, None], []
+
+    def work(k):
+        try:
+            lv, d = jobs[k]
+            with native.Context(0, lv, 8) as ctx:
+                for _ in range(4):
+                    got[k] = ctx.encode(d)
+                    if got[k] != want[k]:
+                        errs.append((k, "mismatch"))
+        except Exception as e:  # noqa: BLE001
+            errs.append((k, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs and got == want
+
+
 def test_two_lanes_level9_several_batches(oracle, native):
     """bzh_set_lanes(2) at level 9 with more than two batches per lane (max_batch 4 -> lanes of 2 blocks)"""
     from banzai_amd import corpus
