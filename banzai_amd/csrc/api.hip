@@ -134,7 +134,7 @@ static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
         carve(p, rs, oA + 4);
         uint32_t **f[21] = {&bt.st_mode, &bt.st_h, &bt.st_nbig, &bt.st_ntail, &bt.c_big, &bt.c_small, &bt.c_tail,
                             &bt.c_prog, &bt.gateS, &bt.gateA, &bt.gateR, &bt.gateT, &bt.actS, &bt.actA, &bt.actR,
-                            &bt.actT, &bt.actQ, nullptr, &bt.c_nolist, nullptr, nullptr}; // row 17: sixth list (bwt.hip)
+                            &bt.actT, &bt.actQ, nullptr, &bt.c_nolist, &bt.c_groups, &bt.scratch}; // row 17: sixth list (bwt.hip)
         for (int k = 0; k < 21; k++)
             if (f[k]) *f[k] = rs ? rs + (size_t)k * NB : nullptr;
         bt.nlist = rs ? rs + 21 * NB : nullptr;
@@ -142,7 +142,6 @@ static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
         bt.stat_A = rs ? reinterpret_cast<unsigned long long *>(rs + oA) : nullptr;
     }
     carve(p, bt.errflag, 64);
-    carve(p, bt.alive, 2 * NB * ((S + 2047) / 2048)); // one 64-bit status word per tail tile
     carve(p, bt.mtfpos, NB * S);
     carve(p, bt.tilelist, NB * MT * 256);
     carve(p, bt.tinfo, NB * MT * 4);
@@ -205,7 +204,7 @@ extern "C" int bzh_create(bzh_ctx **out, int device, int level, int max_batch)
     }
     layout_batch(ctx->bt, ctx->arena, ctx->max_batch, ctx->M);
     ctx->S = ctx->bt.S;
-    if (hipHostMalloc((void **)&ctx->h_pinned, sizeof(uint32_t) * (ctx->max_batch * 8 + 64 + MAX_ROUNDS * SUMMARY_WORDS)) != hipSuccess) {
+    if (hipHostMalloc((void **)&ctx->h_pinned, sizeof(uint32_t) * (ctx->max_batch * 8 + 64 + MAX_ROUNDS * SUMMARY_WORDS), hipHostMallocCoherent) != hipSuccess) {
         hipFree(ctx->arena);
         delete ctx;
         return BZH_E_NOMEM;
@@ -428,6 +427,7 @@ extern "C" int bzh_bwt_roundtrip_device(bzh_ctx *ctx, size_t b0, size_t b1, uint
     if (b1 > ctx->plan_blocks.size()) return BZH_E_STATE;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    ctx->evnext = 0; // (the pool is reused from the start by every entry point that takes events)
     unsigned long long *d_acc = ctx->bt.stat_A; // (the forward sort has read it back by the time it is reused)
     unsigned long long total = 0;
     for (size_t k0 = b0; k0 < b1; k0 += ctx->max_batch) {
@@ -635,7 +635,7 @@ static int ensure_lanes(bzh_ctx *ctx)
         layout_batch(l->bt, ctx->arena + (size_t)k * half, lane_mb, ctx->M);
         l->S = l->bt.S;
         if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess ||
-            hipHostMalloc((void **)&l->h_pinned, sizeof(uint32_t) * (lane_mb * 8 + 64 + MAX_ROUNDS * SUMMARY_WORDS)) != hipSuccess) {
+            hipHostMalloc((void **)&l->h_pinned, sizeof(uint32_t) * (lane_mb * 8 + 64 + MAX_ROUNDS * SUMMARY_WORDS), hipHostMallocCoherent) != hipSuccess) {
             delete l;
             return BZH_E_NOMEM;
         }

@@ -59,15 +59,29 @@
 typedef unsigned long long u64;
 
 enum GenMode : int {
-    GEN_BYTES4 = 0, // element e is suffix e keyed by its 4-byte cyclic prefix
+    GEN_BYTES5 = 0, // element e is suffix e keyed by bytes 3..7 of its rotation
+    GEN_GID = 2,    // element e is src[e], re-keyed: bytes 0..2 of its rotation + dense index of its 5-byte group
     GEN_SWEEP = 1,  // doubling round, SA-order enumeration
     GEN_LIST = 3,   // element e is src[e]
     GEN_LCOL = 4    // inverse BWT: element e is position e of the last column, keyed by its byte
 };
 
 constexpr u64 SUF_MASK = 0xFFFFFull;
-constexpr uint32_t RANK_MASK = 0x7FFFFFFFu;
 constexpr uint32_t H_DONE = 1u << 30; // depth that stands for "h >= n"
+
+// rank word: [resolved:1][tag:5][less:6][rank:20].  tag = id of the round that wrote the word (1..31; 0: written
+// by refine, which no reader of the same launch ever races with).  A reader of round `tag` sees the rank as it
+// stood when that round began: `rank` if the word was written in this round, `rank + less` otherwise.
+__device__ __forceinline__ uint32_t rank_word(uint32_t r, uint32_t less, uint32_t tag, bool resolved)
+{
+    return (resolved ? RANK_RESOLVED : 0u) | (tag << 26) | (less << 20) | r;
+}
+__device__ __forceinline__ uint32_t rank_at(uint32_t w, uint32_t tag)
+{
+    const uint32_t r = w & 0xFFFFFu, less = (w >> 20) & 63u;
+    return ((w >> 26) & 31u) == tag ? r : r + less;
+}
+__device__ __forceinline__ uint32_t rank_final(uint32_t w) { return (w & 0xFFFFFu) + ((w >> 20) & 63u); }
 
 // The blocks a launch works on: ids[0 .. *cnt) (both on the device), or all of 0 .. B-1 when ids is null.
 struct Lst {
@@ -86,7 +100,7 @@ struct SortArgs {
     const uint32_t *hb;   // [B] depth of the block's round (GEN_SWEEP, active_gen)
     const u64 *src;       // [B][S]
     u64 *dst;             // [B][S]
-    uint32_t S, TPB, h, shift; // h: byte offset of the key (GEN_BYTES4)
+    uint32_t S, TPB, h, shift;
     uint32_t T;           // tiles per block in this launch (| WG_SPREAD)
     Lst lst;
     // single-pass (look-back) scatter:
@@ -95,6 +109,8 @@ struct SortArgs {
     uint32_t doff;         // which 128/256-entry group of dbase this pass uses
     uint32_t *err;         // bit 1: a look-back gave up (internal error, never a hang)
     uint32_t pass;         // id of this pass in the status words (stale words read as "not there yet")
+    uint32_t tag;          // id of the round in the rank words (rank_at)
+    u64 *gst;              // [B][TPB][2] tile status words of GEN_GID's look-back
 };
 
 constexpr int NBMAX = 256;
@@ -166,12 +182,22 @@ template <int MODE>
 __device__ __forceinline__ bool gen_elem(const SortArgs &a, uint32_t b, uint32_t e, uint32_t n, uint32_t h, u64 &v)
 {
     const size_t base = (size_t)b * a.S;
-    if (MODE == GEN_BYTES4) {
-        // a.h = byte offset of the key inside the rotation (4 for the low half of the 8-byte prefix)
-        uint32_t i = e + a.h;
-        if (i >= n) i = n > 4 ? i - n : i % n;
-        const uint32_t key = text4(a.blk + base, i, n);
-        v = ((u64)key << 32) | e;
+    if (MODE == GEN_BYTES5) {
+        // key = bytes 3..7 of the rotation, the most significant first, in bits 20..59
+        const uint32_t a4 = (e + 3u) & ~3u;
+        if (a4 + 8u <= n) { // one aligned 8-byte window holds all five bytes (the lanes of a wavefront share 17 dwords)
+            uint2 w;
+            __builtin_memcpy(&w, a.blk + base + a4, 8);
+            const u64 x = (((u64)w.y << 32) | w.x) >> (8u * ((e + 3u) & 3u)); // byte 3 of the rotation lowest
+            v = ((u64)(__builtin_bswap64(x << 24) & 0xFFFFFFFFFFull) << 20) | e;
+            return true;
+        }
+        uint32_t i = e + 3u;
+        if (i >= n) i = n > 3 ? i - n : i % n;
+        uint32_t i7 = i + 4u;
+        if (i7 >= n) i7 = n > 4 ? i7 - n : i7 % n;
+        const uint32_t w4 = text4(a.blk + base, i, n);
+        v = ((u64)w4 << 28) | ((u64)a.blk[base + i7] << 20) | e;
         return true;
     } else if (MODE == GEN_SWEEP) {
         uint32_t i, k2;
@@ -179,15 +205,15 @@ __device__ __forceinline__ bool gen_elem(const SortArgs &a, uint32_t b, uint32_t
             const uint32_t j = a.sa[base + e];
             k2 = a.headp[base + e]; // = rank[j] without the gather (loaded next to sa[e], not behind the rank gather)
             i = j >= h ? j - h : j + n - h;
-            const uint32_t r = a.rank[base + rslot(i)];
+            const uint32_t r = a.rank[base + rslot(i)]; // (a block in SWEEP mode only ever holds refine's plain words)
             if (r & RANK_RESOLVED) return false;
-            v = ((u64)r << 40) | ((u64)k2 << 20) | i;
+            v = ((u64)rank_at(r, a.tag) << 40) | ((u64)k2 << 20) | i;
             return true;
         }
         i = n - 1 - e; // identical rotations: larger index first; e doubles as a distinct key2
         const uint32_t r = a.rank[base + rslot(i)];
         if (r & RANK_RESOLVED) return false;
-        v = ((u64)r << 40) | ((u64)e << 20) | i;
+        v = ((u64)rank_at(r, a.tag) << 40) | ((u64)e << 20) | i;
         return true;
     } else if (MODE == GEN_LCOL) {
         v = ((u64)a.blk[base + e] << 32) | e;
@@ -267,7 +293,7 @@ __global__ void __launch_bounds__(SORT_THREADS) active_gen(SortArgs a, uint32_t 
             if (h < n) {
                 uint32_t i2 = i + h;
                 if (i2 >= n) i2 -= n;
-                k2 = rank[rslot(i2)] & RANK_MASK;
+                k2 = rank_at(rank[rslot(i2)], a.tag);
             } else {
                 k2 = n - 1 - i;
             }
@@ -327,15 +353,57 @@ __device__ __forceinline__ u64 look2_word(uint32_t pass, uint32_t state, uint32_
     return ((u64)(pass & 0xFFFFFu) << 44) | ((u64)state << 42) | ((u64)ca << 21) | cb;
 }
 
-// REKEY: the element leaves with the key of the NEXT key half (bytes i..i+3 of the rotation) --
-// used by the last pass over the low half of the 8-byte prefix.
+// Exclusive prefix of a tile's count over the earlier tiles of its block: decoupled look-back, run by ONE WHOLE
+// WAVEFRONT (lane j inspects tile t - j, so 64 predecessors cost one round trip: with every tile of a block in
+// flight at once a one-tile-at-a-time walk is a chain of hundreds of dependent loads).  Publishes the tile's own
+// status words on the way.  Status word: [pass:32][state:2][count:30].  Returns the prefix in every lane.
+__device__ __forceinline__ uint32_t lookback_wave(u64 *st, uint32_t tile, uint32_t pass, uint32_t own, uint32_t *err,
+                                                   bool published = false)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t acc = 0;
+    if (tile > 0) {
+        if (lane == 0 && !published) __hip_atomic_store(st + tile, look_word(pass, LOOK_LOCAL, own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int t = (int)tile - 1; // nearest predecessor not yet summed
+        uint32_t spins = 0;
+        for (;;) {
+            const int idx = t - lane;
+            u64 w = look_word(pass, LOOK_GLOBAL, 0u); // before tile 0: a known prefix of nothing
+            if (idx >= 0) w = __hip_atomic_load(st + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t state = (uint32_t)(w >> 30) & 3u;
+            const bool ready = (uint32_t)(w >> 32) == pass && state != 0u;
+            const u64 nr = __ballot(!ready);
+            const int first_nr = nr ? __ffsll((long long)nr) - 1 : 64;
+            const u64 usable = first_nr == 64 ? ~0ull : ((1ull << first_nr) - 1ull);
+            const u64 gl = __ballot(ready && state == LOOK_GLOBAL) & usable;
+            const int upto = gl ? __ffsll((long long)gl) - 1 : first_nr - 1; // last lane whose count is taken
+            acc += wave_reduce_add(lane <= upto ? (uint32_t)w & 0x3FFFFFFFu : 0u);
+            if (gl) break;
+            t -= first_nr;
+            if (first_nr == 0) {
+                if (++spins > (1u << 24)) { // seconds: only a logic error gets here
+                    if (lane == 0) atomicOr(err, 2u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+    }
+    if (lane == 0) __hip_atomic_store(st + tile, look_word(pass, LOOK_GLOBAL, acc + own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return acc;
+}
+
+// MODE == GEN_GID (first pass over the upper 3 bytes of the 8-byte prefix): the list arrives ordered by bytes
+// 3..7; an element leaves with [bytes 0..2 : 24][dense index of its 5-byte group : 20][suffix : 20], so the
+// refinement after the last pass compares (bytes 0..2, index) pairs and never goes back to the text.  The index
+// is a prefix count of key changes: inside the tile by ballots, over the earlier tiles by a look-back (gst).
 // Single pass: no histogram / scan launches before this kernel.  The tile publishes its digit
 // counts, then each digit's thread looks back over the earlier tiles of the block (decoupled
 // look-back: a predecessor offers either its own counts or, once known, its inclusive prefix) for
 // the tile's first slot; digit bases come from a.dbase.  A status word is one 64-bit atomic, so no
 // fences are needed; tiles only ever wait for LOWER workgroup ids, which the dispatcher starts
 // first; waits are bounded (a.err) so that a logic error cannot hang the device.
-template <int BITS, int MODE, bool REKEY = false>
+template <int BITS, int MODE>
 __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
 {
     constexpr int NB = 1 << BITS;
@@ -358,11 +426,69 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
     // wave w owns the contiguous run [w*ITEMS*64, (w+1)*ITEMS*64) of the tile, 64 elements a step
     u64 v[SORT_ITEMS];
     uint32_t actmask = 0;
+    uint32_t gid_total = 0;
+    if (MODE == GEN_GID) {
+        const u64 *src = a.src + (size_t)b * a.S;
+        const uint32_t e0w = tile * SORT_TILE + wave * (SORT_ITEMS * 64);
+        // the element before my wavefront's run (lane 0 of the first step compares with it)
+        u64 carry = (e0w > 0 && e0w <= cnt) ? src[e0w - 1] : 0ull;
 #pragma unroll
-    for (int k = 0; k < SORT_ITEMS; k++) {
-        const uint32_t e = tile * SORT_TILE + wave * (SORT_ITEMS * 64) + k * 64 + lane;
-        v[k] = 0;
-        if (e < cnt && gen_elem<MODE>(a, b, e, n, h, v[k])) actmask |= 1u << k;
+        for (int k = 0; k < SORT_ITEMS; k++) {
+            const uint32_t e = e0w + k * 64 + lane;
+            v[k] = e < cnt ? src[e] : 0ull;
+            if (e < cnt) actmask |= 1u << k;
+        }
+        uint32_t incp[SORT_ITEMS / 2]; // key changes up to and including the element, inside the run: 16 bits each
+#pragma unroll
+        for (int k = 0; k < SORT_ITEMS / 2; k++) incp[k] = 0;
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < SORT_ITEMS; k++) {
+            const uint32_t klo = (uint32_t)(v[k] >> 20), khi = (uint32_t)(v[k] >> 52) & 0xFFu; // the 40 key bits
+            uint32_t plo = (uint32_t)__shfl_up((int)klo, 1, 64), phi = (uint32_t)__shfl_up((int)khi, 1, 64);
+            if (lane == 0) {
+                plo = (uint32_t)(carry >> 20);
+                phi = (uint32_t)(carry >> 52) & 0xFFu;
+            }
+            const bool f = ((actmask >> k) & 1u) && (e0w + k * 64 + lane == 0 || klo != plo || khi != phi);
+            carry = ((u64)(uint32_t)__shfl((int)khi, 63, 64) << 52) | ((u64)(uint32_t)__shfl((int)klo, 63, 64) << 20);
+            const u64 m = __ballot(f);
+            const uint32_t inc = run + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) + (f ? 1u : 0u);
+            incp[k >> 1] |= inc << (16 * (k & 1));
+            run += (uint32_t)__popcll(m);
+        }
+        if (lane == 0) ls[wave] = run;
+        __syncthreads();
+        uint32_t wpre = 0, gtot = 0; // key changes in the earlier wavefronts of the tile / in the whole tile
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const uint32_t c = ls[w];
+            if (w < wave) wpre += c;
+            gtot += c;
+        }
+        // The tile's count goes out right away; the count of the earlier tiles is only needed when the elements
+        // leave (the index does not take part in this pass's digit), so the look-back runs beside the digits'
+        // look-back further down and finds its predecessors long published.
+        if (threadIdx.x == 0 && tile > 0)
+            __hip_atomic_store(a.gst + (size_t)b * a.TPB * 2 + tile, look_word(a.pass, LOOK_LOCAL, gtot), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        gid_total = gtot;
+        const uint8_t *txt = a.blk + (size_t)b * a.S;
+#pragma unroll
+        for (int k = 0; k < SORT_ITEMS; k++) {
+            if ((actmask >> k) & 1u) {
+                const uint32_t i = (uint32_t)(v[k] & SUF_MASK);
+                const uint32_t gid = wpre + ((incp[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+                v[k] = ((u64)(text4(txt, i, n) >> 8) << 40) | ((u64)gid << 20) | i;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < SORT_ITEMS; k++) {
+            const uint32_t e = tile * SORT_TILE + wave * (SORT_ITEMS * 64) + k * 64 + lane;
+            v[k] = 0;
+            if (e < cnt && gen_elem<MODE>(a, b, e, n, h, v[k])) actmask |= 1u << k;
+        }
     }
     __syncthreads();
     // Rank inside the wavefront, once: a step's 64 elements are grouped by digit with BITS ballots
@@ -430,6 +556,10 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
             stage[cur[wave][d] + ((wr[k >> 1] >> (16 * (k & 1))) & 0xFFFFu)] = v[k];
         }
     }
+    if (MODE == GEN_GID && wave == NW - 1) { // (the digits keep the first NB threads busy)
+        const uint32_t pre = lookback_wave(a.gst + (size_t)b * a.TPB * 2, tile, a.pass, gid_total, a.err, true);
+        if (lane == 0) ls[NW + 1] = pre;
+    }
     if (threadIdx.x < NB) { // look back for the counts of digit `bin` in tiles 0 .. tile-1
         const uint32_t bin = threadIdx.x;
         u64 *col = a.look + (size_t)b * a.TPB * NBMAX + bin;
@@ -456,20 +586,18 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
     }
     __syncthreads();
     u64 *dst = a.dst + (size_t)b * a.S;
+    // (the staged elements count the key changes from the tile's start, 1-based; the index is 0-based over the block)
+    const u64 gadd = MODE == GEN_GID ? ((u64)ls[NW + 1] << 20) - (1ull << 20) : 0ull;
     for (uint32_t e = threadIdx.x; e < tile_total; e += SORT_THREADS) {
-        u64 x = stage[e];
+        const u64 x = stage[e];
         const uint32_t d = (uint32_t)(x >> a.shift) & (NB - 1);
-        if (REKEY) {
-            const uint32_t i = (uint32_t)(x & SUF_MASK);
-            x = ((u64)text4(a.blk + (size_t)b * a.S, i, n) << 32) | i;
-        }
-        dst[goff[d] + (e - binstart[d])] = x;
+        dst[goff[d] + (e - binstart[d])] = x + gadd;
     }
 }
 
 // ---- group refinement ---------------------------------------------------------------------------
-// small groups (<= TAIL_G members) are ranked locally: a workgroup owns TAIL_T list slots and sees TAIL_G either side
-constexpr int TAIL_G = 64, TAIL_W = 2048, TAIL_T = TAIL_W - 2 * TAIL_G, TAIL_THREADS = 512;
+// small groups (<= TAIL_G members) are ranked locally (tail_round)
+constexpr int TAIL_G = 64;
 
 struct RefineArgs {
     const uint32_t *n;   // [B]
@@ -514,13 +642,11 @@ __device__ __forceinline__ void stage_tile(const u64 *list, uint32_t tile0, uint
     }
 }
 
-// lo/plo: bytes 4..7 of the rotations of cur / prev (init pass only)
-__device__ __forceinline__ void elem_flags(const RefineArgs &a, uint32_t q, u64 cur, u64 prev, uint32_t lo, uint32_t plo,
-                                           bool &gs, bool &bd)
+__device__ __forceinline__ void elem_flags(const RefineArgs &a, uint32_t q, u64 cur, u64 prev, bool &gs, bool &bd)
 {
-    if (a.init) {
+    if (a.init) { // [bytes 0..2][index of the 5-byte group][suffix]
         gs = (q == 0);
-        bd = gs || (cur >> 32) != (prev >> 32) || lo != plo;
+        bd = gs || (cur >> 20) != (prev >> 20);
     } else {
         gs = (q == 0) || (cur >> 40) != (prev >> 40);
         bd = gs || (cur >> 20) != (prev >> 20);
@@ -547,20 +673,13 @@ __global__ void __launch_bounds__(SORT_THREADS) flag_tiles(RefineArgs a)
     int lastgs = -1, lastbd = -1, firstbd = INT32_MAX, nbd = 0;
     if (q0 < cnt) {
         u64 prev = e0 ? lds[slot_of(e0 - 1)] : (q0 ? list[q0 - 1] : 0ull);
-        const uint32_t n = a.n[b];
-        const uint8_t *txt = a.blk + base;
-        uint32_t plo = 0;
-        if (a.init && q0) plo = text4(txt, wrap_add(prev, n), n);
 #pragma unroll
         for (int k = 0; k < SORT_ITEMS; k++) {
             const uint32_t q = q0 + k;
             if (q < cnt) {
                 const u64 cur = lds[slot_of(e0 + k)];
-                uint32_t lo = 0;
-                if (a.init) lo = text4(txt, wrap_add(cur, n), n);
                 bool gs, bd;
-                elem_flags(a, q, cur, prev, lo, plo, gs, bd);
-                plo = lo;
+                elem_flags(a, q, cur, prev, gs, bd);
                 if (gs) lastgs = (int)q;
                 if (bd) {
                     lastbd = (int)q;
@@ -869,249 +988,480 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
     }
 }
 
-// ---- small groups: sorted locally ---------------------------------------------------------------------
-// The block's small-group list (listC) holds, in `len` slots, the unresolved suffixes of every group
-// with at most TAIL_G members; a group's records are adjacent, the order of the groups is arbitrary
-// (refine appends new small groups behind the survivors).  Each record carries the suffix and its group
-// rank, so nothing has to be gathered but key2.  tail_sort: a workgroup owns the groups whose first member
-// lies in its range of TAIL_T slots and sees TAIL_G slots either side, so every owned group is complete
-// in its window; every member of an owned group counts the members that sort before it (at most TAIL_G
-// steps over keys in LDS -- all-pairs work stays below ~6 comparisons per suffix of the block because
-// larger groups never come here) and a record for the slot of the u-th member goes into listD (same slot
-// numbering), so the input stays untouched during the kernel.  tail_sort reads only OLD ranks; tail_finish
-// stores the new ranks (the kernel boundary keeps rank reads consistent) and moves the still-unresolved
-// records, order preserved, back to listC, so the next round touches only what is left.
-constexpr int TAIL_PER = TAIL_W / TAIL_THREADS; // 4 window slots per thread
-constexpr int FIN_T = 2048;                     // slots per workgroup of tail_finish
-constexpr uint32_t NONE32 = 0xFFFFFFFFu;
-static_assert(TAIL_W % TAIL_THREADS == 0, "window = whole slots per thread");
+// ---- refinement in ONE kernel (the initial sort, and the big lists of SPLIT-mode blocks) ---------------------
+// What flag_tiles + flag_carry + refine do in three launches and two reads of the list, for blocks that need
+// neither provisional SA entries nor digit counts (i.e. everything but SWEEP mode):
+//  * the extent of a group to the LEFT (its head position = its new rank) is carried from tile to tile by a
+//    look-back over per-tile aggregates (last group start, last boundary) that every tile publishes right after
+//    its own flags -- no tile waits for another tile's look-back;
+//  * to the RIGHT only "does the group end within TAIL_G elements" matters (single / small / large), so a tile
+//    reads TAIL_G elements of its successor instead of waiting for it;
+//  * neither list needs an order among tiles (the big list is re-sorted from scratch, the groups of the small
+//    list are independent), so a tile claims its room with one atomic add per list.  A small group that
+//    straddles a tile end is written, whole, by the tile it starts in (its members must stay adjacent); the
+//    next tile ranks its part of that group and leaves the records alone.
+constexpr int POS_FAR = INT32_MAX; // "no boundary within reach"
+
+// Carries of a tile: last group start / last boundary in any earlier tile of the block (-1: none).  Run by one
+// whole wavefront; lane j inspects tile t - j.  Status word: look2_word(pass, state, start + 1, boundary + 1).
+__device__ __forceinline__ void carry_lookback(u64 *st, uint32_t tile, uint32_t pass, int own_gs, int own_bd, bool need_gs,
+                                               int &cg, int &cd, uint32_t *err)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t egs = (uint32_t)(own_gs + 1), ebd = (uint32_t)(own_bd + 1);
+    uint32_t fg = 0, fb = 0;
+    if (tile > 0) {
+        if (lane == 0) __hip_atomic_store(st + (size_t)tile * NBMAX, look2_word(pass, LOOK_LOCAL, egs, ebd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool hg = !need_gs, hb = false;
+        int t = (int)tile - 1;
+        uint32_t spins = 0;
+        for (;;) {
+            const int idx = t - lane;
+            u64 w = look2_word(pass, LOOK_GLOBAL, 0u, 0u); // before tile 0: nothing
+            if (idx >= 0) w = __hip_atomic_load(st + (size_t)idx * NBMAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t state = (uint32_t)(w >> 42) & 3u;
+            const bool ready = (uint32_t)(w >> 44) == (pass & 0xFFFFFu) && state != 0u;
+            const uint32_t vg = (uint32_t)(w >> 21) & 0x1FFFFFu, vb = (uint32_t)w & 0x1FFFFFu;
+            const u64 nr = __ballot(!ready);
+            const int first_nr = nr ? __ffsll((long long)nr) - 1 : 64;
+            const u64 usable = first_nr == 64 ? ~0ull : ((1ull << first_nr) - 1ull);
+            const u64 mg = __ballot(ready && state == LOOK_GLOBAL) & usable; // inclusive over everything before
+            if (!hb) {
+                const u64 m = (__ballot(ready && vb != 0u) & usable) | mg;
+                if (m) {
+                    fb = (uint32_t)__shfl((int)vb, __ffsll((long long)m) - 1, 64);
+                    hb = true;
+                }
+            }
+            if (!hg) {
+                const u64 m = (__ballot(ready && vg != 0u) & usable) | mg;
+                if (m) {
+                    fg = (uint32_t)__shfl((int)vg, __ffsll((long long)m) - 1, 64);
+                    hg = true;
+                }
+            }
+            if (hb && hg) break;
+            t -= first_nr;
+            if (first_nr == 0) {
+                if (++spins > (1u << 24)) { // seconds: only a logic error gets here
+                    if (lane == 0) atomicOr(err, 2u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+    }
+    if (lane == 0)
+        __hip_atomic_store(st + (size_t)tile * NBMAX, look2_word(pass, LOOK_GLOBAL, max(egs, fg), max(ebd, fb)), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    cg = (int)fg - 1;
+    cd = (int)fb - 1;
+}
+
+template <bool INIT>
+__global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_t *c_groups, u64 *recs)
+{
+    uint32_t b, tile;
+    if (!wg_map(a.T, a.lst, b, tile)) return;
+    const uint32_t cnt = a.cnt[b];
+    const uint32_t ntile = (cnt + SORT_TILE - 1) / SORT_TILE;
+    if (tile >= ntile) return;
+    const size_t base = (size_t)b * a.S;
+    const u64 *list = a.list + base;
+    const uint32_t tile0 = tile * SORT_TILE, tend = tile0 + SORT_TILE;
+    constexpr int NW = SORT_THREADS / 64;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ u64 lds[STAGE_SLOTS];
+    __shared__ u64 halo[TAIL_G + 1]; // [0]: the element before the tile; [1 + t]: element tend + t
+    __shared__ int l01[2 * NW];
+    __shared__ int ex0[SORT_THREADS], ex1[SORT_THREADS];
+    __shared__ uint32_t lsu[NW + 2];
+    __shared__ int s_cg, s_cd, s_hend;
+    __shared__ uint32_t s_offS, s_offB;
+    stage_tile(list, tile0, cnt, lds);
+    if (threadIdx.x < (uint32_t)TAIL_G) halo[1 + threadIdx.x] = tend + threadIdx.x < cnt ? list[tend + threadIdx.x] : 0ull;
+    if (threadIdx.x == (uint32_t)TAIL_G) halo[0] = tile0 ? list[tile0 - 1] : 0ull;
+    __syncthreads();
+
+    // flags of my 16 elements -- bit 0: first of its (old) group, bit 1: first of its refined group
+    const uint32_t e0 = threadIdx.x * SORT_ITEMS, q0 = tile0 + e0;
+    uint32_t packed = 0;
+    int lastgs = -1, lastbd = -1, firstbd = POS_FAR;
+    uint32_t nbd = 0;
+    bool progress = false;
+    if (q0 < cnt) {
+        u64 prev = e0 ? lds[slot_of(e0 - 1)] : halo[0];
+#pragma unroll
+        for (int k = 0; k < SORT_ITEMS; k++) {
+            const uint32_t q = q0 + k;
+            if (q < cnt) {
+                const u64 cur = lds[slot_of(e0 + k)];
+                // init: [bytes 0..2][index of the 5-byte group][suffix], one "old group"; rounds: [rank][key2][suffix]
+                const bool gs = q == 0 || (!INIT && (cur >> 40) != (prev >> 40));
+                const bool bd = gs || (cur >> 20) != (prev >> 20);
+                if (gs) lastgs = (int)q;
+                if (bd) {
+                    lastbd = (int)q;
+                    if (firstbd == POS_FAR) firstbd = (int)q;
+                    nbd++;
+                    if (!gs) progress = true; // a boundary inside an old group: that group was refined
+                }
+                packed |= ((gs ? 1u : 0u) | (bd ? 2u : 0u)) << (2 * k);
+                prev = cur;
+            }
+        }
+    }
+    // first boundary behind the tile, as far as it matters: within TAIL_G elements (the list end counts)
+    if (wave == 0) {
+        bool bd = false;
+        const uint32_t q = tend + lane;
+        if (q == cnt) {
+            bd = true;
+        } else if (q < cnt) {
+            const u64 cur = halo[1 + lane], prev = lane ? halo[lane] : lds[slot_of(SORT_TILE - 1)];
+            bd = (cur >> 20) != (prev >> 20);
+        }
+        const u64 m = __ballot(bd);
+        if (lane == 0) s_hend = cnt <= tend ? (int)cnt : (m ? (int)(tend + __ffsll((long long)m) - 1) : POS_FAR);
+    }
+    int tg = lastgs, td = lastbd;
+    block_incl_max2(tg, td, l01);
+    ex0[threadIdx.x] = tg;
+    ex1[threadIdx.x] = td;
+    int nxt = block_excl_min_rev(firstbd, l01); // barrier inside: ex0 / ex1 / s_hend visible
+    if (wave == 0) {
+        int cgi, cdi;
+        carry_lookback(a.cstat + (size_t)b * a.TPB * NBMAX + 192, tile, a.cpass, ex0[SORT_THREADS - 1], ex1[SORT_THREADS - 1], !INIT,
+                       cgi, cdi, a.err);
+        if (lane == 0) {
+            s_cg = cgi;
+            s_cd = cdi;
+        }
+    }
+    if (INIT) { // groups of the block: round_begin picks the block's first mode from it
+        const uint32_t c = wave_reduce_add(nbd);
+        if (lane == 0 && c) atomicAdd(&c_groups[b], c);
+    }
+    __syncthreads();
+    const int cg_in = s_cg, cd_in = s_cd, hend = s_hend;
+    int cg = cg_in, cd = cd_in;
+    if (threadIdx.x > 0) {
+        cg = max(cg, ex0[threadIdx.x - 1]);
+        cd = max(cd, ex1[threadIdx.x - 1]);
+    }
+    if (nxt == POS_FAR) nxt = hend;
+    // backward: end of every element's group; forward: its start -> class, 2 bits per element
+    uint32_t gend[SORT_ITEMS];
+    {
+        int run = nxt;
+#pragma unroll
+        for (int k = SORT_ITEMS - 1; k >= 0; k--) {
+            gend[k] = (uint32_t)run;
+            if (q0 + k < cnt && ((packed >> (2 * k)) & 2u)) run = (int)(q0 + k);
+        }
+    }
+    uint32_t cls = 0, nS = 0, nB = 0, foreign = 0;
+    {
+        int run = cd;
+#pragma unroll
+        for (int k = 0; k < SORT_ITEMS; k++) {
+            if (q0 + k < cnt) {
+                if ((packed >> (2 * k)) & 2u) run = (int)(q0 + k);
+                const uint32_t size = gend[k] - (uint32_t)run;
+                const uint32_t c = size == 1u ? CLS_SINGLE : (size <= (uint32_t)TAIL_G ? CLS_SMALL : CLS_BIG);
+                cls |= c << (2 * k);
+                const bool fo = c == CLS_SMALL && run < (int)tile0; // the tile the group starts in writes its records
+                foreign |= (fo ? 1u : 0u) << k;
+                nS += c == CLS_SMALL && !fo;
+                nB += c == CLS_BIG;
+            }
+        }
+    }
+    // the small group that runs over the tile end (if any): its members behind the tile are mine to write
+    const int last_start = max(cd_in, ex1[SORT_THREADS - 1]), last_gs = max(cg_in, ex0[SORT_THREADS - 1]);
+    const uint32_t nH = (cnt > tend && hend != POS_FAR && (uint32_t)hend > tend && (uint32_t)(hend - last_start) <= (uint32_t)TAIL_G)
+                            ? (uint32_t)hend - tend
+                            : 0u;
+    uint32_t totS = 0, totB = 0;
+    const uint32_t offS = block_excl_add(nS, lsu, &totS);
+    const uint32_t offB = block_excl_add(nB, lsu, &totB);
+    if (threadIdx.x == 0) {
+        s_offS = (totS + nH) ? atomicAdd(&a.c_small[b], totS + nH) : 0u;
+        s_offB = totB ? atomicAdd(&a.c_big[b], totB) : 0u;
+    }
+    uint32_t *rank = a.rank + base;
+    u64 outv[SORT_ITEMS]; // list record (rank : 20 @40, suffix : 20 @0) or all ones
+#pragma unroll
+    for (int k = 0; k < SORT_ITEMS; k++) outv[k] = ~0ull;
+    if (q0 < cnt) {
+#pragma unroll
+        for (int k = 0; k < SORT_ITEMS; k++) {
+            const uint32_t q = q0 + k;
+            if (q < cnt) {
+                const uint32_t f = (packed >> (2 * k)) & 3u;
+                if (f & 1u) cg = (int)q;
+                if (f & 2u) cd = (int)q;
+                const uint32_t c = (cls >> (2 * k)) & 3u;
+                const u64 cur = lds[slot_of(e0 + k)];
+                const uint32_t i = (uint32_t)(cur & SUF_MASK);
+                // SA position of the group's first list entry, minus that entry's list index
+                const uint32_t oldr = (uint32_t)(cur >> 40);
+                const uint32_t gbase = INIT ? 0u : (oldr - (uint32_t)cg);
+                const uint32_t head = gbase + (uint32_t)cd;
+                const bool single = c == CLS_SINGLE;
+                // (the last column is emitted from the ranks; a rank that did not move and stays unresolved is in place)
+                const uint32_t word = single ? (head | RANK_RESOLVED) : head;
+                if (INIT)
+                    lds[slot_of(e0 + k)] = ((u64)word << 32) | i; // every suffix gets a rank: binned, then applied (rank_apply)
+                else if (single || head != oldr)
+                    rank[rslot(i)] = word;
+                if (!single && !((foreign >> k) & 1u)) outv[k] = ((u64)c << 62) | ((u64)head << 40) | i;
+            }
+        }
+    }
+    if (__ballot(progress) && lane == 0) a.c_prog[b] = 1u; // same value from everyone
+    if (INIT) { // the (rank word, suffix) pairs of the tile, in list order, as coalesced stores
+        __syncthreads();
+        u64 *rc = recs + base;
+#pragma unroll
+        for (int k = 0; k < SORT_ITEMS; k++) {
+            const uint32_t e = k * SORT_THREADS + threadIdx.x;
+            if (tile0 + e < cnt) rc[tile0 + e] = lds[slot_of(e)];
+        }
+    }
+    __syncthreads(); // every thread is done with the staged tile; s_off* are there
+    // records leave through LDS: the tile's small-group records at [0, totS + nH), its large-group records behind them
+    {
+        uint32_t wS = offS, wB = totS + nH + offB;
+#pragma unroll
+        for (int k = 0; k < SORT_ITEMS; k++) {
+            if (outv[k] != ~0ull) {
+                const u64 rec = outv[k] & ~(3ull << 62);
+                if ((outv[k] >> 62) == CLS_SMALL) lds[wS++] = rec;
+                else lds[wB++] = rec;
+            }
+        }
+        if (threadIdx.x < nH) { // same (old and refined) group as the tile's last element
+            const uint32_t oldr = (uint32_t)(halo[1 + threadIdx.x] >> 40);
+            const uint32_t head = (INIT ? 0u : oldr - (uint32_t)last_gs) + (uint32_t)last_start;
+            lds[totS + threadIdx.x] = ((u64)head << 40) | (halo[1 + threadIdx.x] & SUF_MASK);
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t tbase = INIT ? 0u : a.tbase[b];
+        u64 *ts = a.tail + base + tbase + s_offS;
+        u64 *bs = a.big + base + s_offB;
+        const uint32_t nSm = totS + nH;
+        for (uint32_t e = threadIdx.x; e < nSm; e += SORT_THREADS) ts[e] = lds[e];
+        for (uint32_t e = threadIdx.x; e < totB; e += SORT_THREADS) bs[e] = lds[nSm + e];
+    }
+}
+
+// ---- small groups: ranked locally, one kernel per round -------------------------------------------------
+// The block's small-group list holds, in `len` slots, the unresolved suffixes of every group with at most
+// TAIL_G members; a group's records are adjacent, the order of the groups is arbitrary (refine appends new
+// small groups behind the survivors).  Each record carries the suffix and its group rank, so nothing has to
+// be gathered but key2.
+//
+// tail_round does a whole round for these groups in ONE kernel: a workgroup owns the groups whose first member
+// lies in its range of TR_T slots and sees TAIL_G slots either side, so every owned group is complete in its
+// window; every slot walks outwards over the members of its group (keys in LDS) and counts the members that
+// sort before it -- all-pairs work stays below ~6 comparisons per suffix of the block because larger groups
+// never come here.  New ranks are stored straight away, which is only sound because a rank word keeps BOTH
+// versions (rank_word / rank_at): another workgroup of the same launch that gathers the word as its key2 still
+// reads the rank the suffix had when the round began (a mix of old and new ranks inside one group of key2
+// values would mis-order its readers).  A group of <= TAIL_G members moves a member by less than TAIL_G
+// places, so the new rank is the old one plus a 6-bit count.  Survivors are compacted into the block's OTHER
+// list buffer (ballots inside the tile; a tile claims its room in the new list with one atomic add -- the order
+// of the groups in a list does not matter, only that a group's members are adjacent), so the next round touches
+// only what is left.
+constexpr int TR_THREADS = 256, TR_PER = 8, TR_W = TR_THREADS * TR_PER, TR_T = TR_W - 2 * TAIL_G;
+static_assert(TAIL_G <= 64, "the rank word keeps a 6-bit displacement");
 
 struct TailArgs {
     const uint32_t *n;   // [B]
     const uint32_t *len; // [B] slot count of the block's list this round
-    u64 *bufC, *bufD;    // [B][S]
+    u64 *src;            // [B][S] the lists as the round finds them (read only)
+    u64 *dst;            // [B][S] the survivors, compacted
     uint32_t *rank;      // [B][S]
     uint32_t *c_tail;    // [B] survivors of the round
     uint32_t *c_prog;    // [B] "a group was refined"
-    u64 *stat;           // [B][FT] tile status words of tail_finish's look-back
-    uint32_t pass;       // pass id in those words
+    uint32_t tag;        // this round's id in the rank words
     uint32_t *err;       // [1] precondition violations
     const uint32_t *hb;  // [B] depth h of each block
-    uint32_t S, T, FT;
+    uint32_t S, T;
     Lst lst;
 };
 
-// record: [unchanged:1 @61][resolved:1 @60][new rank:20 @40][0:20][suffix:20 @0]
+// list record: [rank:20 @40][0:20][suffix:20 @0]
 template <bool QUAD>
-__global__ void __launch_bounds__(TAIL_THREADS) tail_sort(TailArgs a)
+__global__ void __launch_bounds__(TR_THREADS) tail_round(TailArgs a)
 {
     uint32_t b, tile;
     if (!wg_map(a.T, a.lst, b, tile)) return;
     const uint32_t len = a.len[b];
-    const uint32_t r0 = tile * TAIL_T;
+    const uint32_t r0 = tile * TR_T;
     if (r0 >= len) return;
-    const uint32_t r1 = min(len, r0 + (uint32_t)TAIL_T);
+    const uint32_t r1 = min(len, r0 + (uint32_t)TR_T);
     const uint32_t s_lo = r0 >= (uint32_t)TAIL_G ? r0 - TAIL_G : 0u;
     const uint32_t s_hi = min(len, r1 + (uint32_t)TAIL_G);
-    const uint32_t nwin = s_hi - s_lo; // <= TAIL_W
-    const uint32_t n = a.n[b], h = a.hb[b];
+    const uint32_t nwin = s_hi - s_lo; // <= TR_W
+    const uint32_t n = a.n[b], h = a.hb[b], tag = a.tag;
     const size_t base = (size_t)b * a.S;
-    const u64 *buf = a.bufC + base; // read only during this kernel
-    u64 *out = a.bufD + base;       // records, same slot numbering
-    const uint32_t *rank = a.rank + base;
-    // A0 group rank of every window slot, A3 (A4, A5) keys of the owned ones, GE group end (stored at the group's head)
-    __shared__ uint32_t A0[TAIL_W], A3[TAIL_W];
-    __shared__ uint32_t A4[QUAD ? TAIL_W : 1], A5[QUAD ? TAIL_W : 1]; // extra keys of the 4h form only
-    __shared__ uint16_t GE[TAIL_W];
-    __shared__ int lm[TAIL_THREADS / 64];
-    __shared__ int exh[TAIL_THREADS];
+    const u64 *src = a.src + base;
+    u64 *dst = a.dst + base;
+    uint32_t *rank = a.rank + base;
+    constexpr int NWV = TR_THREADS / 64, ROWS = TR_W / 64;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // R: group rank of every window slot (all ones: no record), K2 (K34): its key(s); HM: per 64 slots, which of
+    // them start a group.  After the ranking BUF is reused for the records in their new order.
+    __shared__ u64 BUF[TR_W];
+    __shared__ u64 K34[QUAD ? TR_W : 1];
+    __shared__ u64 HM[ROWS];
+    __shared__ uint32_t wc[TR_PER * NWV];
+    __shared__ uint32_t tpre;
+    uint32_t *R = reinterpret_cast<uint32_t *>(BUF), *K2 = R + TR_W;
 
-    // a thread owns TAIL_PER consecutive window slots; 16-byte loads of two records
-    const uint32_t w0 = threadIdx.x * TAIL_PER;
-    const uint32_t cnt = w0 < nwin ? min((uint32_t)TAIL_PER, nwin - w0) : 0u;
-    uint32_t cr[TAIL_PER], ci[TAIL_PER];
+    // slot w = k * TR_THREADS + thread: coalesced loads, and the lanes of a wavefront hold 64 consecutive slots
+    // (the ranking loop below runs as long as the largest group among them, not among 4 times as many)
+    uint32_t ci[TR_PER], cr[TR_PER];
+    {
+        u64 x[TR_PER];
 #pragma unroll
-    for (int k = 0; k < TAIL_PER; k++) {
-        cr[k] = NONE32;
-        ci[k] = 0;
-        if ((uint32_t)k < cnt) {
-            const u64 x = buf[s_lo + w0 + k];
-            ci[k] = (uint32_t)(x & SUF_MASK);
-            cr[k] = (uint32_t)(x >> 40) & 0xFFFFFu;
+        for (int k = 0; k < TR_PER; k++) {
+            const uint32_t w = k * TR_THREADS + threadIdx.x;
+            x[k] = w < nwin ? src[s_lo + w] : LIST_INVALID;
         }
-        A0[w0 + k] = cr[k];
-    }
-    __syncthreads();
-    // group structure by scan: start of every element's group, end of the group stored at its head
-    const uint32_t prevr = (cnt && w0 > 0) ? A0[w0 - 1] : NONE32;
-    const uint32_t nextr = (cnt && w0 + cnt < nwin) ? A0[w0 + cnt] : NONE32;
-    int lasthead = -1;
 #pragma unroll
-    for (int j = 0; j < TAIL_PER; j++)
-        if ((uint32_t)j < cnt && cr[j] != (j ? cr[j - 1] : prevr)) lasthead = (int)(w0 + j);
-    const int inc = block_incl_max(lasthead, lm);
-    exh[threadIdx.x] = inc;
-    __syncthreads();
-    int run = threadIdx.x ? exh[threadIdx.x - 1] : -1;
-    uint32_t gstart[TAIL_PER];
-#pragma unroll
-    for (int j = 0; j < TAIL_PER; j++) {
-        gstart[j] = 0;
-        if ((uint32_t)j < cnt) {
-            if (cr[j] != (j ? cr[j - 1] : prevr)) run = (int)(w0 + j);
-            gstart[j] = (uint32_t)run;
-            const uint32_t nx = ((uint32_t)(j + 1) < cnt) ? cr[(j + 1 < TAIL_PER) ? j + 1 : j] : nextr;
-            if (nx != cr[j]) GE[run] = (uint16_t)(w0 + j + 1);
-        }
-    }
-    // ownership and the keys of owned elements
-    uint32_t owned = 0;
-    bool bad = false;
-#pragma unroll
-    for (int j = 0; j < TAIL_PER; j++) {
-        if ((uint32_t)j < cnt) {
-            const uint32_t e = w0 + j;
-            const uint32_t fs = s_lo + gstart[j];
-            if (fs >= r0 && fs < r1) {
-                owned |= 1u << j;
-                if (e - gstart[j] >= (uint32_t)TAIL_G) bad = true; // beyond the window guarantee
-                const uint32_t i = ci[j];
-                uint32_t k2, k3 = 0, k4 = 0;
+        for (int k = 0; k < TR_PER; k++) {
+            const uint32_t w = k * TR_THREADS + threadIdx.x;
+            ci[k] = (uint32_t)(x[k] & SUF_MASK);
+            cr[k] = w < nwin ? (uint32_t)(x[k] >> 40) & 0xFFFFFu : 0xFFFFFFFFu;
+            uint32_t k2 = 0, k3 = 0, k4 = 0;
+            if (w < nwin) {
+                const uint32_t i = ci[k];
                 if (h < n) {
                     uint32_t i2 = i + h;
                     if (i2 >= n) i2 -= n;
-                    k2 = rank[rslot(i2)] & RANK_MASK;
+                    k2 = rank_at(rank[rslot(i2)], tag);
                     if (QUAD) { // two more h-blocks of the (cyclic) rotation
                         uint32_t i3 = i2 + h;
                         if (i3 >= n) i3 -= n;
                         uint32_t i4 = i3 + h;
                         if (i4 >= n) i4 -= n;
-                        k3 = rank[rslot(i3)] & RANK_MASK;
-                        k4 = rank[rslot(i4)] & RANK_MASK;
+                        k3 = rank_at(rank[rslot(i3)], tag);
+                        k4 = rank_at(rank[rslot(i4)], tag);
                     }
                 } else {
                     k2 = n - 1 - i; // identical rotations: larger index first
                 }
-                A3[e] = k2;
-                if (QUAD) {
-                    A4[e] = k3;
-                    A5[e] = k4;
-                }
             }
+            R[w] = cr[k];
+            K2[w] = k2;
+            if (QUAD) K34[w] = ((u64)k3 << 32) | k4;
         }
     }
     __syncthreads();
-    bool moved = false; // some owned element left the head of its group: the group was refined
+    // group structure: slot w starts a group if its rank differs from slot w-1's; the end of the window counts
 #pragma unroll
-    for (int j = 0; j < TAIL_PER; j++) {
-        if ((uint32_t)j < cnt && (owned & (1u << j))) {
-            const uint32_t e = w0 + j, r = cr[j], g = gstart[j];
-            const uint32_t ge = min((uint32_t)GE[g], g + (uint32_t)TAIL_G);
-            // lexicographic key (k2, k3, k4): two 64-bit words compare it
-            const uint32_t my_hi = A3[e];
-            const u64 my_lo = QUAD ? (((u64)A4[e] << 32) | A5[e]) : 0ull;
-            uint32_t less = 0, eq_before = 0, eq = 0;
+    for (int k = 0; k < TR_PER; k++) {
+        const uint32_t w = k * TR_THREADS + threadIdx.x;
+        const bool head = w <= nwin && (w == 0 || w == nwin || R[w - 1] != cr[k]);
+        const u64 hm = __ballot(head);
+        if (lane == 0) HM[k * NWV + wave] = hm;
+    }
+    __syncthreads();
+    // Ranking: every member counts the members of its group that sort before it.
+    uint32_t res[TR_PER]; // [owned:1 @31][single:1 @30][less:6 @24][dest slot:12 @0]
+    bool moved = false, bad = false;
+#pragma unroll
+    for (int k = 0; k < TR_PER; k++) {
+        const uint32_t w = k * TR_THREADS + threadIdx.x;
+        res[k] = w; // slots without a record stay where they are
+        if (w < nwin) {
+            const uint32_t row = k * NWV + wave;
+            const u64 own = HM[row];
+            const u64 upto = (2ull << lane) - 1ull; // bits 0..lane (lane 63: all)
+            const u64 below = own & upto, above = own & ~upto;
+            uint32_t g, ge;
+            if (below) {
+                g = row * 64u + 63u - (uint32_t)__clzll((long long)below);
+            } else { // the group began in the 64 slots before (row > 0: slot 0 starts a group)
+                const u64 pm = HM[row - 1];
+                g = pm ? (row - 1) * 64u + 63u - (uint32_t)__clzll((long long)pm) : (row - 1) * 64u;
+            }
+            if (above) {
+                ge = row * 64u + (uint32_t)__ffsll((long long)above) - 1u;
+            } else {
+                const u64 nm = row + 1 < (uint32_t)ROWS ? HM[row + 1] : 0ull;
+                ge = nm ? (row + 1) * 64u + (uint32_t)__ffsll((long long)nm) - 1u : min(nwin, (row + 2) * 64u);
+            }
+            const uint32_t fs = s_lo + g;
+            const bool owned = fs >= r0 && fs < r1;
+            if (ge - g > (uint32_t)TAIL_G) { // beyond the window guarantee (never for an owned group)
+                bad |= owned;
+                ge = g + TAIL_G;
+            }
+            const uint32_t my = K2[w];
+            const u64 my2 = QUAD ? K34[w] : 0ull;
+            uint32_t less = 0, eq = 0, eqb = 0;
 #pragma unroll 4
             for (uint32_t f = g; f < ge; f++) { // bounds known up front: the LDS reads pipeline
-                const uint32_t f_hi = A3[f];
-                const u64 f_lo = QUAD ? (((u64)A4[f] << 32) | A5[f]) : 0ull;
-                const bool same = f_hi == my_hi && f_lo == my_lo;
-                less += (f_hi < my_hi) || (f_hi == my_hi && f_lo < my_lo);
+                const uint32_t kf = K2[f];
+                const u64 kf2 = QUAD ? K34[f] : 0ull;
+                const bool same = kf == my && kf2 == my2;
+                less += (kf < my) || (QUAD && kf == my && kf2 < my2);
                 eq += same;
-                eq_before += same && (f < e);
+                eqb += same && f < w;
             }
-            const uint32_t u = less + eq_before;
-            const bool single = eq == 1;
-            moved |= less != 0;
-            // bit 60: resolved; bit 61: rank unchanged and still unresolved (nothing to store for this suffix)
-            const u64 rec = ((u64)(single ? 1u : (less == 0u ? 2u : 0u)) << 60) | ((u64)(r + less) << 40) | ci[j];
-            out[s_lo + g + u] = rec; // the u-th smallest member takes the slot of the u-th member
+            const bool single = eq == 1u;
+            if (owned) {
+                moved |= less != 0u;
+                // (the last column is emitted from the ranks, so nothing but the rank word is stored per suffix;
+                // an unchanged rank that stays unresolved needs no store at all)
+                if (single || less) rank[rslot(ci[k])] = rank_word(cr[k], less, tag, single);
+            }
+            res[k] = (owned ? 0x80000000u : 0u) | (single ? 0x40000000u : 0u) | (less << 24) | (g + less + eqb);
         }
     }
-    if (__ballot(moved) && (threadIdx.x & 63) == 0) a.c_prog[b] = 1u;
-    if (bad) atomicOr(a.err, 1u);
-}
-
-// After tail_sort, one kernel: applies the records of a tile (new ranks -- the kernel boundary after
-// tail_sort keeps its rank reads consistent), and moves the records that are still unresolved, order
-// preserved, back to the block's list: a thread owns 8 slots, ballots give the offsets inside the tile, a
-// look-back over the tile counts the offset of the tile.  The last tile leaves the block's survivor count.
-__global__ void __launch_bounds__(256) tail_finish(TailArgs a)
-{
-    uint32_t b, tile;
-    if (!wg_map(a.T, a.lst, b, tile)) return;
-    const uint32_t len = a.len[b];
-    const uint32_t r0 = tile * FIN_T;
-    if (r0 >= len) return;
-    const size_t base = (size_t)b * a.S;
-    const u64 *rec = a.bufD + base; // tail_sort's output
-    u64 *dst = a.bufC + base;       // back home, compacted
-    uint32_t *rank = a.rank + base;
-    constexpr int PER = FIN_T / 256, NWV = 256 / 64;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // slot = r0 + k*256 + thread: coalesced reads; survivors keep slot order = (k, wave, lane) order
-    __shared__ uint32_t wc[PER * NWV + 1];
-    __shared__ uint32_t tpre;
-    u64 x[PER];
-    uint32_t lo[PER]; // survivors of my wavefront's row k in lower lanes
+    __syncthreads(); // everybody is done reading the keys
+    // the u-th smallest member takes the slot of the u-th member; resolved and foreign records leave as "none"
 #pragma unroll
-    for (int k = 0; k < PER; k++) {
-        const uint32_t sl = r0 + k * 256 + threadIdx.x;
-        x[k] = sl < len ? rec[sl] : LIST_INVALID;
+    for (int k = 0; k < TR_PER; k++) {
+        const uint32_t w = k * TR_THREADS + threadIdx.x;
+        u64 rec = LIST_INVALID;
+        if (w < nwin && (res[k] >> 30) == 2u) // owned, not single
+            rec = ((u64)(cr[k] + ((res[k] >> 24) & 63u)) << 40) | ci[k];
+        BUF[res[k] & 0xFFFu] = rec;
     }
+    __syncthreads();
+    u64 x[TR_PER];
+    uint32_t lo[TR_PER]; // survivors of my wavefront's row k in lower lanes
 #pragma unroll
-    for (int k = 0; k < PER; k++) {
-        if (x[k] != LIST_INVALID) {
-            const uint32_t i = (uint32_t)(x[k] & SUF_MASK);
-            const uint32_t nr = (uint32_t)(x[k] >> 40) & 0xFFFFFu;
-            const bool res = (x[k] >> 60) & 1ull, same = (x[k] >> 61) & 1ull;
-            // (the last column is emitted from the ranks, so nothing but the rank is stored per suffix)
-            if (!same) rank[rslot(i)] = res ? (nr | RANK_RESOLVED) : nr;
-            if (res) x[k] = LIST_INVALID;
-        }
+    for (int k = 0; k < TR_PER; k++) {
+        x[k] = BUF[k * TR_THREADS + threadIdx.x];
         const u64 m = __ballot(x[k] != LIST_INVALID);
         lo[k] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         if (lane == 0) wc[k * NWV + wave] = (uint32_t)__popcll(m);
     }
+    if (__ballot(moved) && lane == 0) a.c_prog[b] = 1u; // same value from everyone
+    if (bad) atomicOr(a.err, 1u);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-#pragma unroll
-        for (int q = 0; q < PER * NWV; q++) { // exclusive scan in slot order
-            const uint32_t c = wc[q];
-            wc[q] = tot;
-            tot += c;
-        }
-        u64 *st = a.stat + (size_t)b * a.FT; // one word per tile
-        uint32_t acc = 0, spins = 0;
-        if (tile > 0) {
-            __hip_atomic_store(st + tile, look_word(a.pass, LOOK_LOCAL, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int t = (int)tile - 1;
-            while (t >= 0) {
-                const u64 w = __hip_atomic_load(st + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t state = (uint32_t)(w >> 30) & 3u;
-                if ((uint32_t)(w >> 32) != a.pass || state == 0) {
-                    if (++spins > (1u << 26)) {
-                        atomicOr(a.err, 2u);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                    continue;
-                }
-                acc += (uint32_t)w & 0x3FFFFFFFu;
-                if (state == LOOK_GLOBAL) break;
-                t--;
-            }
-        }
-        __hip_atomic_store(st + tile, look_word(a.pass, LOOK_GLOBAL, acc + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tpre = acc;
-        if (r0 + FIN_T >= len) a.c_tail[b] = acc + tot; // last tile: the block's small-group survivors
+    if (wave == 0) { // exclusive scan of the row counts in slot order, then the tile's place in the block's new list
+        const uint32_t c = lane < (uint32_t)(TR_PER * NWV) ? wc[lane] : 0u;
+        const uint32_t inc = wave_incl_add(c, (int)lane);
+        if (lane < (uint32_t)(TR_PER * NWV)) wc[lane] = inc - c;
+        // The order of the GROUPS in a small-group list is arbitrary (only a group's members must be adjacent), so a
+        // tile just claims room behind whatever is there: no tile ever waits for another.  c_tail ends up as the
+        // block's survivor count (round_begin cleared it).
+        if (lane == 63) tpre = inc ? atomicAdd(&a.c_tail[b], inc) : 0u;
     }
     __syncthreads();
     const uint32_t pre = tpre;
 #pragma unroll
-    for (int k = 0; k < PER; k++)
-        if (x[k] != LIST_INVALID) dst[pre + wc[k * NWV + wave] + lo[k]] = x[k] & ~(3ull << 60);
+    for (int k = 0; k < TR_PER; k++)
+        if (x[k] != LIST_INVALID) dst[pre + wc[k * NWV + wave] + lo[k]] = x[k];
 }
 
 // ---- last column ---------------------------------------------------------------------------------
@@ -1149,10 +1499,10 @@ __global__ void __launch_bounds__(256) bwt_emit(Batch bt, uint32_t T, uint32_t B
         c[0] = s[i0 ? i0 - 1 : n - 1];
         for (uint32_t k = 1; k < m; k++) c[k] = s[i0 + k - 1];
         for (uint32_t k = 0; k < m; k++) {
-            out[r[k] & 0xFFFFFu] = c[k];
+            out[rank_final(r[k])] = c[k];
             seen[c[k]] = 1; // every byte of S appears exactly once in the last column
         }
-        if (i0 == 0) bt.ptr[b] = r[0] & 0xFFFFFu;
+        if (i0 == 0) bt.ptr[b] = rank_final(r[0]);
     }
     __syncthreads();
     if (seen[threadIdx.x]) bt.hasbyte[(size_t)b * 256 + threadIdx.x] = 1;
@@ -1165,11 +1515,12 @@ __global__ void __launch_bounds__(256) bwt_emit(Batch bt, uint32_t T, uint32_t B
 // path, and writes the summary the host reads one round late.
 // summary words: 0 round, 1 nS, 2 nA, 3 nT, 4 nQ, 5 maxS, 6 maxA, 7 maxT, 8/9 total unresolved (lo/hi),
 //                10/11 sum of the S lists, 12/13 sum of the A lists, 14 error flag, 15 largest depth in use,
-//                16 S blocks whose refine writes lists this round (the only ones that can leave SWEEP mode next round)
+//                16 S blocks whose refine writes lists this round (the only ones that can leave SWEEP mode next round),
+//                17/18 sum over the rounds so far of the unresolved suffixes entering them, 19 sequence word (last)
 constexpr uint32_t QUAD_BIT = 0x80000000u; // in st_ntail-derived gates: this round runs at depth x4
 enum ListId : int { L_S = 0, L_A = 1, L_R = 2, L_T = 3, L_Q = 4, L_P = 5 };
 
-__global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32_t round, uint32_t *actP)
+__global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32_t round, uint32_t *actP, uint32_t *hsum, uint32_t seq)
 {
     const uint32_t b = threadIdx.x;
     const bool valid = b < B;
@@ -1184,7 +1535,9 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
     uint32_t gS = 0, gA = 0, gT = 0, quad = 0, h = 0;
     if (valid) {
         const uint32_t n = bt.n[b];
-        uint32_t mode = bt.st_mode[b]; // round 0: what flag_carry of the initial refine decided
+        // Round 0: with fewer than one group per 8 suffixes after the 8-byte sort the block is run-heavy / periodic
+        // and starts in SWEEP mode; text-like blocks start in SPLIT mode and never pay for SA order by position.
+        uint32_t mode = round == 0 ? (((uint64_t)bt.c_groups[b] * 8u < n) ? 0u : 1u) : bt.st_mode[b];
         h = round == 0 ? 8u : bt.st_h[b]; // the initial sort ordered the rotations by their first 8 bytes
         const uint32_t nbig = bt.c_big[b], ntail = bt.c_tail[b] + bt.c_small[b];
         if (round > 0) {
@@ -1253,7 +1606,9 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < 6; k++) bt.nlist[k] = tot[k];
-        uint32_t *s = bt.summary;
+        const unsigned long long asum = *bt.stat_A + acc64[0]; // unresolved suffixes entering the rounds so far
+        *bt.stat_A = asum;
+        uint32_t *s = hsum; // pinned host memory
         s[0] = round;
         s[1] = tot[L_S];
         s[2] = tot[L_A];
@@ -1271,20 +1626,23 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
         s[14] = *bt.errflag;
         s[15] = accmax[3];
         s[16] = sconv;
-        *bt.stat_A += acc64[0];
+        s[17] = (uint32_t)asum;
+        s[18] = (uint32_t)(asum >> 32);
+        // the record is complete before its last word says so
+        __hip_atomic_store(s + SUMMARY_WORDS - 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
 // ---- host driver -----------------------------------------------------------------------------------
 // one radix pass = one kernel (look-back scatter)
-template <int BITS, int MODE, bool REKEY>
+template <int BITS, int MODE>
 static void launch_pass(bzh_ctx *ctx, SortArgs &a, uint32_t NB, uint32_t maxcnt)
 {
     const uint32_t tiles = (maxcnt + SORT_TILE - 1) / SORT_TILE;
     if (tiles == 0 || NB == 0) return;
     a.T = tiles | (NB < 32 ? WG_SPREAD : 0u);
     a.pass++;
-    radix_scatter<BITS, MODE, REKEY><<<dim3(xcd_grid(a.T, NB)), SORT_THREADS, 0, ctx->stream>>>(a);
+    radix_scatter<BITS, MODE><<<dim3(xcd_grid(a.T, NB)), SORT_THREADS, 0, ctx->stream>>>(a);
     if (ctx->profiling) ctx->stats.bwt_sort_launches++; // every launch issued, also the ones that find their list empty
 }
 
@@ -1352,15 +1710,64 @@ static void launch_refine(bzh_ctx *ctx, RefineArgs &r, uint32_t NB, uint32_t max
     if (bases) sweep_bases<<<dim3(NB), 768, 0, ctx->stream>>>(r, ctx->bt.dbase);
 }
 
-// Waits for an event the GPU has normally passed long ago (the summary of the round before the one being
-// queued): a few polls, then the blocking call.
-static hipError_t wait_event(hipEvent_t ev)
+// ---- initial ranks: binned by destination, then applied -------------------------------------------------------
+// A 4-byte store to a random slot of a block's 3.6 MB rank array leaves the XCD as a partial 64-byte write: the
+// 100 M stores of the initial refinement cost 6.4 GB of fabric writes.  Instead refine_one<init> leaves (rank word,
+// suffix) pairs in list order; one ordinary radix pass on suffix bits 12..19 gathers the pairs of every 4096-suffix
+// window of the rank array (the bins are full by construction, so the digit bases are known up front); rank_apply
+// places a window's words in LDS and stores them as whole lines.
+constexpr uint32_t APPLY_W = 4096;
+__global__ void __launch_bounds__(256) bin_bases(const uint32_t *nn, uint32_t *dbase)
 {
-    for (int it = 0; it < 64; it++) {
-        const hipError_t e = hipEventQuery(ev);
-        if (e != hipErrorNotReady) return e;
+    const uint32_t b = blockIdx.x, n = nn[b];
+    dbase[(size_t)b * DB_STRIDE + threadIdx.x] = min(n, threadIdx.x * APPLY_W);
+}
+
+__global__ void __launch_bounds__(256) rank_apply(const u64 *binned, const uint32_t *nn, uint32_t *rank, uint32_t S)
+{
+    const uint32_t b = blockIdx.y, n = nn[b];
+    const uint32_t w0 = blockIdx.x * APPLY_W;
+    if (w0 >= n) return;
+    const uint32_t cnt = min(APPLY_W, n - w0);
+    const size_t base = (size_t)b * S;
+    __shared__ uint32_t win[APPLY_W];
+    constexpr int PER = APPLY_W / 256;
+#pragma unroll
+    for (int k = 0; k < PER; k++) win[k * 256 + threadIdx.x] = 0xFFFFFFFFu; // (a last window may be short)
+    __syncthreads();
+    u64 v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const uint32_t e = k * 256 + threadIdx.x;
+        v[k] = e < cnt ? binned[base + w0 + e] : ~0ull;
     }
-    return hipEventSynchronize(ev);
+#pragma unroll
+    for (int k = 0; k < PER; k++)
+        if (v[k] != ~0ull) win[rslot((uint32_t)v[k] & (uint32_t)SUF_MASK) - w0] = (uint32_t)(v[k] >> 32); // rslot stays inside the aligned 1024-block
+    __syncthreads();
+    uint32_t *dst = rank + base + w0;
+#pragma unroll
+    for (int k = 0; k < PER / 4; k++) {
+        const uint32_t e = (k * 256 + threadIdx.x) * 4;
+        const uint4 q = *reinterpret_cast<const uint4 *>(&win[e]);
+        if (q.x != 0xFFFFFFFFu && q.y != 0xFFFFFFFFu && q.z != 0xFFFFFFFFu && q.w != 0xFFFFFFFFu) {
+            *reinterpret_cast<uint4 *>(dst + e) = q;
+        } else {
+            if (q.x != 0xFFFFFFFFu) dst[e] = q.x;
+            if (q.y != 0xFFFFFFFFu) dst[e + 1] = q.y;
+            if (q.z != 0xFFFFFFFFu) dst[e + 2] = q.z;
+            if (q.w != 0xFFFFFFFFu) dst[e + 3] = q.w;
+        }
+    }
+}
+
+template <bool INIT>
+static void launch_refine_one(bzh_ctx *ctx, RefineArgs &r, uint32_t NB, uint32_t maxcnt, u64 *recs = nullptr)
+{
+    const uint32_t tiles = (maxcnt + SORT_TILE - 1) / SORT_TILE;
+    if (tiles == 0 || NB == 0) return;
+    r.T = tiles | (NB < 32 ? WG_SPREAD : 0u);
+    refine_one<INIT><<<dim3(xcd_grid(r.T, NB)), SORT_THREADS, 0, ctx->stream>>>(r, ctx->bt.c_groups, recs);
 }
 
 // Suffix-sort and emit the last column for blocks 0..B-1 of the batch (bt.rle / bt.n filled).
@@ -1386,16 +1793,18 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     a.S = bt.S;
     a.TPB = bt.TPB;
 
-    // ---- initial sort on the 8-byte cyclic prefix: LSD, 8 passes of 8 bits.  Passes 0-3 order by
-    // bytes 4..7 of the rotation (the key field holds them), the scatter of pass 3 swaps in bytes 0..3,
-    // passes 4-7 order by those.  A plain pass over every suffix costs far less than a doubling round
-    // does per suffix, so this replaces "4-byte sort + refine + first doubling round".
+    // ---- initial sort on the 8-byte cyclic prefix: LSD, 8 passes of 8 bits.  Passes 0-4 order by bytes 3..7 of
+    // the rotation (the element carries all five); pass 5 finds each element's 5-byte group on the way in (the list
+    // is in that order), replaces the key by bytes 0..2 + the dense index of the group (one gather from the
+    // L2-resident text) and orders by byte 2; passes 6-7 order by bytes 1 and 0.  The refinement that follows
+    // compares whole elements.  A plain pass over every suffix costs far less than a doubling round does per
+    // suffix, so this replaces "4-byte sort + refine + first doubling round".
     // The passes run as single look-back kernels (no histogram / scan launches): their digit bases
     // are the block's byte counts.
     a.cnt = bt.n;
     a.lst = all;
-    a.shift = 32;
-    a.h = 4; // key offset for GEN_BYTES4
+    a.shift = 20;
+    a.gst = reinterpret_cast<u64 *>(bt.tagg); // (flag_tiles / flag_carry use it after the initial sort only)
     a.src = nullptr;
     a.dst = bufA;
     a.look = reinterpret_cast<u64 *>(bt.hist);
@@ -1405,7 +1814,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     a.pass = 0;
     HIP_TRY(ctx, hipMemsetAsync(bt.errflag, 0, sizeof(uint32_t), st));
     HIP_TRY(ctx, hipMemsetAsync(a.look, 0, (size_t)B * bt.TPB * NBMAX * sizeof(u64), st));
-    HIP_TRY(ctx, hipMemsetAsync(bt.alive, 0, (size_t)B * ((bt.S + FIN_T - 1) / FIN_T) * sizeof(u64), st));
+    HIP_TRY(ctx, hipMemsetAsync(bt.tagg, 0, (size_t)B * bt.TPB * sizeof(int4), st));
     HIP_TRY(ctx, hipMemsetAsync(bt.dtot, 0, (size_t)B * DB_STRIDE * sizeof(uint32_t), st));
     // round state: everything from st_mode to the 64-bit counter (one contiguous carve, see layout_batch)
     HIP_TRY(ctx, hipMemsetAsync(bt.st_mode, 0,
@@ -1413,16 +1822,16 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     byte_count<<<dim3(BYTE_SEGS, B), 1024, 0, st>>>(bt.rle, bt.n, bt.dtot, bt.S);
     active_bases<<<dim3(B), 256, 0, st>>>(bt.dtot, bt.dbase, all, 1);
     hipEvent_t ev_init = span_begin(ctx);
-    launch_pass<8, GEN_BYTES4, false>(ctx, a, B, nmax);
+    launch_pass<8, GEN_BYTES5>(ctx, a, B, nmax);
     u64 *cur = bufA, *oth = bufB;
     for (int p = 1; p < 8; p++) {
-        a.shift = 32 + 8 * (p & 3);
+        a.shift = p < 5 ? 20 + 8 * p : 40 + 8 * (p - 5);
         a.src = cur;
         a.dst = oth;
-        if (p == 3)
-            launch_pass<8, GEN_LIST, true>(ctx, a, B, nmax);
+        if (p == 5)
+            launch_pass<8, GEN_GID>(ctx, a, B, nmax);
         else
-            launch_pass<8, GEN_LIST, false>(ctx, a, B, nmax);
+            launch_pass<8, GEN_LIST>(ctx, a, B, nmax);
         u64 *t = cur;
         cur = oth;
         oth = t;
@@ -1457,7 +1866,25 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     r.cpass = ++a.pass;
     r.err = bt.errflag;
     r.lst = all;
-    launch_refine(ctx, r, B, nmax, true);
+    // lists of every block + (rank word, suffix) pairs in list order; the blocks that start in SWEEP mode get their
+    // SA order and digit bases in round 0 (below)
+    launch_refine_one<true>(ctx, r, B, nmax, bufD);
+    { // the pairs, binned by 4096-suffix window (into sa|headp, which nobody needs before round 0), become the ranks
+        u64 *binned = reinterpret_cast<u64 *>(bt.sa);
+        static_assert(sizeof(u64) == 2 * sizeof(uint32_t), "sa and headp together hold one 64-bit word per suffix");
+        bin_bases<<<dim3(B), 256, 0, st>>>(bt.n, bt.dbase);
+        a.cnt = bt.n;
+        a.lst = all;
+        a.shift = 12;
+        a.doff = 0;
+        a.src = bufD;
+        a.dst = binned;
+        hipEvent_t e0 = span_begin(ctx);
+        launch_pass<8, GEN_LIST>(ctx, a, B, nmax);
+        span_end(ctx, e0);
+        if (ctx->profiling) ctx->stats.bwt_sort_elems += ntotal;
+        rank_apply<<<dim3((nmax + APPLY_W - 1) / APPLY_W, B), 256, 0, st>>>(binned, bt.n, bt.rank, bt.S);
+    }
     { // the big lists of the first round are in `oth`
         u64 *t = cur;
         cur = oth;
@@ -1469,36 +1896,137 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     TailArgs ta{};
     ta.n = bt.n;
     ta.len = bt.st_ntail; // (gateT carries the QUAD bit; the plain length lives here)
-    ta.bufC = bufC;
-    ta.bufD = bufD;
+    ta.src = bufC; // the small-group lists move between bufC and bufD, one hop per round that has any
+    ta.dst = bufD;
     ta.rank = bt.rank;
     ta.c_tail = bt.c_tail;
     ta.c_prog = bt.c_prog;
     ta.err = bt.errflag;
-    ta.stat = reinterpret_cast<u64 *>(bt.alive);
     ta.hb = bt.st_h;
     ta.S = bt.S;
-    ta.FT = (bt.S + FIN_T - 1) / FIN_T; // <= 512 (S <= 2^20)
 
     // ---- doubling rounds, queued one ahead of the summaries ---------------------------------------------
-    uint32_t *hsum = ctx->h_pinned + (size_t)mb * 8 + 64; // [MAX_ROUNDS][SUMMARY_WORDS], pinned
-    std::vector<hipEvent_t> evs;
+    // round_begin writes its summary straight into pinned host memory and sets the record's last word to
+    // round + 1 behind a system-scope release: no copy, no event -- the host looks at the word.
+    // (The word also carries the number of this call: the round_begin queued last by the call before may still
+    // be on its way when this one starts.)
+    volatile uint32_t *hsum = ctx->h_pinned + (size_t)mb * 8 + 64; // [MAX_ROUNDS][SUMMARY_WORDS]
+    const uint32_t epoch = (++ctx->bwt_epoch & 0xFFFFFFu) << 6;
+    auto wait_summary = [&](uint32_t rd, uint32_t *out) -> hipError_t { // normally there already
+        volatile uint32_t *rec = hsum + (size_t)rd * SUMMARY_WORDS;
+        const uint32_t want = epoch + rd + 1u;
+        int idle = 0;
+        for (uint64_t it = 0; rec[SUMMARY_WORDS - 1] != want; it++) {
+            if ((it & 0xFFFu) == 0xFFFu) { // a kernel fault would leave us here for ever: ask the stream now and then
+                const hipError_t e = hipStreamQuery(st);
+                if (e != hipSuccess && e != hipErrorNotReady) return e;
+                if (e == hipSuccess && ++idle > 64) return hipErrorUnknown; // stream drained, still no record
+            }
+            __builtin_ia32_pause();
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        for (int k = 0; k < SUMMARY_WORDS; k++) out[k] = rec[k];
+        return hipSuccess;
+    };
     static const bool trace = getenv("BZH_TRACE_ROUNDS") != nullptr;
     // bounds for the launches of the round being queued (exact lists live on the device)
     uint32_t nS = B, nA = B, nT = B, nQ = B, maxS = nmax, maxA = nmax, maxT = nmax;
     uint32_t err = 0;
     bool finished = false;
+    uint32_t s[SUMMARY_WORDS];
+
+    // -- blocks in SWEEP mode: three look-back passes; the last refine left the digit bases (sweep_bases)
+    auto run_S = [&](uint32_t round) {
+        if (!nS) return;
+        if (round == 0) {
+            // round_begin has just picked the blocks that start in SWEEP mode: they need provisional SA entries,
+            // group heads by position and digit bases, which the one-kernel refinement does not produce -- the
+            // three-kernel refinement runs again over the sorted list of those blocks only (same ranks, same lists)
+            RefineArgs r0 = r;
+            r0.init = 1;
+            r0.cnt = bt.n;
+            r0.list = oth; // the sorted list (the big lists went to `cur`)
+            r0.big = cur;
+            r0.c_big = r0.c_small = r0.c_prog = bt.scratch; // consumed by round_begin already
+            r0.cpass = ++a.pass;
+            r0.lst = Lst{bt.actS, bt.nlist + L_S, B};
+            launch_refine(ctx, r0, nS, nmax, true);
+        }
+        a.lst = Lst{bt.actS, bt.nlist + L_S, B};
+        a.cnt = bt.n; // enumerate SA positions
+        a.shift = 40;
+        a.doff = 0;
+        a.src = nullptr;
+        a.dst = cur;
+        hipEvent_t e0 = span_begin(ctx);
+        launch_pass<7, GEN_SWEEP>(ctx, a, nS, nmax);
+        a.cnt = bt.gateS;
+        a.shift = 47;
+        a.doff = 128;
+        a.src = cur;
+        a.dst = oth;
+        launch_pass<7, GEN_LIST>(ctx, a, nS, maxS);
+        a.shift = 54;
+        a.doff = 256;
+        a.src = oth;
+        a.dst = cur;
+        launch_pass<7, GEN_LIST>(ctx, a, nS, maxS);
+        span_end(ctx, e0);
+    };
+    // -- SPLIT-mode blocks with large groups: re-key the big list once, then five look-back passes on bits
+    //    20..59; gen: cur -> oth, passes: oth -> cur -> oth -> cur -> oth -> cur
+    auto run_A = [&]() {
+        const uint32_t gt = (maxA + SORT_TILE - 1) / SORT_TILE;
+        if (!nA || !gt) return;
+        a.lst = Lst{bt.actA, bt.nlist + L_A, B};
+        a.cnt = bt.gateA;
+        a.src = cur;
+        a.dst = oth;
+        a.T = gt | (nA < 32 ? WG_SPREAD : 0u);
+        active_gen<<<dim3(xcd_grid(a.T, nA)), SORT_THREADS, 0, st>>>(a, bt.dtot);
+        active_bases<<<dim3(nA), 256, 0, st>>>(bt.dtot, bt.dbase, a.lst, 5);
+        u64 *c = oth, *o = cur;
+        hipEvent_t e0 = span_begin(ctx);
+        for (int p = 0; p < 5; p++) {
+            a.shift = 20 + 8 * p;
+            a.doff = 256 * p;
+            a.src = c;
+            a.dst = o;
+            launch_pass<8, GEN_LIST>(ctx, a, nA, maxA);
+            u64 *t = c;
+            c = o;
+            o = t;
+        }
+        span_end(ctx, e0);
+    };
+    // -- small groups: one kernel per form (depth x2 / depth x4); survivors move to the other list buffer
+    auto run_T = [&]() {
+        const uint32_t tt = (maxT + TR_T - 1) / TR_T;
+        if (!nT || !tt) return;
+        ta.T = tt | (nT < 32 ? WG_SPREAD : 0u);
+        ta.tag = a.tag;
+        ta.lst = Lst{actP, bt.nlist + L_P, B};
+        tail_round<false><<<dim3(xcd_grid(ta.T, nT)), TR_THREADS, 0, st>>>(ta);
+        if (nQ) {
+            ta.lst = Lst{bt.actQ, bt.nlist + L_Q, B};
+            tail_round<true><<<dim3(xcd_grid(ta.T, nQ)), TR_THREADS, 0, st>>>(ta);
+        }
+        r.tail = ta.dst; // refine appends this round's new small groups behind the survivors
+        std::swap(ta.src, ta.dst);
+    };
+    auto account = [&](const uint32_t *sm) { // statistics of the round a summary describes
+        if (!ctx->profiling) return;
+        if (sm[1]) ctx->stats.bwt_sort_elems += 3 * ((uint64_t)sm[10] | ((uint64_t)sm[11] << 32));
+        if (sm[2]) ctx->stats.bwt_sort_elems += 5 * ((uint64_t)sm[12] | ((uint64_t)sm[13] << 32));
+    };
+
     for (uint32_t round = 0; round < (uint32_t)MAX_ROUNDS; round++) {
-        round_begin<<<1, (B + 63u) / 64u * 64u, 0, st>>>(bt, B, round, actP);
-        HIP_TRY(ctx, hipMemcpyAsync(hsum + (size_t)round * SUMMARY_WORDS, bt.summary, SUMMARY_WORDS * sizeof(uint32_t),
-                                    hipMemcpyDeviceToHost, st));
-        hipEvent_t ev = bzh_event(ctx);
-        HIP_TRY(ctx, hipEventRecord(ev, st));
-        evs.push_back(ev);
-        if (round > 0) {
+        a.tag = 1u + round % 31u; // (a block is at work for fewer than 31 rounds: its depth doubles every time)
+        round_begin<<<1, (B + 63u) / 64u * 64u, 0, st>>>(bt, B, round, actP,
+                                                          const_cast<uint32_t *>(hsum) + (size_t)round * SUMMARY_WORDS, epoch + round + 1u);
+        if (round > 1) {
             // the summary of the PREVIOUS round: where every block stood when that round began
-            HIP_TRY(ctx, wait_event(evs[round - 1]));
-            const uint32_t *s = hsum + (size_t)(round - 1) * SUMMARY_WORDS;
+            HIP_TRY(ctx, wait_summary(round - 1, s));
             const uint64_t total = (uint64_t)s[8] | ((uint64_t)s[9] << 32);
             err |= s[14];
             if (trace)
@@ -1509,10 +2037,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
                 break;
             }
             ctx->stats.bwt_rounds = (uint64_t)round > ctx->stats.bwt_rounds ? (uint64_t)round : ctx->stats.bwt_rounds;
-            if (ctx->profiling) {
-                if (s[1]) ctx->stats.bwt_sort_elems += 3 * ((uint64_t)s[10] | ((uint64_t)s[11] << 32));
-                if (s[2]) ctx->stats.bwt_sort_elems += 5 * ((uint64_t)s[12] | ((uint64_t)s[13] << 32));
-            }
+            account(s);
             // One round on: SWEEP blocks can only leave; their unresolved suffixes may turn up in the big or the
             // small lists; big lists shrink, small lists gain at most what the big lists lose.
             // SWEEP blocks only leave that mode with lists in hand: cS of them wrote lists in the round before.
@@ -1525,85 +2050,73 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             nQ = nT;
             maxT = std::min(nmax, mT + std::max(mA, cS ? mS : 0u));
         }
-
-        // -- blocks in SWEEP mode: three look-back passes; the last refine left the digit bases (sweep_bases)
-        if (nS) {
-            a.lst = Lst{bt.actS, bt.nlist + L_S, B};
-            a.cnt = bt.n; // enumerate SA positions
-            a.shift = 40;
-            a.doff = 0;
-            a.src = nullptr;
-            a.dst = cur;
-            hipEvent_t e0 = span_begin(ctx);
-            launch_pass<7, GEN_SWEEP, false>(ctx, a, nS, nmax);
-            a.cnt = bt.gateS;
-            a.shift = 47;
-            a.doff = 128;
-            a.src = cur;
-            a.dst = oth;
-            launch_pass<7, GEN_LIST, false>(ctx, a, nS, maxS);
-            a.shift = 54;
-            a.doff = 256;
-            a.src = oth;
-            a.dst = cur;
-            launch_pass<7, GEN_LIST, false>(ctx, a, nS, maxS);
-            span_end(ctx, e0);
-        }
-        // -- SPLIT-mode blocks with large groups: re-key the big list once, then five look-back passes on bits
-        //    20..59; gen: cur -> oth, passes: oth -> cur -> oth -> cur -> oth -> cur
-        if (nA) {
-            a.lst = Lst{bt.actA, bt.nlist + L_A, B};
-            a.cnt = bt.gateA;
-            a.src = cur;
-            a.dst = oth;
-            const uint32_t gt = (maxA + SORT_TILE - 1) / SORT_TILE;
-            if (gt) {
-                a.T = gt | (nA < 32 ? WG_SPREAD : 0u);
-                active_gen<<<dim3(xcd_grid(a.T, nA)), SORT_THREADS, 0, st>>>(a, bt.dtot);
-                active_bases<<<dim3(nA), 256, 0, st>>>(bt.dtot, bt.dbase, a.lst, 5);
-                u64 *c = oth, *o = cur;
-                hipEvent_t e0 = span_begin(ctx);
-                for (int p = 0; p < 5; p++) {
-                    a.shift = 20 + 8 * p;
-                    a.doff = 256 * p;
-                    a.src = c;
-                    a.dst = o;
-                    launch_pass<8, GEN_LIST, false>(ctx, a, nA, maxA);
-                    u64 *t = c;
-                    c = o;
-                    o = t;
-                }
-                span_end(ctx, e0);
+        if (round == 0) {
+            // Nothing is known yet, and text-like batches have no block in SWEEP mode: the big-list and small-group
+            // paths go first with full-size launches (they take a millisecond), by then round 0's own summary is
+            // there and the SWEEP path runs with exact sizes -- or, mostly, not at all.
+            run_A();
+            run_T();
+            HIP_TRY(ctx, wait_summary(0, s));
+            const uint64_t total = (uint64_t)s[8] | ((uint64_t)s[9] << 32);
+            err |= s[14];
+            if (trace)
+                fprintf(stderr, "[bzhip] round %u h<=%u unresolved=%llu  S blocks=%u (max %u)  A blocks=%u (max %u)  T blocks=%u (quad %u, max %u)\n",
+                        s[0], s[15], (unsigned long long)total, s[1], s[5], s[2], s[6], s[3], s[4], s[7]);
+            if (total == 0) { // the initial sort resolved everything
+                finished = true;
+                break;
             }
-        }
-        // -- small groups
-        if (nT) {
-            const uint32_t tt = (maxT + TAIL_T - 1) / TAIL_T;
-            if (tt) {
-                ta.T = tt | (nT < 32 ? WG_SPREAD : 0u);
-                ta.lst = Lst{actP, bt.nlist + L_P, B};
-                tail_sort<false><<<dim3(xcd_grid(ta.T, nT)), TAIL_THREADS, 0, st>>>(ta);
-                if (nQ) {
-                    ta.lst = Lst{bt.actQ, bt.nlist + L_Q, B};
-                    tail_sort<true><<<dim3(xcd_grid(ta.T, nQ)), TAIL_THREADS, 0, st>>>(ta);
+            ctx->stats.bwt_rounds = std::max<uint64_t>(ctx->stats.bwt_rounds, 1);
+            account(s);
+            nS = s[1];
+            maxS = s[5];
+            run_S(0);
+            // exact figures of round 0 from here on (they also bound round 1, as above)
+            const uint32_t pA = s[2], pT = s[3], mA = s[6], mT = s[7], cS = s[16];
+            nA = pA;
+            maxA = mA;
+            if (nS | nA) {
+                r.list = cur;
+                r.big = oth;
+                if (nS) {
+                    r.cpass = ++a.pass;
+                    r.lst = Lst{bt.actS, bt.nlist + L_S, B};
+                    launch_refine(ctx, r, nS, maxS, true);
                 }
-                ta.lst = Lst{bt.actT, bt.nlist + L_T, B};
-                ta.pass = ++a.pass;
-                ta.T = ((maxT + FIN_T - 1) / FIN_T) | (nT < 32 ? WG_SPREAD : 0u);
-                tail_finish<<<dim3(xcd_grid(ta.T, nT)), 256, 0, st>>>(ta);
+                if (nA) {
+                    r.cpass = ++a.pass;
+                    r.lst = Lst{bt.actA, bt.nlist + L_A, B};
+                    launch_refine_one<false>(ctx, r, nA, maxA);
+                }
+                std::swap(cur, oth);
             }
+            // bounds of round 1
+            nA = std::min(B, pA + cS);
+            maxA = std::max(mA, cS ? maxS : 0u);
+            nT = std::min(B, pT + pA + cS);
+            nQ = nT;
+            maxT = std::min(nmax, mT + std::max(mA, cS ? maxS : 0u));
+            continue;
         }
-        // -- every block that went through radix passes: flags, group extents, ranks, routing
-        const uint32_t nR = std::min(B, nS + nA), maxR = std::max(maxS, maxA);
-        if (nR) {
+        run_S(round);
+        run_A();
+        run_T();
+        // -- every block that went through radix passes: flags, group extents, ranks, routing (SWEEP-mode blocks in
+        //    three kernels with SA order and digit counts, the big lists of SPLIT-mode blocks in one)
+        if (nS | nA) {
             r.list = cur;
             r.big = oth;
-            r.cpass = ++a.pass;
-            r.lst = Lst{bt.actR, bt.nlist + L_R, B};
-            launch_refine(ctx, r, nR, maxR, nS != 0);
-            u64 *t = cur;
-            cur = oth;
-            oth = t;
+            if (nS) {
+                r.cpass = ++a.pass;
+                r.lst = Lst{bt.actS, bt.nlist + L_S, B};
+                launch_refine(ctx, r, nS, maxS, true);
+            }
+            if (nA) {
+                r.cpass = ++a.pass;
+                r.lst = Lst{bt.actA, bt.nlist + L_A, B};
+                launch_refine_one<false>(ctx, r, nA, maxA);
+            }
+            std::swap(cur, oth);
         }
     }
     if (!finished) { // MAX_ROUNDS is far beyond log2(n) + the rounds queued ahead
@@ -1611,15 +2124,9 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         bzh_set_error(ctx, "BWT: the doubling rounds did not terminate (internal error)");
         return BZH_E_HIP;
     }
-    {
-        unsigned long long asum = 0;
-        uint32_t e2 = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&asum, bt.stat_A, sizeof asum, hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipMemcpyAsync(&e2, bt.errflag, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, bzh_stream_wait(st));
-        ctx->stats.bwt_active_sum += asum;
-        err |= e2;
-    }
+    // (the last summary read is the one of a round that found nothing to do: every kernel before it has run, so
+    // its error word and its sum of unresolved suffixes are final)
+    ctx->stats.bwt_active_sum += (uint64_t)s[17] | ((uint64_t)s[18] << 32);
     if (err) {
         bzh_set_error(ctx, err & 2 ? "BWT: a look-back gave up waiting (internal error)"
                                    : "BWT: a small-group window saw a group larger than its guarantee (internal error)");
@@ -1727,7 +2234,7 @@ int unbwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax)
     HIP_TRY(ctx, hipMemsetAsync(bt.dtot, 0, (size_t)B * DB_STRIDE * sizeof(uint32_t), st));
     byte_count<<<dim3(BYTE_SEGS, B), 1024, 0, st>>>(bt.bwt, bt.n, bt.dtot, bt.S);
     active_bases<<<dim3(B), 256, 0, st>>>(bt.dtot, bt.dbase, all, 1);
-    launch_pass<8, GEN_LCOL, false>(ctx, a, B, nmax);
+    launch_pass<8, GEN_LCOL>(ctx, a, B, nmax);
     UnbwtArgs u{};
     u.L = bt.bwt;
     u.n = bt.n;

@@ -54,7 +54,7 @@ constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS; // 8192 elements per workgr
                                                      // scan overhead per element against 256 x 16, -7 % on the bench)
 constexpr uint32_t RANK_RESOLVED = 0x80000000u;      // suffix is alone in its group
 constexpr int SUMMARY_WORDS = 20; // round summary: see round_begin (bwt.hip)
-constexpr int MAX_ROUNDS = 64;
+constexpr int MAX_ROUNDS = 30; // depth 8 doubles every round and ends at 2^20; < 31 keeps the rank words' round tags unique
 
 struct BlockDesc { // device-side description of one planned block (mirrors bzh_block + restart info)
     uint64_t in_off;
@@ -96,13 +96,14 @@ struct Batch {
     uint32_t *st_ntail; // records in the small-group list
     uint32_t *c_big, *c_small, *c_tail, *c_prog; // produced by a round: list lengths, "some group was refined"
     uint32_t *c_nolist; // produced by a round: refine did not write the block's lists (SWEEP mode, mostly large groups)
+    uint32_t *c_groups; // groups of the block after the initial sort (refine_one<init>; round_begin picks the first mode)
+    uint32_t *scratch;  // a row nobody reads
     uint32_t *gateS, *gateA, *gateR, *gateT;     // this round: sorted-list length per path (0 = not on that path)
     uint32_t *actS, *actA, *actR, *actT, *actQ;  // this round: ids of the blocks on each path (Q: TAIL at depth x4)
     uint32_t *nlist;    // [8] lengths of those lists (S, A, R, T, Q)
     uint32_t *summary;  // [SUMMARY_WORDS] what the host reads, one round late
     unsigned long long *stat_A; // [1] sum over rounds of the unresolved suffixes entering them
     uint32_t *errflag; // [1]
-    uint32_t *alive;   // [B][S/2048] x 64 bit: status words of tail_finish's look-back
     // MTF / RLE2
     uint8_t *mtfpos;   // [B][S]   MTF position of every BWT byte
     uint8_t *tilelist; // [B][MT][256] recency list at each MTF tile entry
@@ -214,6 +215,7 @@ struct bzh_ctx {
         size_t h_out_cap = 0;
     } strm;
     bzh_stats stats{};
+    uint32_t bwt_epoch = 0;           // calls of bwt_run so far (tags the round summaries in pinned memory)
     std::vector<hipEvent_t> evpool;
     size_t evnext = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> sort_spans;
