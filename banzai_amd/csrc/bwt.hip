@@ -1213,7 +1213,7 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
                 const uint32_t word = single ? (head | RANK_RESOLVED) : head;
                 if (INIT)
                     lds[slot_of(e0 + k)] = ((u64)word << 32) | i; // every suffix gets a rank: binned, then applied (rank_apply)
-                else if (single || head != oldr)
+                else if (head != oldr) // (see tail_round: a SPLIT-mode block's "resolved" bits have no reader)
                     rank[rslot(i)] = word;
                 if (!single && !((foreign >> k) & 1u)) outv[k] = ((u64)c << 62) | ((u64)head << 40) | i;
             }
@@ -1418,9 +1418,11 @@ __global__ void __launch_bounds__(TR_THREADS) tail_round(TailArgs a)
             const bool single = eq == 1u;
             if (owned) {
                 moved |= less != 0u;
-                // (the last column is emitted from the ranks, so nothing but the rank word is stored per suffix;
-                // an unchanged rank that stays unresolved needs no store at all)
-                if (single || less) rank[rslot(ci[k])] = rank_word(cr[k], less, tag, single);
+                // The last column is emitted from the ranks, so nothing but the rank word is stored per suffix, and
+                // only if the rank moved: nobody reads the "resolved" bit of a block in SPLIT mode (the SA-order
+                // enumeration of SWEEP mode is its one reader), and a random 4-byte store is the most expensive
+                // thing this kernel does (it leaves the XCD as a partial 64-byte write).
+                if (less) rank[rslot(ci[k])] = rank_word(cr[k], less, tag, single);
             }
             res[k] = (owned ? 0x80000000u : 0u) | (single ? 0x40000000u : 0u) | (less << 24) | (g + less + eqb);
         }
