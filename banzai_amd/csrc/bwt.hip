@@ -1526,39 +1526,33 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
 {
     const uint32_t b = threadIdx.x;
     const bool valid = b < B;
-    __shared__ uint32_t ls[1024 / 64 + 2];
-    __shared__ unsigned long long acc64[3], ntot;
-    __shared__ uint32_t accmax[4], sconv;
-    if (threadIdx.x < 3) acc64[threadIdx.x] = 0;
-    if (threadIdx.x < 4) accmax[threadIdx.x] = 0;
-    if (threadIdx.x == 0) sconv = 0;
-    if (threadIdx.x == 0) ntot = 0;
-    __syncthreads();
-    uint32_t gS = 0, gA = 0, gT = 0, quad = 0, h = 0;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    // per-wavefront partial results: sums (all, S, A, n, sconv), maxima (S, A, T, depth), list counts
+    __shared__ uint32_t psum[5][16], pmax[4][16], pcnt[6][16];
+    uint32_t gS = 0, gA = 0, gT = 0, h = 0, n = 0, conv = 0;
     if (valid) {
-        const uint32_t n = bt.n[b];
+        // everything this thread needs, loaded at once
+        n = bt.n[b];
+        const uint32_t groups = bt.c_groups[b], mode_in = bt.st_mode[b], h_in = bt.st_h[b];
+        const uint32_t nbig = bt.c_big[b], ntail = bt.c_tail[b] + bt.c_small[b];
+        const uint32_t gR = bt.gateR[b], gTin = bt.gateT[b], prog = bt.c_prog[b], nolist = bt.c_nolist[b];
         // Round 0: with fewer than one group per 8 suffixes after the 8-byte sort the block is run-heavy / periodic
         // and starts in SWEEP mode; text-like blocks start in SPLIT mode and never pay for SA order by position.
-        uint32_t mode = round == 0 ? (((uint64_t)bt.c_groups[b] * 8u < n) ? 0u : 1u) : bt.st_mode[b];
-        h = round == 0 ? 8u : bt.st_h[b]; // the initial sort ordered the rotations by their first 8 bytes
-        const uint32_t nbig = bt.c_big[b], ntail = bt.c_tail[b] + bt.c_small[b];
-        if (round > 0) {
-            const bool hadwork = bt.gateR[b] | bt.gateT[b];
-            const bool wasquad = (bt.gateT[b] & QUAD_BIT) != 0;
-            if (hadwork) {
-                if (!bt.c_prog[b] && h < n)
-                    h = H_DONE; // nothing was refined: equal ranks at depth h are equal at every depth (block = w^k)
-                else if (h < H_DONE)
-                    h = (h << (wasquad ? 2 : 1)) > H_DONE ? H_DONE : (h << (wasquad ? 2 : 1));
-            }
+        uint32_t mode = round == 0 ? (((uint64_t)groups * 8u < n) ? 0u : 1u) : mode_in;
+        h = round == 0 ? 8u : h_in; // the initial sort ordered the rotations by their first 8 bytes
+        if (round > 0 && (gR | gTin)) { // the block had work in the round before
+            const bool wasquad = (gTin & QUAD_BIT) != 0;
+            if (!prog && h < n)
+                h = H_DONE; // nothing was refined: equal ranks at depth h are equal at every depth (block = w^k)
+            else if (h < H_DONE)
+                h = (h << (wasquad ? 2 : 1)) > H_DONE ? H_DONE : (h << (wasquad ? 2 : 1));
         }
         // SWEEP mode pays a sweep of all n positions + 3 passes, the big-list path ~6 passes over the large
         // groups only: leave SWEEP mode, for good, once those hold less than a third of the block
-        if (mode == 0u && (uint64_t)nbig * 3u < n && !bt.c_nolist[b]) mode = 1u;
-        const uint32_t unres = nbig + ntail;
+        if (mode == 0u && (uint64_t)nbig * 3u < n && !nolist) mode = 1u;
         if (mode == 0u) {
-            gS = unres;
-            if (gS && (uint64_t)nbig * 2u < n) atomicAdd(&sconv, 1u); // (refine's `nolist` rule, negated)
+            gS = nbig + ntail;
+            conv = (gS && (uint64_t)nbig * 2u < n) ? 1u : 0u; // (refine's `nolist` rule, negated)
         } else {
             gA = nbig;
             gT = ntail;
@@ -1575,63 +1569,74 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
         bt.c_tail[b] = 0;
         bt.c_prog[b] = 0;
         bt.c_nolist[b] = 0;
-        atomicAdd(&acc64[0], (unsigned long long)(gS + gA + gT));
-        atomicAdd(&acc64[1], (unsigned long long)gS);
-        atomicAdd(&acc64[2], (unsigned long long)gA);
-        atomicAdd(&ntot, (unsigned long long)n);
+    }
+    { // (every sum stays below 2^30: at most 1024 blocks of fewer than 2^20 suffixes)
+        const uint32_t v[5] = {gS + gA + gT, gS, gA, n, conv};
+        const uint32_t m[4] = {gS, gA, gT, (gS | gA | gT) ? h : 0u};
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const uint32_t r = wave_reduce_add(v[k]);
+            if (lane == 0) psum[k][wave] = r;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t r = m[k];
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) r = max(r, (uint32_t)__shfl_xor((int)r, d, 64));
+            if (lane == 0) pmax[k][wave] = r;
+        }
     }
     __syncthreads();
-    if (valid) {
-        // a block with small groups only may look three h-blocks ahead (depth 4h, three gathers per suffix):
-        // worth it once few suffixes are left -- in the block, or in the whole batch -- when rounds are latency-bound
-        const uint32_t n = bt.n[b];
-        const bool few = (uint64_t)gT * 10u < n || acc64[0] * 10ull < ntot;
-        quad = (gA == 0u && gT != 0u && few && h < (1u << 28)) ? 1u : 0u;
-        bt.gateT[b] = gT | (quad ? QUAD_BIT : 0u);
+    uint32_t sum[5] = {0, 0, 0, 0, 0}, mx[4] = {0, 0, 0, 0};
+    for (uint32_t w = 0; w < nw; w++) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) sum[k] += psum[k][w];
+#pragma unroll
+        for (int k = 0; k < 4; k++) mx[k] = max(mx[k], pmax[k][w]);
     }
-    // order-preserving lists
-    uint32_t tot[6];
-    const uint32_t fl[6] = {gS != 0u, gA != 0u, (gS | gA) != 0u, gT != 0u, (gT != 0u && quad) ? 1u : 0u, (gT != 0u && !quad) ? 1u : 0u};
+    // a block with small groups only may look three h-blocks ahead (depth 4h, three gathers per suffix):
+    // worth it once few suffixes are left -- in the block, or in the whole batch -- when rounds are latency-bound
+    const bool few = (uint64_t)gT * 10u < n || (uint64_t)sum[0] * 10ull < sum[3];
+    const uint32_t quad = (valid && gA == 0u && gT != 0u && few && h < (1u << 28)) ? 1u : 0u;
+    if (valid) bt.gateT[b] = gT | (quad ? QUAD_BIT : 0u);
+    // order-preserving lists: position = listed blocks in lower lanes + in earlier wavefronts
+    const bool fl[6] = {gS != 0u, gA != 0u, (gS | gA) != 0u, gT != 0u, gT != 0u && quad, gT != 0u && !quad};
     uint32_t *dst[6] = {bt.actS, bt.actA, bt.actR, bt.actT, bt.actQ, actP};
+    uint32_t pre[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
-        const uint32_t off = block_excl_add(fl[k], ls, &tot[k]);
-        if (fl[k]) dst[k][off] = b;
-    }
-    if (valid) {
-        atomicMax(&accmax[0], gS);
-        atomicMax(&accmax[1], gA);
-        atomicMax(&accmax[2], gT);
-        if (gS | gA | gT) atomicMax(&accmax[3], h);
+        const u64 m = __ballot(fl[k]);
+        pre[k] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (lane == 0) pcnt[k][wave] = (uint32_t)__popcll(m);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    uint32_t tot[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) bt.nlist[k] = tot[k];
-        const unsigned long long asum = *bt.stat_A + acc64[0]; // unresolved suffixes entering the rounds so far
-        *bt.stat_A = asum;
-        uint32_t *s = hsum; // pinned host memory
-        s[0] = round;
-        s[1] = tot[L_S];
-        s[2] = tot[L_A];
-        s[3] = tot[L_T];
-        s[4] = tot[L_Q];
-        s[5] = accmax[0];
-        s[6] = accmax[1];
-        s[7] = accmax[2];
-        s[8] = (uint32_t)acc64[0];
-        s[9] = (uint32_t)(acc64[0] >> 32);
-        s[10] = (uint32_t)acc64[1];
-        s[11] = (uint32_t)(acc64[1] >> 32);
-        s[12] = (uint32_t)acc64[2];
-        s[13] = (uint32_t)(acc64[2] >> 32);
-        s[14] = *bt.errflag;
-        s[15] = accmax[3];
-        s[16] = sconv;
-        s[17] = (uint32_t)asum;
-        s[18] = (uint32_t)(asum >> 32);
-        // the record is complete before its last word says so
-        __hip_atomic_store(s + SUMMARY_WORDS - 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int k = 0; k < 6; k++) {
+        uint32_t off = 0, t = 0;
+        for (uint32_t w = 0; w < nw; w++) {
+            const uint32_t c = pcnt[k][w];
+            if (w < wave) off += c;
+            t += c;
+        }
+        tot[k] = t;
+        if (fl[k]) dst[k][off + pre[k]] = b;
+    }
+    if (wave == 0) { // the summary, one word per lane, straight into pinned host memory
+        const unsigned long long asum = *bt.stat_A + sum[0]; // unresolved suffixes entering the rounds so far
+        const uint32_t words[SUMMARY_WORDS] = {round,  tot[L_S], tot[L_A], tot[L_T], tot[L_Q], mx[0],  mx[1], mx[2], sum[0], 0u,
+                                               sum[1], 0u,       sum[2],   0u,       *bt.errflag, mx[3], sum[4], (uint32_t)asum,
+                                               (uint32_t)(asum >> 32), 0u};
+        uint32_t mine = 0;
+#pragma unroll
+        for (int k = 0; k < SUMMARY_WORDS - 1; k++) mine = lane == (uint32_t)k ? words[k] : mine;
+        if (lane < (uint32_t)SUMMARY_WORDS - 1) hsum[lane] = mine;
+        if (lane < 6) bt.nlist[lane] = lane == 0 ? tot[0] : lane == 1 ? tot[1] : lane == 2 ? tot[2] : lane == 3 ? tot[3] : lane == 4 ? tot[4] : tot[5];
+        if (lane == 0) {
+            *bt.stat_A = asum;
+            // the record is complete before its last word says so
+            __hip_atomic_store(hsum + SUMMARY_WORDS - 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
