@@ -168,6 +168,7 @@ struct bzh_ctx {
     uint32_t wgflag = 0;                // WG_SPREAD for the launches of the current group when few blocks are active
     std::vector<bzh_block> plan_blocks;
     std::vector<uint8_t> plan_open;     // per block: 1 = cut not final unless the input ends here
+    std::vector<uint8_t> plan_host;     // host copy of the plan's device records (scratch of rle1_plan)
     std::vector<uint8_t> plan_crc_ok;   // per block: CRC computed (bzh_plan_device_nocrc leaves them to the encoder)
     void *plan_ws = nullptr;            // device scratch of the plan (run tables)
     size_t plan_ws_size = 0;

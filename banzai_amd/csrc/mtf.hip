@@ -61,12 +61,16 @@ __global__ void __launch_bounds__(256) mtf_tile_last(Batch bt, int32_t *tlast, u
     const uint32_t p0 = tile * MTF_TILE + threadIdx.x * 8;
     if (p0 < n) {
         uint2 w = *reinterpret_cast<const uint2 *>(s + p0);
+        // only the last byte of a run inside my 8 bytes can be its symbol's last occurrence among them (after a
+        // BWT most bytes repeat their neighbour, and equal symbols from one wavefront queue on one LDS word)
+        const uint64_t w64 = ((uint64_t)w.y << 32) | w.x;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             uint32_t p = p0 + k;
             if (p < n) {
-                uint32_t c = ((k < 4 ? w.x : w.y) >> ((k & 3) * 8)) & 255u;
-                atomicMax(&last[names[c]], (int)p);
+                const uint32_t c = (uint32_t)(w64 >> (8 * k)) & 255u;
+                const bool more = k < 7 && p + 1 < n && ((uint32_t)(w64 >> (8 * (k + 1))) & 255u) == c;
+                if (!more) atomicMax(&last[names[c]], (int)p);
             }
         }
     }

@@ -522,13 +522,15 @@ __device__ __forceinline__ uint32_t gf_pow_x(const CrcTables &ct, uint64_t e, ui
     return f;
 }
 
+// Workgroup x of block y takes the block's tiles x, x + gridDim.x, ...; `nbp` (optional) = number of valid blocks
+// on the device (the plan launches this before the host knows how many blocks the split found).
 __global__ void __launch_bounds__(RL_THREADS) crc_tiles(const uint8_t *in, const BlockDesc *blocks, uint32_t *acc,
-                                                         const CrcTables *ctp)
+                                                         const CrcTables *ctp, const uint32_t *nbp)
 {
     const uint32_t b = blockIdx.y;
+    if (nbp && b >= *nbp) return;
     const BlockDesc d = blocks[b];
-    const uint64_t t0 = (uint64_t)blockIdx.x * CRC_TILE;
-    if (t0 >= d.in_len) return;
+    if ((uint64_t)blockIdx.x * CRC_TILE >= d.in_len) return;
     const CrcTables &ct = *ctp;
     __shared__ uint32_t tab[256];
     {
@@ -539,6 +541,8 @@ __global__ void __launch_bounds__(RL_THREADS) crc_tiles(const uint8_t *in, const
     }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
+    __shared__ uint32_t wred[RL_THREADS / 64];
+    for (uint64_t t0 = (uint64_t)blockIdx.x * CRC_TILE; t0 < d.in_len; t0 += (uint64_t)gridDim.x * CRC_TILE) {
     const uint32_t tile_len = d.in_len - t0 < CRC_TILE ? (uint32_t)(d.in_len - t0) : CRC_TILE;
     // pieces: a ragged first piece of r bytes (if any), then full 32-byte pieces, so that the bytes
     // after every piece are a multiple of 32
@@ -559,7 +563,6 @@ __global__ void __launch_bounds__(RL_THREADS) crc_tiles(const uint8_t *in, const
     }
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) crc ^= __shfl_xor(crc, s, 64);
-    __shared__ uint32_t wred[RL_THREADS / 64];
     if (lane == 0) wred[threadIdx.x >> 6] = crc;
     __syncthreads();
     if (threadIdx.x < 64) {
@@ -569,13 +572,15 @@ __global__ void __launch_bounds__(RL_THREADS) crc_tiles(const uint8_t *in, const
         const uint32_t pw = gf_pow_x(ct, 8ull * after_tile, lane);
         if (lane == 0) atomicXor(&acc[b], gf_mul(c, pw));
     }
+    __syncthreads(); // wred is reused by the next tile
+    }
 }
 
 __global__ void __launch_bounds__(64) crc_finish(BlockDesc *blocks, const uint32_t *acc, uint32_t nb,
-                                                  const CrcTables *ctp)
+                                                  const CrcTables *ctp, const uint32_t *nbp)
 {
     const uint32_t b = blockIdx.x;
-    if (b >= nb) return;
+    if (b >= (nbp ? *nbp : nb)) return;
     const CrcTables &ct = *ctp;
     const uint32_t pw = gf_pow_x(ct, 8ull * blocks[b].in_len, threadIdx.x);
     if (threadIdx.x == 0) blocks[b].crc = acc[b] ^ gf_mul(0xFFFFFFFFu, pw) ^ 0xFFFFFFFFu;
@@ -837,33 +842,43 @@ int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n, bool with_crc)
     plan_granules<<<dim3(pa.ntiles), RL_THREADS, 0, st>>>(pa);
     plan_tc<<<dim3(1), 1024, 0, st>>>(pa);
     plan_split<<<dim3(1), 64, 0, st>>>(pa);
-    uint32_t nb = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&nb, pa.nblocks, 4, hipMemcpyDeviceToHost, st));
+    // The block CRCs are queued right behind the split, over as many blocks as there could be (the kernels read the
+    // count on the device), and everything the host needs -- count, descriptors with their CRCs, cut status -- comes
+    // back in ONE copy: the plan costs the host one wait.
+    const CrcTables *ct = nullptr;
+    if (with_crc) {
+        BZH_TRY(crc_tables(ctx, &ct));
+        HIP_TRY(ctx, hipMemsetAsync(w.crcacc, 0, (size_t)pa.maxblocks * 4, st));
+        for (uint32_t k0 = 0; k0 < pa.maxblocks; k0 += 32768) { // grid.y limit
+            const uint32_t cnt = pa.maxblocks - k0 < 32768 ? pa.maxblocks - k0 : 32768;
+            crc_tiles<<<dim3(128, cnt), RL_THREADS, 0, st>>>(d_in, pa.blocks + k0, w.crcacc + k0, ct, pa.nblocks);
+        }
+        crc_finish<<<dim3(pa.maxblocks), 64, 0, st>>>(pa.blocks, w.crcacc, 0, ct, pa.nblocks);
+    }
+    // blocks | aux | nblocks are consecutive in the workspace (plan_layout)
+    const size_t span = (size_t)((const uint8_t *)pa.nblocks - (const uint8_t *)pa.blocks) + 4;
+    ctx->plan_host.resize(span);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->plan_host.data(), pa.blocks, span, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, bzh_stream_wait(st));
+    HIP_TRY(ctx, hipGetLastError());
+    uint32_t nb = 0;
+    memcpy(&nb, ctx->plan_host.data() + span - 4, 4);
     if (nb == 0 || nb == 0xFFFFFFFFu || nb > pa.maxblocks) {
         bzh_set_error(ctx, "block split failed (nb=%u)", nb);
         return BZH_E_HIP;
     }
-    std::vector<BlockDesc> hb(nb);
-    HIP_TRY(ctx, hipMemcpyAsync(hb.data(), pa.blocks, nb * sizeof(BlockDesc), hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, bzh_stream_wait(st));
-    HIP_TRY(ctx, hipGetLastError());
-    {
-        std::vector<BlockAux> hax(nb);
-        HIP_TRY(ctx, hipMemcpyAsync(hax.data(), pa.aux, nb * sizeof(BlockAux), hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, bzh_stream_wait(st));
-        ctx->plan_open.resize(nb);
-        for (uint32_t b = 0; b < nb; b++) ctx->plan_open[b] = (uint8_t)hax[b].open;
-    }
+    const BlockDesc *hb = reinterpret_cast<const BlockDesc *>(ctx->plan_host.data());
+    const BlockAux *hax = reinterpret_cast<const BlockAux *>(ctx->plan_host.data() + ((const uint8_t *)pa.aux - (const uint8_t *)pa.blocks));
+    ctx->plan_open.resize(nb);
     ctx->plan_blocks.resize(nb);
     for (uint32_t b = 0; b < nb; b++) {
+        ctx->plan_open[b] = (uint8_t)hax[b].open;
         ctx->plan_blocks[b].in_off = hb[b].in_off;
         ctx->plan_blocks[b].in_len = hb[b].in_len;
         ctx->plan_blocks[b].rle_len = hb[b].rle_len;
-        ctx->plan_blocks[b].crc = 0;
+        ctx->plan_blocks[b].crc = with_crc ? hb[b].crc : 0;
     }
-    ctx->plan_crc_ok.assign(nb, 0);
-    if (with_crc) BZH_TRY(rle1_plan_crc(ctx, 0, nb));
+    ctx->plan_crc_ok.assign(nb, with_crc ? 1 : 0);
     return BZH_OK;
 }
 
@@ -887,9 +902,9 @@ int rle1_plan_crc(bzh_ctx *ctx, size_t b0, size_t b1)
     const uint32_t ctiles = (uint32_t)((maxlen + CRC_TILE - 1) / CRC_TILE);
     for (uint32_t k0 = 0; k0 < nb; k0 += 32768) { // grid.y limit
         const uint32_t cnt = nb - k0 < 32768 ? nb - k0 : 32768;
-        crc_tiles<<<dim3(ctiles, cnt), RL_THREADS, 0, st>>>(ctx->plan_in, pa.blocks + b0 + k0, w.crcacc + b0 + k0, ct);
+        crc_tiles<<<dim3(ctiles, cnt), RL_THREADS, 0, st>>>(ctx->plan_in, pa.blocks + b0 + k0, w.crcacc + b0 + k0, ct, nullptr);
     }
-    crc_finish<<<dim3(nb), 64, 0, st>>>(pa.blocks + b0, w.crcacc + b0, nb, ct);
+    crc_finish<<<dim3(nb), 64, 0, st>>>(pa.blocks + b0, w.crcacc + b0, nb, ct, nullptr);
     std::vector<BlockDesc> hb(nb);
     HIP_TRY(ctx, hipMemcpyAsync(hb.data(), pa.blocks + b0, nb * sizeof(BlockDesc), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, bzh_stream_wait(st));
@@ -937,8 +952,8 @@ int crc_device(bzh_ctx *ctx, const uint8_t *d_in, size_t n, uint32_t *crc_out)
     HIP_TRY(ctx, hipMemcpyAsync(dd, &d, sizeof d, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemsetAsync(acc, 0, 4, st));
     const uint32_t ctiles = (uint32_t)((n + CRC_TILE - 1) / CRC_TILE);
-    if (ctiles) crc_tiles<<<dim3(ctiles, 1), RL_THREADS, 0, st>>>(d_in, dd, acc, ct);
-    crc_finish<<<dim3(1), 64, 0, st>>>(dd, acc, 1, ct);
+    if (ctiles) crc_tiles<<<dim3(ctiles, 1), RL_THREADS, 0, st>>>(d_in, dd, acc, ct, nullptr);
+    crc_finish<<<dim3(1), 64, 0, st>>>(dd, acc, 1, ct, nullptr);
     HIP_TRY(ctx, hipMemcpyAsync(&d, dd, sizeof d, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, bzh_stream_wait(st));
     *crc_out = d.crc;
