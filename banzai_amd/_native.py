@@ -44,6 +44,11 @@ class Stats(ctypes.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "pad"}
 
 
+class KStat(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 48), ("ms", ctypes.c_double), ("launches", ctypes.c_uint64),
+                ("alg_bytes", ctypes.c_uint64)]
+
+
 # name -> (restype, argtypes); also the list the symbol-export test checks against include/bzhip.h
 SIGNATURES = {
     "bzh_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int]),
@@ -56,6 +61,7 @@ SIGNATURES = {
     "bzh_set_lanes": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "bzh_set_mode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "bzh_get_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Stats)]),
+    "bzh_get_kernel_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(KStat), ctypes.c_size_t, szp]),
     "bzh_encode": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_size_t, u8p, ctypes.c_size_t, szp, szp]),
     "bzh_encode_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                                          ctypes.c_size_t, szp, szp]),
@@ -174,6 +180,14 @@ class Context:
         s = Stats()
         self.check(lib().bzh_get_stats(self._h, ctypes.byref(s)))
         return s.as_dict()
+
+    def kernel_stats(self):
+        """Per-kernel-class (name, ms, launches, algorithmic bytes) of the last call made with profiling on."""
+        arr = (KStat * 64)()
+        cnt = ctypes.c_size_t(0)
+        self.check(lib().bzh_get_kernel_stats(self._h, arr, 64, ctypes.byref(cnt)))
+        return [{"name": arr[k].name.decode(), "ms": arr[k].ms, "launches": int(arr[k].launches),
+                 "alg_bytes": int(arr[k].alg_bytes)} for k in range(cnt.value)]
 
     # ---- stage seams (host numpy in / out) ----
     def bwt(self, data):

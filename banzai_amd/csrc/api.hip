@@ -294,15 +294,55 @@ extern "C" int bzh_get_stats(const bzh_ctx *ctx, bzh_stats *out)
     });
 }
 
+static void kstats_reset(bzh_ctx *ctx);
 static void stats_begin(bzh_ctx *ctx)
 {
     memset(&ctx->stats, 0, sizeof ctx->stats);
     ctx->evnext = 0;
     ctx->sort_spans.clear();
+    kstats_reset(ctx);
+}
+
+static void kstats_reset(bzh_ctx *ctx)
+{
+    ctx->kspans.clear();
+    for (int k = 0; k < K_COUNT; k++) {
+        ctx->k_ms[k] = 0;
+        ctx->k_bytes[k] = 0;
+        ctx->k_launch[k] = 0;
+    }
+}
+
+// Event pairs -> milliseconds per kernel class (the stream has been waited for).
+static void kstats_collect(bzh_ctx *ctx)
+{
+    for (auto &r : ctx->kspans) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) ctx->k_ms[r.cls] += t;
+    }
+    ctx->kspans.clear();
+}
+
+extern "C" int bzh_get_kernel_stats(const bzh_ctx *ctx, bzh_kstat *out, size_t max, size_t *count)
+{
+    return bzh_guard(const_cast<bzh_ctx *>(ctx), [&]() -> int {
+    if (!ctx || !count || (max && !out)) return BZH_E_ARG;
+    *count = K_COUNT;
+    if (max < (size_t)K_COUNT) return BZH_E_CAP;
+    for (int k = 0; k < K_COUNT; k++) {
+        memset(&out[k], 0, sizeof out[k]);
+        strncpy(out[k].name, KCLASS_NAME[k], sizeof out[k].name - 1);
+        out[k].ms = ctx->k_ms[k];
+        out[k].launches = ctx->k_launch[k];
+        out[k].alg_bytes = ctx->k_bytes[k];
+    }
+    return BZH_OK;
+    });
 }
 
 static void stats_collect_sort(bzh_ctx *ctx)
 {
+    kstats_collect(ctx);
     double ms = 0;
     for (auto &sp : ctx->sort_spans) {
         float t = 0;
@@ -663,12 +703,13 @@ static int prepare_batch(bzh_ctx *lane, RangeJob &j)
             hipEventRecord(j.ev[i], st);
         }
     };
+    lane->k_cur_ntotal = j.ntotal;
     mark(0);
     BZH_TRY(rle1_emit(lane, j.k0, j.B));
     mark(1);
     BZH_TRY(bwt_run(lane, j.B, j.nmax, j.ntotal));
     mark(2);
-    BZH_TRY(mtf_run(lane, j.B, j.nmax));
+    BZH_TRY(mtf_run(lane, j.B, j.nmax, j.ntotal));
     mark(3);
     BZH_TRY(huff_prepare(lane, j.B, j.mmax));
     mark(4);
@@ -719,6 +760,7 @@ static int encode_range(bzh_ctx *ctx, size_t b0, size_t b1, uint8_t *d_out, size
     for (bzh_ctx *l : lanes) {
         l->profiling = ctx->profiling;
         l->sort_spans.clear();
+        if (l != ctx) kstats_reset(l);
         if (l != ctx) {
             l->evnext = 0;
             memset(&l->stats, 0, sizeof l->stats);
@@ -822,6 +864,11 @@ static int encode_range(bzh_ctx *ctx, size_t b0, size_t b1, uint8_t *d_out, size
             ctx->stats.ms_bwt_sort += l->stats.ms_bwt_sort;
             ctx->stats.bwt_sort_launches += l->stats.bwt_sort_launches;
             ctx->stats.bwt_sort_elems += l->stats.bwt_sort_elems;
+            for (int k = 0; k < K_COUNT; k++) {
+                ctx->k_ms[k] += l->k_ms[k];
+                ctx->k_bytes[k] += l->k_bytes[k];
+                ctx->k_launch[k] += l->k_launch[k];
+            }
         }
     }
     for (bzh_ctx *l : lanes) {
@@ -924,6 +971,7 @@ extern "C" int bzh_encode_range_device(bzh_ctx *ctx, size_t b0, size_t b1, void 
     memset(&ctx->stats, 0, sizeof ctx->stats);
     ctx->stats.ms_plan = keep_plan;
     ctx->sort_spans.clear();
+    kstats_reset(ctx);
     ctx->evnext = 0;
     *nbits = 0;
     if (b0 == b1) return BZH_OK;
@@ -978,6 +1026,7 @@ extern "C" int bzh_encode_device(bzh_ctx *ctx, const void *d_in, size_t n, void 
     hipEvent_t t0 = nullptr, t1 = nullptr, t2 = nullptr;
     ctx->evnext = 0;
     ctx->sort_spans.clear();
+    kstats_reset(ctx);
     memset(&ctx->stats, 0, sizeof ctx->stats);
     if (ctx->profiling) {
         t0 = bzh_event(ctx);

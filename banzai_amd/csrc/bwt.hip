@@ -1826,15 +1826,22 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     // round state: everything from st_mode to the 64-bit counter (one contiguous carve, see layout_batch)
     HIP_TRY(ctx, hipMemsetAsync(bt.st_mode, 0,
                                 (size_t)((uint8_t *)(bt.stat_A + 1) - (uint8_t *)bt.st_mode), st));
-    byte_count<<<dim3(BYTE_SEGS, B), 1024, 0, st>>>(bt.rle, bt.n, bt.dtot, bt.S);
-    active_bases<<<dim3(B), 256, 0, st>>>(bt.dtot, bt.dbase, all, 1);
+    {
+        KSpan ks(ctx, K_BYTE_COUNT, ntotal, 2);
+        byte_count<<<dim3(BYTE_SEGS, B), 1024, 0, st>>>(bt.rle, bt.n, bt.dtot, bt.S);
+        active_bases<<<dim3(B), 256, 0, st>>>(bt.dtot, bt.dbase, all, 1);
+    }
     hipEvent_t ev_init = span_begin(ctx);
-    launch_pass<8, GEN_BYTES5>(ctx, a, B, nmax);
+    {
+        KSpan ks(ctx, K_RADIX_INIT, 13 * ntotal); // 5 text bytes in, one element out
+        launch_pass<8, GEN_BYTES5>(ctx, a, B, nmax);
+    }
     u64 *cur = bufA, *oth = bufB;
     for (int p = 1; p < 8; p++) {
         a.shift = p < 5 ? 20 + 8 * p : 40 + 8 * (p - 5);
         a.src = cur;
         a.dst = oth;
+        KSpan ks(ctx, p == 5 ? K_RADIX_GID : K_RADIX_INIT, (p == 5 ? 20 : 16) * ntotal); // (re-key: + one 4-byte gather)
         if (p == 5)
             launch_pass<8, GEN_GID>(ctx, a, B, nmax);
         else
@@ -1875,7 +1882,11 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     r.lst = all;
     // lists of every block + (rank word, suffix) pairs in list order; the blocks that start in SWEEP mode get their
     // SA order and digit bases in round 0 (below)
-    launch_refine_one<true>(ctx, r, B, nmax, bufD);
+    {
+        // list in, one pair out per suffix; the list records of the unresolved ones are added when round 0's summary is in
+        KSpan ks(ctx, K_REFINE_INIT, 16 * ntotal);
+        launch_refine_one<true>(ctx, r, B, nmax, bufD);
+    }
     { // the pairs, binned by 4096-suffix window (into sa|headp, which nobody needs before round 0), become the ranks
         u64 *binned = reinterpret_cast<u64 *>(bt.sa);
         static_assert(sizeof(u64) == 2 * sizeof(uint32_t), "sa and headp together hold one 64-bit word per suffix");
@@ -1887,9 +1898,13 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         a.src = bufD;
         a.dst = binned;
         hipEvent_t e0 = span_begin(ctx);
-        launch_pass<8, GEN_LIST>(ctx, a, B, nmax);
+        {
+            KSpan ks(ctx, K_RADIX_BIN, 16 * ntotal);
+            launch_pass<8, GEN_LIST>(ctx, a, B, nmax);
+        }
         span_end(ctx, e0);
         if (ctx->profiling) ctx->stats.bwt_sort_elems += ntotal;
+        KSpan ks(ctx, K_RANK_APPLY, 12 * ntotal);
         rank_apply<<<dim3((nmax + APPLY_W - 1) / APPLY_W, B), 256, 0, st>>>(binned, bt.n, bt.rank, bt.S);
     }
     { // the big lists of the first round are in `oth`
@@ -1945,6 +1960,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     // -- blocks in SWEEP mode: three look-back passes; the last refine left the digit bases (sweep_bases)
     auto run_S = [&](uint32_t round) {
         if (!nS) return;
+        KSpan ks(ctx, K_SWEEP, 0, 3);
         if (round == 0) {
             // round_begin has just picked the blocks that start in SWEEP mode: they need provisional SA entries,
             // group heads by position and digit bases, which the one-kernel refinement does not produce -- the
@@ -1990,10 +2006,14 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         a.src = cur;
         a.dst = oth;
         a.T = gt | (nA < 32 ? WG_SPREAD : 0u);
-        active_gen<<<dim3(xcd_grid(a.T, nA)), SORT_THREADS, 0, st>>>(a, bt.dtot);
-        active_bases<<<dim3(nA), 256, 0, st>>>(bt.dtot, bt.dbase, a.lst, 5);
+        {
+            KSpan ks(ctx, K_ACTIVE_GEN, 0, 2);
+            active_gen<<<dim3(xcd_grid(a.T, nA)), SORT_THREADS, 0, st>>>(a, bt.dtot);
+            active_bases<<<dim3(nA), 256, 0, st>>>(bt.dtot, bt.dbase, a.lst, 5);
+        }
         u64 *c = oth, *o = cur;
         hipEvent_t e0 = span_begin(ctx);
+        KSpan ks(ctx, K_RADIX_ROUNDS, 0, 5);
         for (int p = 0; p < 5; p++) {
             a.shift = 20 + 8 * p;
             a.doff = 256 * p;
@@ -2010,6 +2030,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     auto run_T = [&]() {
         const uint32_t tt = (maxT + TR_T - 1) / TR_T;
         if (!nT || !tt) return;
+        KSpan ks(ctx, K_TAIL_ROUND, 0, nQ ? 2 : 1);
         ta.T = tt | (nT < 32 ? WG_SPREAD : 0u);
         ta.tag = a.tag;
         ta.lst = Lst{actP, bt.nlist + L_P, B};
@@ -2023,14 +2044,26 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     };
     auto account = [&](const uint32_t *sm) { // statistics of the round a summary describes
         if (!ctx->profiling) return;
-        if (sm[1]) ctx->stats.bwt_sort_elems += 3 * ((uint64_t)sm[10] | ((uint64_t)sm[11] << 32));
-        if (sm[2]) ctx->stats.bwt_sort_elems += 5 * ((uint64_t)sm[12] | ((uint64_t)sm[13] << 32));
+        const uint64_t tot = (uint64_t)sm[8] | ((uint64_t)sm[9] << 32), eS = (uint64_t)sm[10] | ((uint64_t)sm[11] << 32),
+                       eA = (uint64_t)sm[12] | ((uint64_t)sm[13] << 32);
+        if (sm[1]) ctx->stats.bwt_sort_elems += 3 * eS;
+        if (sm[2]) ctx->stats.bwt_sort_elems += 5 * eA;
+        // algorithmic bytes of the round's kernels (per-element figures: DESIGN.md section 4)
+        ctx->k_bytes[K_SWEEP] += eS * (3 * 16 + 12 + 20);           // enumeration + gather, 3 passes, flags + refine
+        ctx->k_bytes[K_ACTIVE_GEN] += eA * 20;                      // record in, re-keyed record out, one rank gather
+        ctx->k_bytes[K_RADIX_ROUNDS] += eA * 5 * 16;
+        ctx->k_bytes[K_REFINE_ROUNDS] += eA * 20;                   // record in, rank word, list record out
+        ctx->k_bytes[K_TAIL_ROUND] += (tot - eS - eA) * 24;         // record in, key gather, rank word, survivor out
+        if (sm[0] == 0) ctx->k_bytes[K_REFINE_INIT] += tot * 8;     // the list records the initial refinement wrote
     };
 
     for (uint32_t round = 0; round < (uint32_t)MAX_ROUNDS; round++) {
         a.tag = 1u + round % 31u; // (a block is at work for fewer than 31 rounds: its depth doubles every time)
+        {
+        KSpan ks(ctx, K_ROUND_BEGIN, 0);
         round_begin<<<1, (B + 63u) / 64u * 64u, 0, st>>>(bt, B, round, actP,
                                                           const_cast<uint32_t *>(hsum) + (size_t)round * SUMMARY_WORDS, epoch + round + 1u);
+        }
         if (round > 1) {
             // the summary of the PREVIOUS round: where every block stood when that round began
             HIP_TRY(ctx, wait_summary(round - 1, s));
@@ -2088,11 +2121,13 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
                 if (nS) {
                     r.cpass = ++a.pass;
                     r.lst = Lst{bt.actS, bt.nlist + L_S, B};
+                    KSpan ks(ctx, K_SWEEP, 0, 4);
                     launch_refine(ctx, r, nS, maxS, true);
                 }
                 if (nA) {
                     r.cpass = ++a.pass;
                     r.lst = Lst{bt.actA, bt.nlist + L_A, B};
+                    KSpan ks(ctx, K_REFINE_ROUNDS, 0);
                     launch_refine_one<false>(ctx, r, nA, maxA);
                 }
                 std::swap(cur, oth);
@@ -2116,11 +2151,13 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             if (nS) {
                 r.cpass = ++a.pass;
                 r.lst = Lst{bt.actS, bt.nlist + L_S, B};
+                KSpan ks2(ctx, K_SWEEP, 0, 4);
                 launch_refine(ctx, r, nS, maxS, true);
             }
             if (nA) {
                 r.cpass = ++a.pass;
                 r.lst = Lst{bt.actA, bt.nlist + L_A, B};
+                KSpan ks(ctx, K_REFINE_ROUNDS, 0);
                 launch_refine_one<false>(ctx, r, nA, maxA);
             }
             std::swap(cur, oth);
@@ -2145,6 +2182,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     if (gx > 256) gx = 256;
     if (gx == 0) gx = 1;
     if (B < 32) gx |= WG_SPREAD;
+    KSpan ks(ctx, K_BWT_EMIT, 6 * ntotal);
     bwt_emit<<<dim3(xcd_grid(gx, B)), 256, 0, st>>>(bt, gx, B);
     HIP_TRY(ctx, hipGetLastError());
     return BZH_OK;

@@ -139,6 +139,21 @@ constexpr uint32_t FX_TABLES = 6;         // lib/huffman.rs:319-326 allows 2..6 
 constexpr uint32_t FX_HDR_A = 64;         // bytes reserved for the part before the selectors
 constexpr uint32_t FX_HDR_BYTES = 64 + 6 * 1152; // + up to 6 delta-coded tables (<= 5 + 258 * 35 bits each)
 
+// Kernel classes of the per-kernel roofline table (bzh_get_kernel_stats).  With profiling on, the launches of a
+// class are bracketed by HIP events on the context's stream (KSpan); `bytes` = ALGORITHMIC bytes the launches move
+// (per-element figures in DESIGN.md, element counts from the plan / the round summaries).
+enum KClass : int {
+    K_PLAN = 0, K_CRC, K_RLE1_EMIT, K_BYTE_COUNT, K_RADIX_INIT, K_RADIX_GID, K_REFINE_INIT, K_RADIX_BIN, K_RANK_APPLY,
+    K_ROUND_BEGIN, K_SWEEP, K_ACTIVE_GEN, K_RADIX_ROUNDS, K_TAIL_ROUND, K_REFINE_ROUNDS, K_BWT_EMIT, K_MTF_LAST,
+    K_MTF_WALK, K_RLE2, K_HUFF, K_PACK, K_COUNT
+};
+static const char *const KCLASS_NAME[K_COUNT] = {
+    "plan (granules, carries, split)", "crc_tiles", "rle1_emit", "byte_count", "radix_scatter (initial sort)",
+    "radix_scatter<GID> (re-key pass)", "refine_one<init>", "radix_scatter (rank binning)", "rank_apply", "round_begin",
+    "SWEEP path (3 passes + 3-kernel refine)", "active_gen", "radix_scatter (big-list rounds)", "tail_round",
+    "refine_one (rounds)", "bwt_emit", "mtf_tile_last + mtf_prefix", "mtf_walk", "rle2 (tiles, block, emit)",
+    "huffman (segments, build, header)", "pack_symbols"};
+
 struct Timer {
     hipEvent_t a = nullptr, b = nullptr;
 };
@@ -220,6 +235,34 @@ struct bzh_ctx {
     std::vector<hipEvent_t> evpool;
     size_t evnext = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> sort_spans;
+    struct KRec { int cls; hipEvent_t a, b; };
+    std::vector<KRec> kspans;          // profiling: event pairs per kernel class of the call in flight
+    uint64_t k_cur_ntotal = 0;         // RLE1 bytes of the batch in flight (byte counts of the stages around the sort)
+    double k_ms[K_COUNT] = {0};        // collected by kstats_collect
+    uint64_t k_bytes[K_COUNT] = {0}, k_launch[K_COUNT] = {0};
+};
+
+hipEvent_t bzh_event(bzh_ctx *ctx);
+// Brackets the launches issued during its lifetime (one class) with events when profiling is on.
+struct KSpan {
+    bzh_ctx *c;
+    int cls;
+    hipEvent_t a = nullptr;
+    KSpan(bzh_ctx *ctx, int k, uint64_t bytes, uint64_t launches = 1) : c(ctx), cls(k)
+    {
+        if (!c->profiling) return;
+        a = bzh_event(c);
+        hipEventRecord(a, c->stream);
+        c->k_bytes[k] += bytes;
+        c->k_launch[k] += launches;
+    }
+    ~KSpan()
+    {
+        if (!a) return;
+        hipEvent_t b = bzh_event(c);
+        hipEventRecord(b, c->stream);
+        c->kspans.push_back({cls, a, b});
+    }
 };
 
 // ---- wavefront-64 primitives ----------------------------------------------------------------
@@ -332,7 +375,7 @@ __device__ __forceinline__ int block_excl_min_rev(int v, int *lds)
 int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal); // bwt.hip
 int unbwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax);               // bwt.hip: inverse transform, bt.bwt/ptr -> bt.mtfpos
 int unbwt_compare(bzh_ctx *ctx, uint32_t B, uint32_t nmax, unsigned long long *d_acc); // bwt.hip: bt.rle vs bt.mtfpos
-int mtf_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax);                 // mtf.hip
+int mtf_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal = 0); // mtf.hip (ntotal: statistics only)
 int huff_prepare(bzh_ctx *ctx, uint32_t B, uint32_t mmax);            // huffman.hip: tables, header bits, bit totals
 int huff_pack(bzh_ctx *ctx, uint32_t B, uint32_t mmax, uint8_t *d_out, uint64_t bit_base); // huffman.hip
 int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n, bool with_crc = true); // rle1.hip

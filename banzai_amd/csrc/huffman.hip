@@ -862,6 +862,7 @@ __global__ void __launch_bounds__(64) fx_header(Batch bt, uint32_t selmax, uint3
 // bt.freqs, bt.nsyms, bt.ptr, bt.hasbyte, bt.desc[].crc).
 int huff_prepare(bzh_ctx *ctx, uint32_t B, uint32_t mmax)
 {
+    KSpan ks(ctx, K_HUFF, 4 * (uint64_t)ctx->k_cur_ntotal, 7); // symbols in twice (segments, bit counts)
     Batch &bt = ctx->bt;
     if (B == 0) return BZH_OK;
     hipStream_t st = ctx->stream;
@@ -898,6 +899,7 @@ int huff_prepare(bzh_ctx *ctx, uint32_t B, uint32_t mmax)
 // Writes blocks 0..B-1 at bit_base + bitoff[b] of d_out (zero-initialised, 4-byte aligned).
 int huff_pack(bzh_ctx *ctx, uint32_t B, uint32_t mmax, uint8_t *d_out, uint64_t bit_base)
 {
+    KSpan ks(ctx, K_PACK, 3 * (uint64_t)ctx->k_cur_ntotal, 2); // symbols in, about a third of a byte out per symbol
     Batch &bt = ctx->bt;
     if (B == 0) return BZH_OK;
     hipStream_t st = ctx->stream;

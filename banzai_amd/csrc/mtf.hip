@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(RLE_THREADS) rle_emit(Batch bt, const RleTile 
 
 // MTF + RLE2 for blocks 0..B-1 (bt.bwt / bt.n / bt.hasbyte filled).  tlast and RleTile scratch
 // live in the sort lists, which are free once the BWT is emitted.
-int mtf_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax)
+int mtf_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
 {
     Batch &bt = ctx->bt;
     if (B == 0) return BZH_OK;
@@ -464,9 +464,16 @@ int mtf_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax)
     RleTile *rt = reinterpret_cast<RleTile *>(bt.listB);     // B*(S/RLE_TILE)*16 bytes
     const uint32_t mt = (nmax + MTF_TILE - 1) / MTF_TILE;
     const uint32_t rtiles = (nmax + RLE_TILE - 1) / RLE_TILE;
-    mtf_tile_last<<<dim3(mt, B), 256, 0, st>>>(bt, tlast, MT);
-    mtf_prefix<<<dim3(B), 256, 0, st>>>(bt, tlast, MT);
-    mtf_walk<<<dim3(mt, B), 64, 0, st>>>(bt, tlast, MT);
+    {
+        KSpan ks(ctx, K_MTF_LAST, ntotal, 2);
+        mtf_tile_last<<<dim3(mt, B), 256, 0, st>>>(bt, tlast, MT);
+        mtf_prefix<<<dim3(B), 256, 0, st>>>(bt, tlast, MT);
+    }
+    {
+        KSpan ks(ctx, K_MTF_WALK, 2 * ntotal);
+        mtf_walk<<<dim3(mt, B), 64, 0, st>>>(bt, tlast, MT);
+    }
+    KSpan ks(ctx, K_RLE2, 4 * ntotal, 3); // positions in twice, symbols (<= n, 2 bytes) out
     rle_tiles<<<dim3(rtiles, B), RLE_THREADS, 0, st>>>(bt, rt);
     rle_block<<<dim3(B), 1024, 0, st>>>(bt, rt);
     rle_emit<<<dim3(rtiles, B), RLE_THREADS, 0, st>>>(bt, rt);

@@ -837,17 +837,21 @@ int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n, bool with_crc)
     PlanArrays &pa = w.pa;
     pa.in = d_in;
 
-    plan_starts<<<dim3(pa.ntiles), RL_THREADS, 0, st>>>(pa);
-    plan_carries<<<dim3(1), 1024, 0, st>>>(pa);
-    plan_granules<<<dim3(pa.ntiles), RL_THREADS, 0, st>>>(pa);
-    plan_tc<<<dim3(1), 1024, 0, st>>>(pa);
-    plan_split<<<dim3(1), 64, 0, st>>>(pa);
+    {
+        KSpan ks(ctx, K_PLAN, 2 * n, 5); // two sweeps of the input
+        plan_starts<<<dim3(pa.ntiles), RL_THREADS, 0, st>>>(pa);
+        plan_carries<<<dim3(1), 1024, 0, st>>>(pa);
+        plan_granules<<<dim3(pa.ntiles), RL_THREADS, 0, st>>>(pa);
+        plan_tc<<<dim3(1), 1024, 0, st>>>(pa);
+        plan_split<<<dim3(1), 64, 0, st>>>(pa);
+    }
     // The block CRCs are queued right behind the split, over as many blocks as there could be (the kernels read the
     // count on the device), and everything the host needs -- count, descriptors with their CRCs, cut status -- comes
     // back in ONE copy: the plan costs the host one wait.
     const CrcTables *ct = nullptr;
     if (with_crc) {
         BZH_TRY(crc_tables(ctx, &ct));
+        KSpan ks(ctx, K_CRC, n, 2);
         HIP_TRY(ctx, hipMemsetAsync(w.crcacc, 0, (size_t)pa.maxblocks * 4, st));
         for (uint32_t k0 = 0; k0 < pa.maxblocks; k0 += 32768) { // grid.y limit
             const uint32_t cnt = pa.maxblocks - k0 < 32768 ? pa.maxblocks - k0 : 32768;
@@ -935,6 +939,7 @@ int rle1_emit(bzh_ctx *ctx, size_t b0, uint32_t B)
         const uint64_t t0 = pb.in_off / RL_TILE, t1 = (pb.in_off + pb.in_len - 1) / RL_TILE;
         maxspan = std::max<uint64_t>(maxspan, t1 - t0 + 1);
     }
+    KSpan ks(ctx, K_RLE1_EMIT, 2 * (uint64_t)ctx->k_cur_ntotal);
     rle1_emit_kernel<<<dim3((uint32_t)maxspan, B), RL_THREADS, 0, ctx->stream>>>(ea, ctx->bt);
     HIP_TRY(ctx, hipGetLastError());
     return BZH_OK;

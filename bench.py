@@ -156,11 +156,17 @@ def main():
     ctx.set_profiling(True)
     sort_ms = sort_launches = sort_elems = 0.0
     stage, counters = {}, {}
+    kern = {}
     barrier()
     tp0 = time.perf_counter()
     for _ in range(args.steps):
         out_len = step()
         st = ctx.stats()
+        for ks in ctx.kernel_stats():
+            acc = kern.setdefault(ks["name"], {"ms": 0.0, "launches": 0, "alg_bytes": 0})
+            acc["ms"] += ks["ms"]
+            acc["launches"] += ks["launches"]
+            acc["alg_bytes"] += ks["alg_bytes"]
         sort_ms += st["ms_bwt_sort"]
         sort_launches += st["bwt_sort_launches"]
         sort_elems += st["bwt_sort_elems"]
@@ -288,13 +294,29 @@ def main():
         # HBM bytes per launch from the committed PMC passes of this same command (FETCH_SIZE / WRITE_SIZE in
         # separate rocprofv3 runs, corrected as MI355X_MICROARCH.md prescribes); null if not collected
         traffic = None
+        traffic_source = None
         try:
             pmc = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_pmc_traffic.json"))
             if pmc and world == 1 and seg_bytes == SEGMENT:
                 with open(os.path.join(ROOT, "profiles", pmc[-1])) as f:
                     traffic = round(json.load(f)["radix_scatter_all"]["hbm_bytes_per_launch"])
+                traffic_source = (f"profiles/{pmc[-1]}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this "
+                                  "command, NOT measured in this run")
         except Exception:
             traffic = None
+        # per-kernel-class roofline: HIP-event time of the class's launches in the profiled pass, algorithmic bytes
+        # by DESIGN.md section 4's per-element figures; the six classes that took the most time
+        ktable = []
+        for name, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"]):
+            if v["ms"] <= 0:
+                continue
+            gbs = v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9 if v["alg_bytes"] else None
+            ktable.append({"kernel": name, "us_per_step": round(v["ms"] * 1e3 / args.steps, 1),
+                           "launches_per_step": round(v["launches"] / args.steps, 1),
+                           "alg_bytes_per_step": round(v["alg_bytes"] / args.steps),
+                           "achieved_GBs": round(gbs, 1) if gbs else None,
+                           "frac": round(gbs / HBM_PEAK_GBS, 4) if gbs else None})
+        ktable = ktable[:8]
         path_gbs = alg / (ms_per_step * 1e-3) / 1e9
         result = {
             "metric": "encode MB/s (input) at level 9, enwik8, 1/2/4/8 MI355X; bit-exact vs CPU",
@@ -309,6 +331,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "radix_scatter", "achieved": round(achieved, 1) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
+                         "traffic_source": traffic_source, "kernels": ktable,
                          "launches": int(sort_launches), "avg_launch_us": round(sort_ms * 1e3 / max(1, sort_launches), 2),
                          "alg_bytes_per_launch": round(SORT_BYTES_PER_ELEM * sort_elems / max(1, sort_launches)),
                          "measured_in": "untimed second pass of the same K steps with profiling on "

@@ -87,6 +87,18 @@ BZH_API int bzh_set_mode(bzh_ctx *ctx, int mode);
 BZH_API int bzh_set_lanes(bzh_ctx *ctx, int lanes);
 BZH_API int bzh_get_stats(const bzh_ctx *ctx, bzh_stats *out);
 
+/* Per-kernel-class figures of the last whole-path call made with profiling on (bench.py's `roofline.kernels`):
+ * HIP-event time of the class's launches on the context's stream, launches issued, and the ALGORITHMIC bytes they
+ * moved (per-element figures in DESIGN.md section 4 x the element counts of the plan and the round summaries).
+ * *count receives the number of classes; BZH_E_CAP if max is smaller.  The reference has no counterpart. */
+typedef struct bzh_kstat {
+    char name[48];
+    double ms;
+    uint64_t launches;
+    uint64_t alg_bytes;
+} bzh_kstat;
+BZH_API int bzh_get_kernel_stats(const bzh_ctx *ctx, bzh_kstat *out, size_t max, size_t *count);
+
 /* ---- whole path: replaces banzai::encode(reader, writer, level), lib/lib.rs:84-132 -------- */
 
 /* Host buffers in and out (H2D + encode + D2H).  Produces the complete .bz2 stream for the
