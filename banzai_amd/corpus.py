@@ -145,12 +145,49 @@ def workload(n=100_000_000, segment=0):
 IMAGE_SETS = {
     "python-sources": (["/usr/lib/python3.10/**/*.py", "/usr/lib/python3/dist-packages/**/*.py"], 60_000_000),
     "shared-libs": (["/usr/lib/x86_64-linux-gnu/*.so*"], 60_000_000),
+    "real-text-100MB": ([], 100_000_000),
 }
+
+
+# Real text / markup / source text of the image for a workload of the headline's size: documentation, licences,
+# Perl pods and modules, the Python standard library, C and C++ headers -- walked in sorted order (the same files,
+# hence the same bytes, on every box of this image), every file once (symlinks skipped), cut at 100,000,000 bytes.
+REAL_TEXT = [("/usr/share/doc", None), ("/usr/share/common-licenses", None), ("/usr/share/perl", (".pod", ".pm", ".pl")),
+             ("/usr/lib/python3.10", (".py", ".txt")), ("/usr/include", (".h", ".hpp")),
+             ("/opt/rocm/include", (".h", ".hpp", ".inc")),
+             ("/usr/local/lib/python3.10/dist-packages", (".py", ".md", ".txt", ".rst"))]
+REAL_TEXT_SKIP = (".gz", ".xz", ".bz2", ".png", ".jpg", ".pyc", ".so", ".a", ".o", ".bin", ".pdf", ".ico", ".gif")
+
+
+def _walk_text(roots, limit):
+    buf = bytearray()
+    for root, exts in roots:
+        for dirpath, dirnames, filenames in os.walk(root):
+            dirnames.sort()
+            for fn in sorted(filenames):
+                if fn.endswith(REAL_TEXT_SKIP) or (exts is not None and not fn.endswith(exts)):
+                    continue
+                f = os.path.join(dirpath, fn)
+                try:
+                    if os.path.islink(f) or not os.path.isfile(f):
+                        continue
+                    with open(f, "rb") as fh:
+                        data = fh.read()
+                except OSError:
+                    continue
+                if b"\0" in data[:4096]:  # not text
+                    continue
+                buf += data
+                if len(buf) >= limit:
+                    return np.frombuffer(bytes(buf[:limit]), dtype=np.uint8)
+    return np.frombuffer(bytes(buf), dtype=np.uint8)
 
 
 def image_corpus(name):
     """Concatenation of the image's files matching IMAGE_SETS[name], in sorted order, cut at the limit.
     -> uint8 array (possibly short or empty when the files are not there)"""
+    if name == "real-text-100MB":
+        return _walk_text(REAL_TEXT, 100_000_000)
     import glob
     patterns, limit = IMAGE_SETS[name]
     buf = bytearray()

@@ -49,6 +49,7 @@
 //   tail_sort / tail_finish   small groups
 //   round_begin    per-round bookkeeping on the device
 //   bwt_emit       last column, ptr, has_byte
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -1313,68 +1314,67 @@ __global__ void __launch_bounds__(TR_THREADS) tail_round(TailArgs a)
     u64 *dst = a.dst + base;
     uint32_t *rank = a.rank + base;
     constexpr int NWV = TR_THREADS / 64, ROWS = TR_W / 64;
+    typedef typename std::conditional<QUAD, u64, uint32_t>::type key_t; // the 4h form packs three 20-bit ranks
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // R: group rank of every window slot (all ones: no record), K2 (K34): its key(s); HM: per 64 slots, which of
-    // them start a group.  After the ranking BUF is reused for the records in their new order.
-    __shared__ u64 BUF[TR_W];
-    __shared__ u64 K34[QUAD ? TR_W : 1];
+    // K: key of every window slot; HM: per 64 slots, which of them start a group; OUT: the records in their new order
+    __shared__ key_t K[TR_W];
+    __shared__ u64 OUT[TR_W];
     __shared__ u64 HM[ROWS];
-    __shared__ uint32_t wc[TR_PER * NWV];
+    __shared__ uint32_t wc[TR_PER * NWV], wsurv[NWV];
     __shared__ uint32_t tpre;
-    uint32_t *R = reinterpret_cast<uint32_t *>(BUF), *K2 = R + TR_W;
 
     // slot w = k * TR_THREADS + thread: coalesced loads, and the lanes of a wavefront hold 64 consecutive slots
     // (the ranking loop below runs as long as the largest group among them, not among 4 times as many)
     uint32_t ci[TR_PER], cr[TR_PER];
     {
-        u64 x[TR_PER];
+        u64 x[TR_PER], xp[TR_PER];
 #pragma unroll
         for (int k = 0; k < TR_PER; k++) {
             const uint32_t w = k * TR_THREADS + threadIdx.x;
             x[k] = w < nwin ? src[s_lo + w] : LIST_INVALID;
+            xp[k] = 0; // the record before my wavefront's 64 slots (lane 0 compares with it)
+            if (lane == 0 && w > 0 && w <= nwin) xp[k] = src[s_lo + w - 1];
         }
 #pragma unroll
         for (int k = 0; k < TR_PER; k++) {
             const uint32_t w = k * TR_THREADS + threadIdx.x;
             ci[k] = (uint32_t)(x[k] & SUF_MASK);
             cr[k] = w < nwin ? (uint32_t)(x[k] >> 40) & 0xFFFFFu : 0xFFFFFFFFu;
-            uint32_t k2 = 0, k3 = 0, k4 = 0;
+            key_t key = 0;
             if (w < nwin) {
                 const uint32_t i = ci[k];
                 if (h < n) {
                     uint32_t i2 = i + h;
                     if (i2 >= n) i2 -= n;
-                    k2 = rank_at(rank[rslot(i2)], tag);
+                    const uint32_t k2 = rank_at(rank[rslot(i2)], tag);
+                    key = (key_t)k2;
                     if (QUAD) { // two more h-blocks of the (cyclic) rotation
                         uint32_t i3 = i2 + h;
                         if (i3 >= n) i3 -= n;
                         uint32_t i4 = i3 + h;
                         if (i4 >= n) i4 -= n;
-                        k3 = rank_at(rank[rslot(i3)], tag);
-                        k4 = rank_at(rank[rslot(i4)], tag);
+                        const uint32_t k3 = rank_at(rank[rslot(i3)], tag), k4 = rank_at(rank[rslot(i4)], tag);
+                        key = (key_t)(((u64)k2 << 40) | ((u64)k3 << 20) | k4);
                     }
                 } else {
-                    k2 = n - 1 - i; // identical rotations: larger index first
+                    key = (key_t)(n - 1 - i); // identical rotations: larger index first
+                    if (QUAD) key = (key_t)((u64)(n - 1 - i) << 40);
                 }
             }
-            R[w] = cr[k];
-            K2[w] = k2;
-            if (QUAD) K34[w] = ((u64)k3 << 32) | k4;
+            K[w] = key;
+            // group structure: slot w starts a group if its rank differs from slot w-1's; the end of the window counts
+            uint32_t pr = (uint32_t)__shfl_up((int)cr[k], 1, 64);
+            if (lane == 0) pr = (uint32_t)(xp[k] >> 40) & 0xFFFFFu;
+            const bool head = w <= nwin && (w == 0 || w == nwin || pr != cr[k]);
+            const u64 hm = __ballot(head);
+            if (lane == 0) HM[k * NWV + wave] = hm;
         }
-    }
-    __syncthreads();
-    // group structure: slot w starts a group if its rank differs from slot w-1's; the end of the window counts
-#pragma unroll
-    for (int k = 0; k < TR_PER; k++) {
-        const uint32_t w = k * TR_THREADS + threadIdx.x;
-        const bool head = w <= nwin && (w == 0 || w == nwin || R[w - 1] != cr[k]);
-        const u64 hm = __ballot(head);
-        if (lane == 0) HM[k * NWV + wave] = hm;
     }
     __syncthreads();
     // Ranking: every member counts the members of its group that sort before it.
     uint32_t res[TR_PER]; // [owned:1 @31][single:1 @30][less:6 @24][dest slot:12 @0]
     bool moved = false, bad = false;
+    uint32_t nsurv = 0;
 #pragma unroll
     for (int k = 0; k < TR_PER; k++) {
         const uint32_t w = k * TR_THREADS + threadIdx.x;
@@ -1403,17 +1403,14 @@ __global__ void __launch_bounds__(TR_THREADS) tail_round(TailArgs a)
                 bad |= owned;
                 ge = g + TAIL_G;
             }
-            const uint32_t my = K2[w];
-            const u64 my2 = QUAD ? K34[w] : 0ull;
+            const key_t my = K[w];
             uint32_t less = 0, eq = 0, eqb = 0;
 #pragma unroll 4
             for (uint32_t f = g; f < ge; f++) { // bounds known up front: the LDS reads pipeline
-                const uint32_t kf = K2[f];
-                const u64 kf2 = QUAD ? K34[f] : 0ull;
-                const bool same = kf == my && kf2 == my2;
-                less += (kf < my) || (QUAD && kf == my && kf2 < my2);
-                eq += same;
-                eqb += same && f < w;
+                const key_t kf = K[f];
+                less += kf < my;
+                eq += kf == my;
+                eqb += kf == my && f < w;
             }
             const bool single = eq == 1u;
             if (owned) {
@@ -1423,47 +1420,49 @@ __global__ void __launch_bounds__(TR_THREADS) tail_round(TailArgs a)
                 // enumeration of SWEEP mode is its one reader), and a random 4-byte store is the most expensive
                 // thing this kernel does (it leaves the XCD as a partial 64-byte write).
                 if (less) rank[rslot(ci[k])] = rank_word(cr[k], less, tag, single);
+                nsurv += single ? 0u : 1u;
             }
             res[k] = (owned ? 0x80000000u : 0u) | (single ? 0x40000000u : 0u) | (less << 24) | (g + less + eqb);
         }
-    }
-    __syncthreads(); // everybody is done reading the keys
-    // the u-th smallest member takes the slot of the u-th member; resolved and foreign records leave as "none"
-#pragma unroll
-    for (int k = 0; k < TR_PER; k++) {
-        const uint32_t w = k * TR_THREADS + threadIdx.x;
+        // the u-th smallest member takes the slot of the u-th member; resolved and foreign records leave as "none"
         u64 rec = LIST_INVALID;
         if (w < nwin && (res[k] >> 30) == 2u) // owned, not single
             rec = ((u64)(cr[k] + ((res[k] >> 24) & 63u)) << 40) | ci[k];
-        BUF[res[k] & 0xFFFu] = rec;
+        OUT[res[k] & 0xFFFu] = rec;
     }
+    nsurv = wave_reduce_add(nsurv);
+    if (lane == 0) wsurv[wave] = nsurv;
+    if (__ballot(moved) && lane == 0) a.c_prog[b] = 1u; // same value from everyone
+    if (bad) atomicOr(a.err, 1u);
     __syncthreads();
+    // The order of the GROUPS in a small-group list is arbitrary (only a group's members must be adjacent), so a tile
+    // just claims room behind whatever is there: no tile ever waits for another.  c_tail ends up as the block's
+    // survivor count (round_begin cleared it).  The atomic's round trip runs beside the ballots below.
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < NWV; w++) tot += wsurv[w];
+        tpre = tot ? atomicAdd(&a.c_tail[b], tot) : 0u;
+    }
     u64 x[TR_PER];
     uint32_t lo[TR_PER]; // survivors of my wavefront's row k in lower lanes
 #pragma unroll
     for (int k = 0; k < TR_PER; k++) {
-        x[k] = BUF[k * TR_THREADS + threadIdx.x];
+        x[k] = OUT[k * TR_THREADS + threadIdx.x];
         const u64 m = __ballot(x[k] != LIST_INVALID);
         lo[k] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         if (lane == 0) wc[k * NWV + wave] = (uint32_t)__popcll(m);
     }
-    if (__ballot(moved) && lane == 0) a.c_prog[b] = 1u; // same value from everyone
-    if (bad) atomicOr(a.err, 1u);
     __syncthreads();
-    if (wave == 0) { // exclusive scan of the row counts in slot order, then the tile's place in the block's new list
-        const uint32_t c = lane < (uint32_t)(TR_PER * NWV) ? wc[lane] : 0u;
-        const uint32_t inc = wave_incl_add(c, (int)lane);
-        if (lane < (uint32_t)(TR_PER * NWV)) wc[lane] = inc - c;
-        // The order of the GROUPS in a small-group list is arbitrary (only a group's members must be adjacent), so a
-        // tile just claims room behind whatever is there: no tile ever waits for another.  c_tail ends up as the
-        // block's survivor count (round_begin cleared it).
-        if (lane == 63) tpre = inc ? atomicAdd(&a.c_tail[b], inc) : 0u;
-    }
-    __syncthreads();
+    // exclusive scan of the row counts in slot order (every wavefront for itself: 32 values)
+    const uint32_t c = lane < (uint32_t)(TR_PER * NWV) ? wc[lane] : 0u;
+    const uint32_t ex = wave_incl_add(c, (int)lane) - c;
     const uint32_t pre = tpre;
 #pragma unroll
-    for (int k = 0; k < TR_PER; k++)
-        if (x[k] != LIST_INVALID) dst[pre + wc[k * NWV + wave] + lo[k]] = x[k];
+    for (int k = 0; k < TR_PER; k++) {
+        const uint32_t off = (uint32_t)__shfl((int)ex, k * NWV + (int)wave, 64);
+        if (x[k] != LIST_INVALID) dst[pre + off + lo[k]] = x[k];
+    }
 }
 
 // ---- last column ---------------------------------------------------------------------------------
