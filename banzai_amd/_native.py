@@ -71,6 +71,8 @@ SIGNATURES = {
     "bzh_stream_set_chunk": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
     "bzh_stream_consumed": (ctypes.c_size_t, [ctypes.c_void_p]),
     "bzh_plan_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, szp]),
+    "bzh_plan_tables_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "bzh_plan_split_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, szp]),
     "bzh_plan_blocks": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Block), ctypes.c_size_t]),
     "bzh_plan_device_nocrc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, szp]),
     "bzh_plan_crc_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t]),
@@ -327,6 +329,19 @@ class Context:
         nb = ctypes.c_size_t(0)
         fn = lib().bzh_plan_device if crc else lib().bzh_plan_device_nocrc
         self.check(fn(self._h, ctypes.c_void_p(d_in), n, ctypes.byref(nb)))
+        self._nblocks = nb.value
+        return int(nb.value)
+
+    def plan_tables_device(self, d_in, n):
+        """bzh_plan_tables_device: the split's run tables over d_in[0..n) (queued, no wait)"""
+        self.check(lib().bzh_plan_tables_device(self._h, ctypes.c_void_p(d_in), n))
+
+    def plan_split_device(self, start, stop=None, crc=False):
+        """bzh_plan_split_device: cut blocks from offset `start` of the buffer of plan_tables_device until one starts at
+        or after `stop` (None: to the end) -> number of blocks"""
+        nb = ctypes.c_size_t(0)
+        stop = ctypes.c_size_t(-1).value if stop is None else stop
+        self.check(lib().bzh_plan_split_device(self._h, start, stop, 1 if crc else 0, ctypes.byref(nb)))
         self._nblocks = nb.value
         return int(nb.value)
 

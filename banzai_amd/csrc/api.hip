@@ -928,6 +928,34 @@ extern "C" int bzh_plan_device_nocrc(bzh_ctx *ctx, const void *d_in, size_t n, s
     });
 }
 
+extern "C" int bzh_plan_tables_device(bzh_ctx *ctx, const void *d_in, size_t n)
+{
+    return bzh_guard(ctx, [&]() -> int {
+    if (ctx) stream_join(ctx);
+    if (!ctx || (!d_in && n)) return BZH_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    BZH_TRY(check_in_ptr(ctx, d_in));
+    if (ctx->profiling) {
+        ctx->evnext = 0;
+        kstats_reset(ctx);
+    }
+    return rle1_plan_tables(ctx, (const uint8_t *)d_in, n);
+    });
+}
+
+extern "C" int bzh_plan_split_device(bzh_ctx *ctx, size_t start, size_t stop, int with_crc, size_t *nblocks)
+{
+    return bzh_guard(ctx, [&]() -> int {
+    if (ctx) stream_join(ctx);
+    if (!ctx || !nblocks) return BZH_E_ARG;
+    if (start > ctx->plan_n) return BZH_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    BZH_TRY(rle1_plan_split(ctx, start, with_crc != 0, stop));
+    *nblocks = ctx->plan_blocks.size();
+    return BZH_OK;
+    });
+}
+
 extern "C" int bzh_plan_crc_range(bzh_ctx *ctx, size_t b0, size_t b1)
 {
     return bzh_guard(ctx, [&]() -> int {

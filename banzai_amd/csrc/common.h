@@ -378,7 +378,9 @@ int unbwt_compare(bzh_ctx *ctx, uint32_t B, uint32_t nmax, unsigned long long *d
 int mtf_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal = 0); // mtf.hip (ntotal: statistics only)
 int huff_prepare(bzh_ctx *ctx, uint32_t B, uint32_t mmax);            // huffman.hip: tables, header bits, bit totals
 int huff_pack(bzh_ctx *ctx, uint32_t B, uint32_t mmax, uint8_t *d_out, uint64_t bit_base); // huffman.hip
-int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n, bool with_crc = true); // rle1.hip
+int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n, bool with_crc = true); // rle1.hip: tables + split from 0
+int rle1_plan_tables(bzh_ctx *ctx, const uint8_t *d_in, size_t n);                 // rle1.hip
+int rle1_plan_split(bzh_ctx *ctx, size_t start, bool with_crc, size_t stop);      // rle1.hip
 int rle1_plan_crc(bzh_ctx *ctx, size_t b0, size_t b1);               // rle1.hip: CRCs of plan blocks [b0, b1)
 int rle1_emit(bzh_ctx *ctx, size_t b0, uint32_t B);                   // rle1.hip: fill bt.rle / bt.n / bt.desc
 int crc_device(bzh_ctx *ctx, const uint8_t *d_in, size_t n, uint32_t *crc_out); // rle1.hip

@@ -46,6 +46,8 @@ struct PlanArrays {
     uint32_t ngran;
     uint32_t M;
     uint32_t maxblocks;
+    uint32_t start;    // input offset the split begins at (a block start; 0 unless a sharded rank continues a chain)
+    uint32_t stop;     // the split ends with the first block that starts at or after this offset (a sharded rank's range end)
     uint32_t *lrs;     // [ntiles]   last run start inside the tile (NONE32 if none); then exclusive prefix max
     uint32_t *frs;     // [ntiles+1] first run start inside the tile; then suffix min (frs[ntiles] = n)
     uint32_t *csum;    // [ntiles]   canonical bytes emitted by the tile
@@ -374,7 +376,7 @@ __global__ void __launch_bounds__(64) plan_split(PlanArrays pa)
     const uint32_t lane = threadIdx.x;
     const uint32_t N = (uint32_t)pa.n, M = pa.M, NT = pa.ntiles;
     const uint64_t total = pa.tc[NT];
-    uint32_t s = 0, nb = 0;
+    uint32_t s = pa.start, nb = 0;
     // The granule the previous cut fell into is usually also the one the next block starts in: keep its
     // evaluation (run starts + canonical offsets per byte) instead of recomputing it twice per block.
     Gran cg_eval{};
@@ -486,6 +488,10 @@ __global__ void __launch_bounds__(64) plan_split(PlanArrays pa)
             pa.aux[nb] = ax;
         }
         nb++;
+        if (s >= pa.stop) { // the block that belongs to the next range is on record: its start is all that was wanted
+            s = N;
+            break;
+        }
         s += consumed;
     }
     if (lane == 0) *pa.nblocks = (s < N) ? 0xFFFFFFFFu : nb; // overflow marker
@@ -808,8 +814,11 @@ static PlanWs plan_layout(uint8_t *base, uint64_t n, uint32_t M)
     return w;
 }
 
-// Plan over d_in[0..n): d_in must be 16-byte aligned.
-int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n, bool with_crc)
+// The split's tables (run starts and canonical RLE1 offsets per tile and per granule) over d_in[0..n): d_in must be
+// 16-byte aligned.  They describe the runs of the input, not the blocks, so they hold for a split that begins at
+// any block start inside the buffer (rle1_plan_split) -- a sharded rank builds them while its first block's start
+// is still on its way from the rank before.
+int rle1_plan_tables(bzh_ctx *ctx, const uint8_t *d_in, size_t n)
 {
     hipStream_t st = ctx->stream;
     ctx->plan_blocks.clear();
@@ -836,13 +845,41 @@ int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n, bool with_crc)
     PlanWs w = plan_layout((uint8_t *)ctx->plan_ws, n, ctx->M);
     PlanArrays &pa = w.pa;
     pa.in = d_in;
+    KSpan ks(ctx, K_PLAN, 2 * n, 4); // two sweeps of the input
+    plan_starts<<<dim3(pa.ntiles), RL_THREADS, 0, st>>>(pa);
+    plan_carries<<<dim3(1), 1024, 0, st>>>(pa);
+    plan_granules<<<dim3(pa.ntiles), RL_THREADS, 0, st>>>(pa);
+    plan_tc<<<dim3(1), 1024, 0, st>>>(pa);
+    HIP_TRY(ctx, hipGetLastError());
+    return BZH_OK;
+}
 
+int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n, bool with_crc)
+{
+    BZH_TRY(rle1_plan_tables(ctx, d_in, n));
+    return rle1_plan_split(ctx, 0, with_crc, SIZE_MAX);
+}
+
+// The sequential split over the tables of rle1_plan_tables, from input offset `start` (a block start) to the end of
+// the buffer -- or until a block starts at or after `stop` (that block is the last one listed); block offsets are
+// relative to the buffer.
+int rle1_plan_split(bzh_ctx *ctx, size_t start, bool with_crc, size_t stop)
+{
+    hipStream_t st = ctx->stream;
+    const size_t n = ctx->plan_n;
+    const uint8_t *d_in = ctx->plan_in;
+    ctx->plan_blocks.clear();
+    ctx->plan_open.clear();
+    ctx->plan_crc_ok.clear();
+    if (start > n) return BZH_E_ARG;
+    if (n == 0 || start == n) return BZH_OK;
+    PlanWs w = plan_layout((uint8_t *)ctx->plan_ws, n, ctx->M);
+    PlanArrays &pa = w.pa;
+    pa.in = d_in;
+    pa.start = (uint32_t)start;
+    pa.stop = stop >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)stop;
     {
-        KSpan ks(ctx, K_PLAN, 2 * n, 5); // two sweeps of the input
-        plan_starts<<<dim3(pa.ntiles), RL_THREADS, 0, st>>>(pa);
-        plan_carries<<<dim3(1), 1024, 0, st>>>(pa);
-        plan_granules<<<dim3(pa.ntiles), RL_THREADS, 0, st>>>(pa);
-        plan_tc<<<dim3(1), 1024, 0, st>>>(pa);
+        KSpan ks(ctx, K_PLAN, 0, 1);
         plan_split<<<dim3(1), 64, 0, st>>>(pa);
     }
     // The block CRCs are queued right behind the split, over as many blocks as there could be (the kernels read the

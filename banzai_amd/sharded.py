@@ -2,36 +2,46 @@
 
 bzip2 blocks are independent once the sequential split is known, so the path shards with no
 data-path collective.  Ownership goes by START OFFSET: the input is divided at fixed byte offsets
-B_0 = 0 < B_1 < ... < B_world = n and rank r encodes the blocks that start in [B_r, B_{r+1}).  A block's
-cut depends only on the bytes before it (plus a little look-ahead), so rank r splits just the prefix
-of the input up to B_{r+1} plus a margin -- the splitter marks the cuts that could still move if the
-input went on ("open", the streaming rule), everything before the first open block is exact -- instead
-of every rank splitting everything.  The split is the one sequential step (about 3 us per block on one
-wavefront), so the low ranks, whose prefixes are short, get slightly longer ranges (`offsets`).
+B_0 = 0 < B_1 < ... < B_world = n and rank r encodes the blocks that start in [B_r, B_{r+1}).
+
+The split is CHAINED, not repeated: the loop of the reference (lib/lib.rs:101-126) carries only `raw`, the
+stream CRC, `consumed` and the bit cursor from one block to the next, and a cut depends only on the bytes
+from its block's start on -- so all rank r needs from rank r-1 is the offset s_r at which the first block at or
+after B_r starts (one 8-byte send/recv).  Rank r holds input[B_r, B_{r+1} + look-ahead) and nothing else, builds
+the split's run tables over that while s_r is on its way (they describe runs, not blocks), cuts blocks from s_r
+until one starts at or after B_{r+1}, and forwards that start.  What remains sequential is the chain of the
+splits themselves (about 2.4 us per block on one wavefront): rank r waits for the r splits before it, so the
+ranges shrink slightly with the rank (`offsets`).
 Each rank encodes its blocks into a bit string that starts at bit 0; one small all-gather (bit
 counts, block CRCs) and one gather of the bit strings bring everything to rank 0, which funnel-shifts
-them into the stream and folds the stream CRC in block order (reference lib/lib.rs:101-126 carries
-only `raw`, `stream_crc`, `consumed` and the bit cursor between iterations).
+them into the stream and folds the stream CRC in block order.
 
 The `engine` is the per-rank compute: on a GPU box it is DeviceEngine (libbzhip.so through the
-C ABI); the CPU tests pass their own engine so that partitioning, gather order and assembly are
+C ABI); the CPU tests pass their own engine so that partitioning, chain, gather order and assembly are
 exercised under gloo without a GPU.  An engine provides
-    n                              -> input length in bytes
-    plan(prefix)                   -> ([(in_off, in_len, rle_len, crc)], [open]) for input[0:prefix]; the crc
-                                      field may be 0 (block CRCs are only needed from the rank that encodes)
-    encode_range(b0, b1)           -> (buffer tensor uint8 [cap], nbits) for blocks [b0, b1) of the last plan
+    n                              -> length of the whole input in bytes
+    lo, resident                   -> the engine holds input[lo, lo + resident)
+    tables()                       -> start whatever the split needs over the resident bytes (may do nothing)
+    split(start, stop)             -> ([(in_off, in_len, rle_len, crc)], [open]): the blocks cut from ABSOLUTE offset
+                                      `start` (a block start, >= lo) on, at least up to and including the first
+                                      one that starts at or after `stop` (or to the end of the resident bytes),
+                                      in_off absolute; the crc field may be 0; open[k] = the cut of block k could
+                                      still move if the input went on (the streaming rule)
+    encode_range(b0, b1)           -> (buffer tensor uint8 [cap], nbits) for blocks [b0, b1) of the last split
     crcs(b0, b1)                   -> [crc] of those blocks, valid after encode_range(b0, b1)
     assemble(segments, crcs)       -> stream length; segments = [(tensor, nbits)] in rank order,
                                       crcs = all block CRCs in block order
     cap                            -> fixed gather slab size in bytes (same on every rank)
     min_block                      -> least number of input bytes a block consumes (bounds blocks per range)
 """
+import time
 
-# cost of splitting one more input byte relative to encoding it (round 2, one-GPU simulation of 8 ranks on 800 MB:
-# rank 7 plans its 800 MB prefix in 4.5 ms = 5.7 us/MB while encoding costs 136 us/MB): rank r+1's range is this
-# much shorter than rank r's, which evens out split + encode over the ranks
-PLAN_COST = 0.04
-MARGIN = 4 << 20  # bytes planned beyond the end of the own range; grown when the last own cut is still open
+# what a rank waits for the split of the rank before it, relative to encoding the same bytes (one wavefront cuts
+# a 900 kB block in about 2.4 us, the encode takes about 105 us, i.e. 0.023): rank r+1's range is this much shorter
+# than rank r's -- half of what would even out wait + split + encode, so that the ranks' own work (split + encode)
+# stays within a few per cent of each other
+PLAN_COST = 0.012
+LOOKAHEAD = 64 << 20  # bytes held beyond the end of the own range (a block inside one enormous run eats < 52 MB)
 # rank 0 also receives the gather and assembles the stream (~4 % of a step): its range is shortened by that much
 ROOT_DISCOUNT = 0.96
 
@@ -56,28 +66,40 @@ def offsets(n, world):
     return out
 
 
-def own_blocks(engine, rank, world):
-    """Plan as far as needed and return (blocks, b0, b1): this rank's blocks are blocks[b0:b1] of that plan.
-    `blocks` is whatever the engine's plan() returns: a list of (in_off, in_len, rle_len, crc) tuples or a structured
-    numpy array with those fields (DeviceEngine: a high rank's prefix plan has ~1000 blocks per step)."""
+def resident_range(n, rank, world, lookahead=LOOKAHEAD):
+    """[lo, hi): the input bytes rank `rank` holds -- its own range plus the look-ahead its last block may need."""
+    b = offsets(n, world)
+    return b[rank], min(n, b[rank + 1] + lookahead)
+
+
+def resident_bytes(n, rank, world, lookahead=LOOKAHEAD):
+    lo, hi = resident_range(n, rank, world, lookahead)
+    return hi - lo
+
+
+def own_blocks(engine, rank, world, start):
+    """Cut this rank's blocks given the ABSOLUTE offset `start` its first block begins at.
+    -> (blocks, b0, b1, next_start): the rank's blocks are blocks[b0:b1] of the engine's split; next_start = where
+    the first block of the next range begins (n if there is none)."""
     import numpy as np
 
     n = engine.n
     bounds = offsets(n, world)
-    lo, hi = bounds[rank], bounds[rank + 1]
-    margin = MARGIN
-    while True:
-        prefix = n if rank == world - 1 else min(n, hi + margin)
-        blocks, is_open = engine.plan(prefix)
-        offs = blocks["in_off"] if isinstance(blocks, np.ndarray) else np.fromiter((b[0] for b in blocks), dtype=np.int64,
-                                                                                   count=len(blocks))
-        b0 = int(np.searchsorted(offs, lo, side="left"))  # first block that starts at or after lo
-        b1 = int(np.searchsorted(offs, hi, side="left"))
-        # exact if the plan saw the whole input, or if a block starting at/after `hi` exists whose predecessor's
-        # cut is final (a cut is final once its block is not open; the cuts before a final cut are final too)
-        if prefix == n or (b1 < len(blocks) and (b1 == 0 or not bool(is_open[b1 - 1]))):
-            return blocks, b0, b1
-        margin *= 4
+    hi = bounds[rank + 1]
+    if start >= hi or start >= n:  # a block of an earlier rank runs over this whole range
+        return [], 0, 0, start
+    blocks, is_open = engine.split(start, hi)
+    offs = blocks["in_off"] if isinstance(blocks, np.ndarray) else np.fromiter((b[0] for b in blocks), dtype=np.int64,
+                                                                               count=len(blocks))
+    b1 = int(np.searchsorted(offs, hi, side="left"))  # first block that starts at or after hi
+    sees_end = engine.lo + engine.resident >= n
+    # exact if the split saw the end of the input, or if a block starting at/after `hi` exists whose predecessor's
+    # cut is final (a cut is final once its block is not open; the cuts before a final cut are final too)
+    if not (sees_end or (b1 < len(blocks) and (b1 == 0 or not bool(is_open[b1 - 1])))):
+        raise ShardError(f"rank {rank}: the look-ahead of {engine.lo + engine.resident - hi} bytes behind its range does "
+                         "not settle its last cut")
+    nxt = int(offs[b1]) if b1 < len(blocks) else n
+    return blocks, 0, b1, nxt
 
 
 class ShardError(RuntimeError):
@@ -85,18 +107,50 @@ class ShardError(RuntimeError):
 
 
 def encode_sharded(engine, dist=None, rank=0, world=1):
-    """Run one sharded encode.  Returns the stream length on rank 0 (0 elsewhere)."""
+    """Run one sharded encode.  Returns the stream length on rank 0 (0 elsewhere).  engine.times (if the engine has
+    the attribute) receives this rank's milliseconds: tables + split, waiting for the chain, encode, gather."""
     import torch
 
     # A rank that fails before the collectives must still take part in them, or the others wait for ever:
-    # the failure travels as a status word in the all-gathered meta row and every rank raises together.
+    # the failure travels down the chain as start -1 and as a status word in the all-gathered meta row, and every
+    # rank raises together.
     err, part, nbits, own = None, None, 0, []
+    t = {"ms_plan": 0.0, "ms_wait": 0.0, "ms_encode": 0.0, "ms_gather": 0.0}
+    dev = getattr(engine, "device", "cpu")
+    nxt, start = -1, 0
+    t0 = time.perf_counter()
     try:
-        blocks, b0, b1 = own_blocks(engine, rank, world)
-        part, nbits = engine.encode_range(b0, b1)
-        own = engine.crcs(b0, b1)
+        engine.tables()
     except Exception as e:  # noqa: BLE001 -- whatever it was, the other ranks have to hear about it
         err = e
+    t1 = time.perf_counter()
+    if rank > 0:  # (always: the rank before always sends)
+        box = torch.zeros(1, dtype=torch.int64, device=dev)
+        dist.recv(box, src=rank - 1)
+        start = int(box.item())
+        if start < 0 and err is None:
+            err = ShardError(f"rank {rank}: a rank before this one failed")
+    t2 = time.perf_counter()
+    if err is None:
+        try:
+            blocks, b0, b1, nxt = own_blocks(engine, rank, world, start)
+        except Exception as e:  # noqa: BLE001
+            err, nxt = e, -1
+    t3 = time.perf_counter()
+    t["ms_plan"] = ((t1 - t0) + (t3 - t2)) * 1e3
+    t["ms_wait"] = (t2 - t1) * 1e3
+    if world > 1 and rank < world - 1:
+        dist.send(torch.tensor([nxt], dtype=torch.int64, device=dev), dst=rank + 1)
+    if err is None:
+        try:
+            t3 = time.perf_counter()
+            part, nbits = engine.encode_range(b0, b1)
+            own = engine.crcs(b0, b1)
+            t["ms_encode"] = (time.perf_counter() - t3) * 1e3
+        except Exception as e:  # noqa: BLE001
+            err = e
+    if hasattr(engine, "times"):
+        engine.times = t
     if world == 1:
         if err is not None:
             raise err
@@ -122,28 +176,25 @@ def encode_sharded(engine, dist=None, rank=0, world=1):
     used = min(engine.cap, (max(nb) + 31) // 32 * 4)
     send = part[:used]
     slabs = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+    tg = time.perf_counter()
     dist.gather(send, slabs, dst=0)  # encoded blocks -> rank 0 (RCCL over xGMI on a GPU node)
     if rank != 0:
+        t["ms_gather"] = (time.perf_counter() - tg) * 1e3
         return 0
     crcs = []
     for r in rows:
         crcs += [int(c) for c in r[2:2 + int(r[1])]]
     segs = [(slabs[k], nb[k]) for k in range(world)]
-    return engine.assemble(segs, crcs)
-
-
-def resident_bytes(n, rank, world, margin=64 << 20):
-    """Input bytes rank `rank` has to hold: the prefix up to the end of its range plus the look-ahead the split
-    may ask for (own_blocks grows its margin 4 -> 16 -> 64 MiB); the last rank holds everything."""
-    if rank == world - 1:
-        return n
-    return min(n, offsets(n, world)[rank + 1] + margin)
+    out_len = engine.assemble(segs, crcs)
+    t["ms_gather"] = (time.perf_counter() - tg) * 1e3  # (rank 0: gather + assembly)
+    return out_len
 
 
 def worst_case_slab(n, world, level=9):
-    """Bytes that hold the bit string of any rank's range whatever the data: RLE1 expands by at most 5/4, the
-    Huffman stage by less than 17/8 bits per symbol is never reached (<= 1.02 n + tables in practice, 5/4 n is
-    safe), plus per-block headers and tables (< 4 KiB each)."""
+    """Slab size for a rank's bit string: 5/4 of the range (RLE1 expands by at most 5/4; the Huffman stage stays near
+    or below 8 bits per symbol on anything but adversarial frequency tables) plus 4 KiB of headers and tables per
+    block.  Not a proven bound: a slab that is too small is caught, not overrun (BZH_E_CAP -> ShardError on every
+    rank)."""
     b = offsets(n, world)
     rng = max(b[r + 1] - b[r] for r in range(world))
     blocks = rng // ((100000 * level - 1) * 4 // 5) + 2
@@ -151,26 +202,33 @@ def worst_case_slab(n, world, level=9):
 
 
 class DeviceEngine:
-    """libbzhip.so on this rank's GPU.  d_in holds the first `resident` bytes of the n-byte input (the rank's
-    prefix, see resident_bytes; default: all of it)."""
+    """libbzhip.so on this rank's GPU.  d_in holds input[lo, lo + resident) of the n-byte input (see resident_range;
+    default: all of it)."""
 
-    def __init__(self, ctx, d_in, n, d_out, seg_cap, resident=None):
+    def __init__(self, ctx, d_in, n, d_out, seg_cap, resident=None, lo=0):
         import torch
 
         self.ctx, self.d_in, self.n, self.d_out = ctx, d_in, n, d_out
+        self.lo = lo
         self.resident = n if resident is None else resident
         self.device = d_in.device
         self.cap = seg_cap
+        self.times = {}
         self.part = torch.zeros(seg_cap, dtype=torch.uint8, device=d_in.device)
         # RLE1 expands by at most 5/4, so a block of M = 100000*level - 1 output bytes eats at least 0.8 M input
         # bytes (only the stream's last block may be shorter)
         self.min_block = (100000 * ctx.level - 1) * 4 // 5
 
-    def plan(self, prefix):
-        if prefix > self.resident:
-            raise ShardError(f"the split needs {prefix} input bytes but only {self.resident} are resident on this rank")
-        self.ctx.plan_device_only(self.d_in.data_ptr(), prefix, crc=False)
-        return self.ctx.plan_blocks_np(), self.ctx.plan_open_np()
+    def tables(self):
+        self.ctx.plan_tables_device(self.d_in.data_ptr(), self.resident)
+
+    def split(self, start, stop=None):
+        if start < self.lo or start > self.lo + self.resident:
+            raise ShardError(f"the split starts at {start}, outside the resident bytes [{self.lo}, {self.lo + self.resident})")
+        self.ctx.plan_split_device(start - self.lo, None if stop is None else max(0, stop - self.lo), crc=False)
+        blocks = self.ctx.plan_blocks_np()
+        blocks["in_off"] += self.lo
+        return blocks, self.ctx.plan_open_np()
 
     def encode_range(self, b0, b1):
         nbits = self.ctx.encode_range_device(b0, b1, self.part.data_ptr(), self.cap)

@@ -6,12 +6,13 @@ stream assembly) over the workload, inputs resident in HBM when the timed region
 finished .bz2 stream resident in HBM on rank 0 when it ends.
 
 N = 1: 100,000,000 bytes (BASELINE.json configs[2]) through bzh_encode_device.
-N > 1: weak scaling, N x 100,000,000 bytes as ONE stream.  `python bench.py --gpus N` without a launcher
-starts its own ranks (a fresh `python -m torch.distributed.run` child, before this process touches
-the GPU); under a launcher (WORLD_SIZE set) it is one rank.  Rank r holds only the input prefix its
-split needs (sharded.resident_bytes), splits that prefix, encodes the blocks that start in its range;
-the encoded bit strings are gathered to rank 0 over RCCL (torch.distributed backend "nccl") and
-funnel-shifted into the stream there.
+N > 1: weak scaling, N x 100,000,000 bytes as ONE stream (`--total-bytes 1000000000` instead runs BASELINE.json's
+config 4, one 1 GB stream over the N ranks).  `python bench.py --gpus N` without a launcher starts its own ranks
+(a fresh `python -m torch.distributed.run` child, before this process touches the GPU); under a launcher
+(WORLD_SIZE set) it is one rank.  Rank r holds its own byte range plus a look-ahead (sharded.resident_range),
+builds the split's tables over it, receives the start of its first block from rank r-1 (8 bytes), cuts and
+encodes the blocks that start in its range; the encoded bit strings are gathered to rank 0 over RCCL
+(torch.distributed backend "nccl") and funnel-shifted into the stream there.
 
 Timed region: K steps with profiling OFF (the product's default path).  Stage timings, the radix-pass
 roofline (HIP events on the context's stream) and the counters of `roofline.path_frac` come from a
@@ -46,6 +47,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--bytes", type=int, default=SEGMENT, help="bytes per GPU")
+    ap.add_argument("--total-bytes", type=int, default=0,
+                    help="size of the ONE stream all ranks share (overrides --bytes; 1000000000 = BASELINE config 4)")
     ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="bytes of the workload timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true", help="skip the oracle (no cpu_baseline, no bit-exactness checks)")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_workloads and value_host_inclusive")
@@ -97,19 +100,26 @@ def main():
 
     seg_bytes = args.bytes
     total = seg_bytes * world
-    # ---- workload (untimed): rank k generates segment k; every rank keeps only the prefix its split needs ----
-    seg, wname = corpus.workload(seg_bytes, segment=rank)
-    resident = sharded.resident_bytes(total, rank, world)
+    if args.total_bytes:
+        total = args.total_bytes
+        seg_bytes = -(-total // world)
+    # ---- workload (untimed): rank k generates segment k; every rank keeps its own range + the look-ahead only ----
+    seg_len = max(0, min(seg_bytes, total - rank * seg_bytes))
+    seg, wname = corpus.workload(max(1, seg_len), segment=rank)
+    seg = seg[:seg_len]
+    lo_res, hi_res = sharded.resident_range(total, rank, world) if world > 1 else (0, total)
+    resident = hi_res - lo_res
     d_in = torch.zeros(resident + 16, dtype=torch.uint8, device=dev)
     if world > 1:
         scratch = torch.empty(seg_bytes, dtype=torch.uint8, device=dev)
         for k in range(world):
-            if k == rank:
-                scratch.copy_(torch.from_numpy(seg))
+            klen = max(0, min(seg_bytes, total - k * seg_bytes))
+            if k == rank and klen:
+                scratch[:klen].copy_(torch.from_numpy(seg))
             dist.broadcast(scratch, src=k)
-            lo, hi = k * seg_bytes, min((k + 1) * seg_bytes, resident)
+            lo, hi = max(k * seg_bytes, lo_res), min(k * seg_bytes + klen, hi_res)
             if hi > lo:
-                d_in[lo:hi] = scratch[:hi - lo]
+                d_in[lo - lo_res:hi - lo_res] = scratch[lo - k * seg_bytes:hi - k * seg_bytes]
         del scratch
     else:
         d_in[:total] = torch.from_numpy(seg).to(dev)
@@ -122,7 +132,8 @@ def main():
 
     engine = None
     if world > 1:
-        engine = sharded.DeviceEngine(ctx, d_in, total, d_out, sharded.worst_case_slab(total, world, LEVEL), resident=resident)
+        engine = sharded.DeviceEngine(ctx, d_in, total, d_out, sharded.worst_case_slab(total, world, LEVEL), resident=resident,
+                                      lo=lo_res)
 
     def step():
         """One pass of the hot path; returns the stream length on rank 0."""
@@ -157,11 +168,15 @@ def main():
     sort_ms = sort_launches = sort_elems = 0.0
     stage, counters = {}, {}
     kern = {}
+    rank_ms = {}
     barrier()
     tp0 = time.perf_counter()
     for _ in range(args.steps):
         out_len = step()
         st = ctx.stats()
+        if engine is not None:
+            for k, v in engine.times.items():
+                rank_ms[k] = rank_ms.get(k, 0.0) + v
         for ks in ctx.kernel_stats():
             acc = kern.setdefault(ks["name"], {"ms": 0.0, "launches": 0, "alg_bytes": 0})
             acc["ms"] += ks["ms"]
@@ -180,14 +195,27 @@ def main():
 
     # whole-path accounting needs every rank's counters
     alg = float(path_alg_bytes(counters))
+    per_rank = None
     if world > 1:
         t = torch.tensor([alg], dtype=torch.float64, device=dev)
         dist.all_reduce(t)
         alg = float(t.item())
+        # every rank's share of a step: tables + split, waiting for the chain, encode, gather (+ assembly on rank 0)
+        keys = ("ms_plan", "ms_wait", "ms_encode", "ms_gather")
+        mine = torch.tensor([rank_ms.get(k, 0.0) / args.steps for k in keys] + [float(resident), float(counters["raw_bytes"])],
+                            dtype=torch.float64, device=dev)
+        allr = torch.zeros(world * mine.numel(), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allr, mine)
+        rows = allr.view(world, -1).tolist()
+        per_rank = [dict({k: round(v, 3) for k, v in zip(keys, row)}, resident_bytes=int(row[4]), encoded_input_bytes=int(row[5]))
+                    for row in rows]
         # rank 0 also checks the sharded stream against one GPU encoding the whole input (untimed)
-        d_full = torch.zeros(total + 16, dtype=torch.uint8, device=dev) if rank == 0 else None
+        d_full = torch.zeros(seg_bytes * world + 16, dtype=torch.uint8, device=dev) if rank == 0 else None
         parts = [d_full[k * seg_bytes:(k + 1) * seg_bytes] for k in range(world)] if rank == 0 else None
-        dist.gather(torch.from_numpy(seg).to(dev), parts, dst=0)
+        mine_full = torch.zeros(seg_bytes, dtype=torch.uint8, device=dev)
+        mine_full[:seg_len] = torch.from_numpy(seg).to(dev)
+        dist.gather(mine_full, parts, dst=0)
+        del mine_full
     else:
         d_full = d_in
 
@@ -321,7 +349,9 @@ def main():
         result = {
             "metric": "encode MB/s (input) at level 9, enwik8, 1/2/4/8 MI355X; bit-exact vs CPU",
             "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "strong" if args.total_bytes else "weak",
+            "ranks_seen": dist.get_world_size() if world > 1 else 1, "per_rank": per_rank,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic" if wname != "enwik8" else "enwik8",
             "config": {"workload": f"level {LEVEL} {wname}, {seg_bytes} bytes per GPU, {total} bytes in one stream, "
                                    "full RLE1->BWT->MTF->Huffman pipeline",

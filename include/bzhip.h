@@ -148,6 +148,16 @@ BZH_API size_t bzh_stream_consumed(const bzh_ctx *ctx);
  * every rle_one() cut (lib/rle.rs:102-253) and block CRC, without encoding anything.
  * The plan stays in the context and references d_in (caller keeps it alive). */
 BZH_API int bzh_plan_device(bzh_ctx *ctx, const void *d_in, size_t n, size_t *nblocks);
+
+/* The same in two steps, for a rank that continues another rank's split (banzai_amd/sharded.py): the loop of
+ * lib/lib.rs:101-126 carries only `raw`, the stream CRC, `consumed` and the bit cursor from one block to the
+ * next, so a rank needs nothing from its predecessor but the offset its first block starts at.
+ * bzh_plan_tables_device builds the run tables of d_in[0..n) (no wait; they do not depend on where blocks start);
+ * bzh_plan_split_device then cuts blocks from offset `start` of that buffer (a block start) until one starts at or
+ * after `stop` (listed last: its offset is what the next rank needs; SIZE_MAX = to the end of the buffer), with or
+ * without block CRCs.  Offsets in the resulting plan are relative to d_in. */
+BZH_API int bzh_plan_tables_device(bzh_ctx *ctx, const void *d_in, size_t n);
+BZH_API int bzh_plan_split_device(bzh_ctx *ctx, size_t start, size_t stop, int with_crc, size_t *nblocks);
 BZH_API int bzh_plan_blocks(const bzh_ctx *ctx, bzh_block *out, size_t max_blocks);
 
 /* The same split without the block CRCs (their `crc` fields read 0): for the sharded path, where every

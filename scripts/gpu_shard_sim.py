@@ -1,35 +1,39 @@
-"""What ONE rank of an N-rank sharded encode does, timed on a single GPU (no communication):
-plan over the whole N x 100 MB input, encode its own 1/N of the blocks, assemble N segments."""
+"""What every rank of an N-rank sharded encode does, timed on a single GPU (no communication): the chained split
+(tables over the own range + look-ahead, split from the start handed over), the encode of the own blocks.
+    python scripts/gpu_shard_sim.py [N] [total_bytes]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from banzai_amd import _native as nv, corpus, sharded
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+total = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000_000
 seg = 100_000_000
-parts = [corpus.workload(seg, segment=k % 2)[0] for k in range(2)]
-total = seg * N
-d_in = torch.empty(total + 16, dtype=torch.uint8, device="cuda")
-for k in range(N):
-    d_in[k * seg:(k + 1) * seg] = torch.from_numpy(parts[k % 2]).cuda()
-out_cap = (total // 3 + total // 8 + (1 << 20)) & ~3
-d_out = torch.zeros(out_cap, dtype=torch.uint8, device="cuda")
+host = np.empty(total, dtype=np.uint8)
+for k in range((total + seg - 1) // seg):
+    part = corpus.workload(min(seg, total - k * seg), segment=k)[0]
+    host[k * seg:k * seg + part.size] = part
 ctx = nv.Context(0, 9, 128)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-seg_cap = (seg // 3 + seg // 8 + (1 << 20)) & ~3
-eng = sharded.DeviceEngine(ctx, d_in, total, d_out, seg_cap)
+slab = sharded.worst_case_slab(total, N, 9)
+d_out = torch.zeros(16, dtype=torch.uint8, device="cuda")
 def sync(): torch.cuda.synchronize()
-for it in range(3):
-    sync(); t0 = time.perf_counter()
-    r = N // 2
-    blocks, b0, b1 = sharded.own_blocks(eng, r, N); sync(); t1 = time.perf_counter()
-    part, nbits = eng.encode_range(b0, b1); sync(); t2 = time.perf_counter()
-    segs = [(part, nbits)] * N
-    crcs = eng.crcs(b0, b1) * N  # timing only: the other ranks' CRCs would arrive with the gather
-    n_out = eng.assemble(segs, crcs); sync(); t3 = time.perf_counter()
-    print(f"N={N} rank {r}: planned {int(blocks[-1][0]) + int(blocks[-1][1])} of {total} bytes, own blocks={b1-b0}  plan {1e3*(t1-t0):.2f} ms  encode_range {1e3*(t2-t1):.2f} ms  assemble({N} segs, {nbits//8/1e6:.1f} MB each) {1e3*(t3-t2):.2f} ms  total {1e3*(t3-t0):.2f}", flush=True)
-for r in (0, N - 1):
-    sync(); t0 = time.perf_counter()
-    blocks, b0, b1 = sharded.own_blocks(eng, r, N); sync(); t1 = time.perf_counter()
-    part, nbits = eng.encode_range(b0, b1); sync(); t2 = time.perf_counter()
-    print(f"N={N} rank {r}: own blocks={b1-b0}  plan {1e3*(t1-t0):.2f} ms  encode_range {1e3*(t2-t1):.2f} ms  sum {1e3*(t2-t0):.2f}", flush=True)
+rows = []
+for it in range(2):
+    start, rows = 0, []
+    for r in range(N):
+        lo, hi = sharded.resident_range(total, r, N)
+        d_r = torch.zeros(hi - lo + 16, dtype=torch.uint8, device="cuda")
+        d_r[:hi - lo] = torch.from_numpy(host[lo:hi]).cuda()
+        eng = sharded.DeviceEngine(ctx, d_r, total, d_out, slab, resident=hi - lo, lo=lo)
+        sync(); t0 = time.perf_counter()
+        eng.tables(); sync(); t1 = time.perf_counter()
+        blocks, b0, b1, start = sharded.own_blocks(eng, r, N, start); sync(); t2 = time.perf_counter()
+        part, nbits = eng.encode_range(b0, b1); sync(); t3 = time.perf_counter()
+        rows.append({"rank": r, "resident_MB": round((hi - lo) / 1e6, 1), "blocks": b1 - b0, "ms_tables": round(1e3 * (t1 - t0), 3),
+                     "ms_split": round(1e3 * (t2 - t1), 3), "ms_encode": round(1e3 * (t3 - t2), 3)})
+        del eng, d_r, part
+tot = [r["ms_tables"] + r["ms_split"] + r["ms_encode"] for r in rows]
+import json
+print(json.dumps({"world": N, "total_bytes": total, "ranks": rows, "plan_plus_encode_max_over_mean": round(max(tot) / (sum(tot) / len(tot)), 4),
+                  "chain_ms_before_last_rank": round(sum(r["ms_split"] for r in rows[:-1]), 3)}))

@@ -404,24 +404,24 @@ def test_offset_ownership_with_prefix_plans_on_device(oracle, native):
     d_in[:n] = torch.from_numpy(data).to(dev)
     cap = (n // 2 + (1 << 20)) & ~3
     d_out = torch.zeros(cap, dtype=torch.uint8, device=dev)
-    old = sharded.MARGIN
-    sharded.MARGIN = 100_000
-    try:
-        with native.Context(0, 9, 8) as ctx:
-            eng = sharded.DeviceEngine(ctx, d_in, n, d_out, cap)
-            for world in (2, 3, 7):
-                segs, keep, crcs = [], [], []
-                for r in range(world):
-                    blocks, b0, b1 = sharded.own_blocks(eng, r, world)
-                    part, nbits = eng.encode_range(b0, b1)
-                    keep.append(part.clone())
-                    segs.append((keep[-1], nbits))
-                    crcs += eng.crcs(b0, b1)
-                d_out.zero_()
-                ln = eng.assemble(segs, crcs)
-                assert d_out[:ln].cpu().numpy().tobytes() == want, world
-    finally:
-        sharded.MARGIN = old
+    with native.Context(0, 9, 8) as ctx:
+        for world in (2, 3, 7):
+            segs, keep, crcs, start = [], [], [], 0
+            for r in range(world):  # rank r sees its own range plus a look-ahead, and the start rank r-1 hands over
+                lo, hi = sharded.resident_range(n, r, world, lookahead=3_500_000)
+                d_r = torch.zeros(hi - lo + 16, dtype=torch.uint8, device=dev)
+                d_r[:hi - lo] = d_in[lo:hi]
+                eng = sharded.DeviceEngine(ctx, d_r, n, d_out, cap, resident=hi - lo, lo=lo)
+                eng.tables()
+                blocks, b0, b1, start = sharded.own_blocks(eng, r, world, start)
+                part, nbits = eng.encode_range(b0, b1)
+                keep.append(part.clone())
+                segs.append((keep[-1], nbits))
+                crcs += eng.crcs(b0, b1)
+            assert start == n
+            d_out.zero_()
+            ln = eng.assemble(segs, crcs)
+            assert d_out[:ln].cpu().numpy().tobytes() == want, world
 
 
 def test_two_lanes_same_bytes(oracle, native):
@@ -500,19 +500,24 @@ def test_full_size_config4_one_gigabyte_and_world8_simulation(native, oracle):
         assert all(blocks[k][0] + blocks[k][1] == blocks[k + 1][0] for k in range(len(blocks) - 1))
         assert 1100 <= len(blocks) <= 1130
         assert ctx.bwt_roundtrip_device(0, len(blocks)) == 0  # every block: BWT -> inverse BWT on the device
-        # world = 8, rank by rank; a rank may only plan inside its resident prefix
+        # world = 8, rank by rank: a rank holds its own range + 64 MiB and gets its first block's start from the rank before
         slab = sharded.worst_case_slab(n, world, 9)
-        segs, keep, crcs, nblk = [], [], [], 0
+        segs, keep, crcs, nblk, start = [], [], [], 0, 0
         for r in range(world):
-            eng = sharded.DeviceEngine(ctx, d_in, n, d_out, slab, resident=sharded.resident_bytes(n, r, world))
-            _, b0, b1 = sharded.own_blocks(eng, r, world)
+            lo, hi = sharded.resident_range(n, r, world)
+            assert hi - lo <= (sharded.offsets(n, world)[r + 1] - lo) + (64 << 20)
+            d_r = torch.zeros(hi - lo + 16, dtype=torch.uint8, device=dev)
+            d_r[:hi - lo] = d_in[lo:hi]
+            eng = sharded.DeviceEngine(ctx, d_r, n, d_out, slab, resident=hi - lo, lo=lo)
+            eng.tables()
+            _, b0, b1, start = sharded.own_blocks(eng, r, world, start)
             part, nbits = eng.encode_range(b0, b1)
             keep.append(part[:(nbits + 31) // 32 * 4 + 4].clone())
             segs.append((keep[-1], nbits))
             crcs += eng.crcs(b0, b1)
             nblk += b1 - b0
-            del eng
-        assert nblk == len(blocks) and crcs == [b[3] for b in blocks]
+            del eng, d_r
+        assert start == n and nblk == len(blocks) and crcs == [b[3] for b in blocks]
         d_out.zero_()
         eng = sharded.DeviceEngine(ctx, d_in, n, d_out, 16)
         ln3 = eng.assemble(segs, crcs)

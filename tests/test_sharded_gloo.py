@@ -27,27 +27,36 @@ def _strip_framing(stream):
 
 
 class OracleEngine:
-    def __init__(self, oracle, data, level, cap):
+    def __init__(self, oracle, data, level, cap, lo=0, resident=None):
         self.o, self.data, self.level, self.cap = oracle, data, level, cap
         self.n = len(data)
+        self.lo = lo
+        self.resident = self.n - lo if resident is None else resident
         self.min_block = (100000 * level - 1) * 4 // 5
         self.stream = None
+        self.times = {}
+        self.blocks = []
         _, infos = self.o.encode(self.data, self.level, want_blocks=True)
         self.full = [(int(b.in_off), int(b.in_len), int(b.rle_len), int(b.crc)) for b in infos]
 
-    def plan(self, prefix):
-        """what a splitter that only sees data[:prefix] can know: the blocks that end inside the prefix are
-        exact; whatever is left forms one more block whose cut is still open.  Like the device engine, hand
-        out the cuts without CRCs (a rank only knows the CRCs of the blocks it encodes)."""
-        if prefix >= self.n:
-            self.blocks = list(self.full)
+    def tables(self):
+        pass
+
+    def split(self, start, stop=None):
+        """what a splitter that only sees data[lo : lo + resident] can know when it starts at `start`: the blocks that
+        end inside those bytes are exact; whatever is left forms one more block whose cut is still open.  Like the
+        device engine, hand out the cuts without CRCs (a rank only knows the CRCs of the blocks it encodes)."""
+        assert start in [b[0] for b in self.full], "the chain handed over something that is not a block start"
+        end_seen = self.lo + self.resident
+        if end_seen >= self.n:
+            self.blocks = [b for b in self.full if b[0] >= start]
             return [(o, ln, r, 0) for o, ln, r, _ in self.blocks], [False] * len(self.blocks)
-        self.blocks = [b for b in self.full if b[0] + b[1] <= prefix]
+        self.blocks = [b for b in self.full if b[0] >= start and b[0] + b[1] <= end_seen]
         flags = [False] * len(self.blocks)
-        end = self.blocks[-1][0] + self.blocks[-1][1] if self.blocks else 0
+        end = self.blocks[-1][0] + self.blocks[-1][1] if self.blocks else start
         out = [(o, ln, r, 0) for o, ln, r, _ in self.blocks]
-        if end < prefix:
-            out.append((end, prefix - end, 0, 0))
+        if end < end_seen:
+            out.append((end, end_seen - end, 0, 0))
             flags.append(True)
         return out, flags
 
@@ -82,8 +91,10 @@ def _worker(rank, world, port, data, level, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from banzai_amd import sharded
     from oracle import pyoracle
-    sharded.MARGIN = 30_000  # small look-ahead: forces prefix plans and, on long runs, the margin to grow
-    eng = OracleEngine(pyoracle, data, level, cap=len(data) + 4096)
+    # every rank holds its own range plus a look-ahead only (long runs need a long one: a block inside a run of
+    # 70,000 equal bytes eats them all)
+    lo, hi = sharded.resident_range(len(data), rank, world, lookahead=400_000)
+    eng = OracleEngine(pyoracle, data, level, cap=len(data) + 4096, lo=lo, resident=hi - lo)
     n = sharded.encode_sharded(eng, dist, rank, world)
     if rank == 0:
         q.put((n, eng.stream))
@@ -153,36 +164,42 @@ def test_failure_on_one_rank_raises_on_all(oracle):
     assert "rank(s) [1]" in got[0] and "rank(s) [1]" in got[1] and "slab too small" in got[1]
 
 
-def test_resident_prefix_and_slab_sizes():
+def test_resident_range_and_slab_sizes():
     from banzai_amd import sharded
     n = 800_000_000
     b = sharded.offsets(n, 8)
     for r in range(8):
-        res = sharded.resident_bytes(n, r, 8)
-        assert res == n if r == 7 else res == min(n, b[r + 1] + (64 << 20))
-    assert sharded.resident_bytes(n, 0, 8) < n // 4  # rank 0 holds its own range + look-ahead, not the stream
+        lo, hi = sharded.resident_range(n, r, 8)
+        assert lo == b[r] and hi == min(n, b[r + 1] + (64 << 20))
+        # a rank holds its own range plus the look-ahead, never a prefix of the stream
+        assert sharded.resident_bytes(n, r, 8) <= (b[r + 1] - b[r]) + (64 << 20)
+    assert max(sharded.resident_bytes(n, r, 8) for r in range(8)) < n // 4
     assert sharded.worst_case_slab(n, 8) >= (max(b[k + 1] - b[k] for k in range(8)) * 5) // 4
 
 
-def test_offset_ownership_covers_every_block_once(oracle):
-    """own_blocks over all ranks, each from its own prefix plan, tiles the whole-input plan exactly"""
+def test_chained_ownership_covers_every_block_once(oracle):
+    """the chain of own_blocks calls, every rank seeing only its own range plus a look-ahead, tiles the
+    whole-input plan exactly; a look-ahead that cannot settle the last cut is refused, not guessed"""
     from banzai_amd import sharded
-    old = sharded.MARGIN
-    sharded.MARGIN = 20_000
-    try:
-        for mode, n in (("text", 1_234_567), ("longruns", 900_000), ("same", 400_000), ("random", 50)):
-            data = cases.gen(n, mode, 5)
-            eng = OracleEngine(oracle, data, 1, cap=16)
-            for world in (1, 2, 3, 5, 8):
-                b = sharded.offsets(n, world)
-                assert b[0] == 0 and b[-1] == n and all(b[k] <= b[k + 1] for k in range(world))
-                got = []
-                for r in range(world):
-                    blocks, b0, b1 = sharded.own_blocks(eng, r, world)
-                    got += [blk[:3] for blk in blocks[b0:b1]]
-                assert got == [blk[:3] for blk in eng.full], (mode, world)
-    finally:
-        sharded.MARGIN = old
+    for mode, n in (("text", 1_234_567), ("longruns", 900_000), ("same", 400_000), ("random", 50)):
+        data = cases.gen(n, mode, 5)
+        full = OracleEngine(oracle, data, 1, cap=16)
+        for world in (1, 2, 3, 5, 8):
+            b = sharded.offsets(n, world)
+            assert b[0] == 0 and b[-1] == n and all(b[k] <= b[k + 1] for k in range(world))
+            got, start = [], 0
+            for r in range(world):
+                # (a level-1 block inside long runs eats up to 5.1 MB of input: those inputs are held to their end)
+                lo, hi = sharded.resident_range(n, r, world, lookahead=450_000 if mode in ("text", "random") else n)
+                eng = OracleEngine(oracle, data, 1, cap=16, lo=lo, resident=hi - lo)
+                blocks, b0, b1, start = sharded.own_blocks(eng, r, world, start)
+                got += [blk[:3] for blk in blocks[b0:b1]]
+            assert start == n and got == [blk[:3] for blk in full.full], (mode, world)
+    data = cases.gen(900_000, "longruns", 5)  # blocks inside runs of 70,000 bytes: 10 kB of look-ahead settle nothing
+    lo, hi = sharded.resident_range(len(data), 0, 4, lookahead=10_000)
+    eng = OracleEngine(oracle, data, 1, cap=16, lo=lo, resident=hi - lo)
+    with pytest.raises(sharded.ShardError):
+        sharded.own_blocks(eng, 0, 4, 0)
 
 
 def test_block_range_partition():
