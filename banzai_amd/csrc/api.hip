@@ -171,6 +171,33 @@ static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
     return (size_t)(p - base);
 }
 
+// Makes the arena hold batches of `blocks` blocks (at most max_batch).  It only ever grows: to the size asked for,
+// rounded up so that a stream of growing batches does not reallocate every time.  Nothing is in flight on the
+// arena when this is called (every entry point waits for its own work before it returns).
+static int ensure_arena(bzh_ctx *ctx, uint32_t blocks, size_t min_bytes = 0)
+{
+    blocks = std::max<uint32_t>(1, std::min<uint32_t>(blocks, ctx->max_batch));
+    if (ctx->arena && blocks <= ctx->arena_blocks && min_bytes <= ctx->arena_size) return BZH_OK;
+    uint32_t want = std::min<uint32_t>(ctx->max_batch, std::max<uint32_t>(blocks, 8));
+    if (want > 8) want = std::min<uint32_t>(ctx->max_batch, (want + 15u) & ~15u);
+    Batch probe{};
+    const size_t bytes = std::max(layout_batch(probe, nullptr, want, ctx->M), min_bytes);
+    if (ctx->arena) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        hipFree(ctx->arena);
+        ctx->arena = nullptr;
+        ctx->arena_blocks = 0;
+    }
+    if (hipMalloc((void **)&ctx->arena, bytes) != hipSuccess) {
+        bzh_set_error(ctx, "hipMalloc(%zu) for a %u-block workspace failed", bytes, want);
+        return BZH_E_NOMEM;
+    }
+    ctx->arena_size = bytes;
+    ctx->arena_blocks = want;
+    layout_batch(ctx->bt, ctx->arena, want, ctx->M);
+    return BZH_OK;
+}
+
 extern "C" int bzh_create(bzh_ctx **out, int device, int level, int max_batch)
 {
     return bzh_guard(nullptr, [&]() -> int {
@@ -190,22 +217,19 @@ extern "C" int bzh_create(bzh_ctx **out, int device, int level, int max_batch)
     ctx->max_batch = max_batch ? (uint32_t)max_batch : std::min<uint32_t>(1024u, 128u * 9u / (uint32_t)level);
     // a streaming pass is worth launching once a full batch of input is pending
     ctx->strm.min_feed = std::min<size_t>((size_t)128 << 20, (size_t)ctx->max_batch * (ctx->M + 1));
-    Batch probe{}, probe2{};
-    ctx->arena_size = layout_batch(probe, nullptr, ctx->max_batch, ctx->M);
-    // the same memory also serves as two half-batch arenas (lanes, see ensure_lanes)
-    ctx->arena_size = std::max(ctx->arena_size, 2 * layout_batch(probe2, nullptr, std::max<uint32_t>(1, ctx->max_batch / 2), ctx->M));
+    Batch probe{};
+    (void)layout_batch(probe, nullptr, 1, ctx->M);
     if (probe.TPB > 1024 || ctx->max_batch > 1024) {
         delete ctx;
         return BZH_E_ARG;
     }
-    if (hipMalloc((void **)&ctx->arena, ctx->arena_size) != hipSuccess) {
-        delete ctx;
-        return BZH_E_NOMEM;
-    }
-    layout_batch(ctx->bt, ctx->arena, ctx->max_batch, ctx->M);
-    ctx->S = ctx->bt.S;
+    // The workspace arena (about 45 MB per block of a batch, 5.8 GB for 128 level-9 blocks) is NOT allocated here:
+    // ensure_arena sizes it for the batches actually planned, so a 1 MB file does not pay for a 128-block arena.
+    ctx->S = probe.S;
+    ctx->bt.S = probe.S;
+    ctx->bt.TPB = probe.TPB;
+    ctx->bt.M = ctx->M;
     if (hipHostMalloc((void **)&ctx->h_pinned, sizeof(uint32_t) * (ctx->max_batch * 8 + 64 + MAX_ROUNDS * SUMMARY_WORDS), hipHostMallocCoherent) != hipSuccess) {
-        hipFree(ctx->arena);
         delete ctx;
         return BZH_E_NOMEM;
     }
@@ -224,7 +248,12 @@ extern "C" void bzh_destroy(bzh_ctx *ctx)
     } catch (...) {
     }
     hipSetDevice(ctx->device);
-    hipDeviceSynchronize();
+    // only this context's work has to end (other contexts of the device keep running): its stream, the lanes'
+    // streams, the streaming copy stream
+    hipStreamSynchronize(ctx->stream);
+    for (bzh_ctx *l : ctx->lanes)
+        if (l->stream) hipStreamSynchronize(l->stream);
+    if (ctx->strm.copy_stream) hipStreamSynchronize(ctx->strm.copy_stream);
     for (hipEvent_t e : ctx->evpool) hipEventDestroy(e);
     for (bzh_ctx *l : ctx->lanes) {
         for (hipEvent_t e : l->evpool) hipEventDestroy(e);
@@ -375,6 +404,7 @@ extern "C" int bzh_bwt_batch(bzh_ctx *ctx, const uint8_t *in, const uint64_t *of
     if (!ctx || !in || !offs || !lens || !bwt_out || !ptr || !has_byte) return BZH_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     stats_begin(ctx);
+    BZH_TRY(ensure_arena(ctx, (uint32_t)std::min<size_t>(nblk, ctx->max_batch)));
     Batch &bt = ctx->bt;
     for (size_t k0 = 0; k0 < nblk; k0 += ctx->max_batch) {
         uint32_t B = (uint32_t)std::min<size_t>(ctx->max_batch, nblk - k0);
@@ -432,6 +462,7 @@ extern "C" int bzh_unbwt_batch(bzh_ctx *ctx, const uint8_t *bwt, const uint64_t 
     if (ctx) stream_join(ctx);
     if (!ctx || !bwt || !offs || !lens || !ptr || !out) return BZH_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    BZH_TRY(ensure_arena(ctx, (uint32_t)std::min<size_t>(nblk, ctx->max_batch)));
     Batch &bt = ctx->bt;
     for (size_t k0 = 0; k0 < nblk; k0 += ctx->max_batch) {
         const uint32_t B = (uint32_t)std::min<size_t>(ctx->max_batch, nblk - k0);
@@ -468,6 +499,7 @@ extern "C" int bzh_bwt_roundtrip_device(bzh_ctx *ctx, size_t b0, size_t b1, uint
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     ctx->evnext = 0; // (the pool is reused from the start by every entry point that takes events)
+    BZH_TRY(ensure_arena(ctx, (uint32_t)std::min<size_t>(b1 - b0, ctx->max_batch)));
     unsigned long long *d_acc = ctx->bt.stat_A; // (the forward sort has read it back by the time it is reused)
     unsigned long long total = 0;
     for (size_t k0 = b0; k0 < b1; k0 += ctx->max_batch) {
@@ -502,6 +534,7 @@ extern "C" int bzh_mtf(bzh_ctx *ctx, const uint8_t *bwt, size_t n, const uint8_t
     if (!ctx || !bwt || !has_byte || !syms || !m || !freqs || !num_syms || n == 0 || n > ctx->M) return BZH_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     stats_begin(ctx);
+    BZH_TRY(ensure_arena(ctx, 1));
     Batch &bt = ctx->bt;
     hipStream_t st = ctx->stream;
     uint32_t n32 = (uint32_t)n;
@@ -546,6 +579,7 @@ extern "C" int bzh_huffman(bzh_ctx *ctx, const uint16_t *syms, size_t m, uint32_
         ~ModeGuard() { c->mode = keep; }
     } guard{ctx, ctx->mode};
     ctx->mode = BZH_MODE_REFERENCE;
+    BZH_TRY(ensure_arena(ctx, 1));
     Batch &bt = ctx->bt;
     hipStream_t st = ctx->stream;
     const uint32_t m32 = (uint32_t)m;
@@ -662,7 +696,7 @@ static int ensure_lanes(bzh_ctx *ctx)
     const uint32_t lane_mb = std::max<uint32_t>(1, ctx->max_batch / 2);
     Batch probe{};
     const size_t half = layout_batch(probe, nullptr, lane_mb, ctx->M);
-    if (2 * half > ctx->arena_size) return BZH_E_NOMEM; // bzh_create sizes the arena for both views
+    BZH_TRY(ensure_arena(ctx, ctx->max_batch, 2 * half)); // the lanes share the full-size arena, half each
     for (int k = 0; k < 2; k++) {
         bzh_ctx *l = new (std::nothrow) bzh_ctx();
         if (!l) return BZH_E_NOMEM;
@@ -740,6 +774,7 @@ static int encode_range(bzh_ctx *ctx, size_t b0, size_t b1, uint8_t *d_out, size
     size_t njobs = (nb + lane_mb - 1) / lane_mb;
     if (njobs < NL && nb >= NL) njobs = NL; // give every lane work
     const size_t per = (nb + njobs - 1) / njobs;
+    if (NL == 1) BZH_TRY(ensure_arena(ctx, (uint32_t)per));
     std::vector<std::unique_ptr<RangeJob>> jobs;
     for (size_t k0 = b0; k0 < b1; k0 += per) {
         auto j = std::make_unique<RangeJob>();
@@ -1143,6 +1178,7 @@ extern "C" int bzh_rle1_split(bzh_ctx *ctx, const uint8_t *in, size_t n, bzh_blo
     for (size_t k = 0; k < nb; k++) blocks[k] = ctx->plan_blocks[k];
     if (rle_out) {
         size_t pos = 0;
+        BZH_TRY(ensure_arena(ctx, (uint32_t)std::min<size_t>(nb, ctx->max_batch)));
         Batch &bt = ctx->bt;
         for (size_t k0 = 0; k0 < nb; k0 += ctx->max_batch) {
             const uint32_t B = (uint32_t)std::min<size_t>(ctx->max_batch, nb - k0);
@@ -1168,6 +1204,7 @@ extern "C" int bzh_crc32(bzh_ctx *ctx, const uint8_t *in, size_t n, uint32_t *cr
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     BZH_TRY(ensure_stage(ctx, ctx->d_stage_in, ctx->stage_in_size, n + 16));
     if (n) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage_in, in, n, hipMemcpyHostToDevice, ctx->stream));
+    BZH_TRY(ensure_arena(ctx, 1)); // (crc_device borrows two words of it)
     return crc_device(ctx, ctx->d_stage_in, n, crc);
     });
 }

@@ -1787,7 +1787,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     u64 *bufA = reinterpret_cast<u64 *>(bt.listA), *bufB = reinterpret_cast<u64 *>(bt.listB);
     u64 *bufC = reinterpret_cast<u64 *>(bt.listC), *bufD = reinterpret_cast<u64 *>(bt.listD);
     const Lst all{nullptr, nullptr, B};
-    uint32_t *actP = bt.actQ + mb; // sixth list, behind the five named ones (the layout leaves 21 rows)
+    uint32_t *actP = bt.actQ + bt.B; // sixth list, behind the five named ones (rows of the layout are bt.B apart)
 
     SortArgs a{};
     a.blk = bt.rle;

@@ -176,6 +176,7 @@ struct bzh_ctx {
     // arena
     uint8_t *arena = nullptr;
     size_t arena_size = 0;
+    uint32_t arena_blocks = 0;        // blocks per batch the arena is laid out for (ensure_arena, api.hip)
     Batch bt{};
     // plan
     const uint8_t *plan_in = nullptr; // device
