@@ -141,6 +141,7 @@ static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
         bt.summary = rs ? rs + 21 * NB + 8 : nullptr;
         bt.stat_A = rs ? reinterpret_cast<unsigned long long *>(rs + oA) : nullptr;
     }
+    carve(p, bt.chain, NB * 4);
     carve(p, bt.errflag, 64);
     carve(p, bt.mtfpos, NB * S);
     carve(p, bt.tilelist, NB * MT * 256);

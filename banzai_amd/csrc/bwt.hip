@@ -112,6 +112,8 @@ struct SortArgs {
     uint32_t pass;         // id of this pass in the status words (stale words read as "not there yet")
     uint32_t tag;          // id of the round in the rank words (rank_at)
     u64 *gst;              // [B][TPB][2] tile status words of GEN_GID's look-back
+    const uint32_t *chain; // [B][4] near-periodic blocks (period_probe): flags, period, tails that lead the order
+    const uint32_t *clist; // [B][2S] those tails, then the other tails, ascending (the block's listD)
 };
 
 constexpr int NBMAX = 256;
@@ -212,6 +214,14 @@ __device__ __forceinline__ bool gen_elem(const SortArgs &a, uint32_t b, uint32_t
             return true;
         }
         i = n - 1 - e; // identical rotations: larger index first; e doubles as a distinct key2
+        const uint32_t cf = a.chain[b * 4];
+        if (cf & 1u) { // near-periodic block: every group is a chain ordered by (effective) index, see period_probe
+            const uint32_t p = a.chain[b * 4 + 1], c2 = a.chain[b * 4 + 2];
+            const uint32_t q = (cf & 2u) ? e : n - 1 - e; // ascending / descending
+            const uint32_t *cl = a.clist + (size_t)b * a.S * 2;
+            const uint32_t inner = n - p + 1; // indices 0 .. n-p are no tails
+            i = q < c2 ? cl[q] : (q - c2 < inner ? q - c2 : cl[p + (q - c2 - inner)]);
+        }
         const uint32_t r = a.rank[base + rslot(i)];
         if (r & RANK_RESOLVED) return false;
         v = ((u64)rank_at(r, a.tag) << 40) | ((u64)e << 20) | i;
@@ -1509,6 +1519,160 @@ __global__ void __launch_bounds__(256) bwt_emit(Batch bt, uint32_t T, uint32_t B
     if (seen[threadIdx.x]) bt.hasbyte[(size_t)b * 256 + threadIdx.x] = 1;
 }
 
+// ---- near-periodic blocks --------------------------------------------------------------------------------------
+// A block that is a word w repeated, cut off inside a repetition (S = w^k w', |w| = p, 0 < |w'| = r < p: a tile
+// laid over and over, "abab...a", what RLE1 leaves of one enormous run), keeps prefix doubling busy for log2(n)
+// rounds over nearly all its suffixes: rotations i and i + p agree for n - i - p characters.  But their order is
+// known.  S[u] = w[u mod p] for every u < n, so two members x < y of a group with x = y (mod p) agree until y
+// wraps around (offset n - y); from there x reads w from phase r and y from phase 0, which differ at the same
+// offset d0 < p for EVERY such pair (w is primitive, r != 0): either every such x sorts before its y or every one
+// after it.  A rotation a of the last p - 1 that has wrapped inside the group's depth (n - a <= h) can also sit in
+// the group of the phase it reads after the wrap; it then behaves like index a - n (it is the one that keeps
+// reading).  So if every group of the block is such a chain -- checked over adjacent members in SA order -- the
+// block is finished in ONE round keyed on the (effective) index, ascending or descending.
+// One workgroup per SWEEP-mode block, every round until it fires: candidate period = smallest positive member of
+// suffix 0's group (at most the true period; a smaller candidate is no period and fails the check), verified
+// against the text byte by byte; direction from w; chain check; the tails that lead the order (effective index
+// below 0) and the others go, ascending, into two lists for GEN_SWEEP.  Exactly periodic blocks (r = 0) are left
+// to the "nothing was refined" rule of round_begin.
+struct ProbeArgs {
+    const uint8_t *blk;
+    const uint32_t *n;
+    const uint32_t *rank, *sa, *headp;
+    uint32_t *st_h;
+    uint32_t *chain; // [B][4]
+    uint32_t *clist; // [B][2S]
+    uint8_t *tflag;  // [B][S] scratch: tail rotation leads the order
+    uint32_t S;
+    Lst lst;
+};
+
+__global__ void __launch_bounds__(1024) period_probe(ProbeArgs a)
+{
+    const uint32_t kb = blockIdx.x;
+    if (kb >= (a.lst.ids ? *a.lst.cnt : a.lst.B)) return;
+    const uint32_t b = a.lst.ids ? a.lst.ids[kb] : kb;
+    const uint32_t n = a.n[b], h = a.st_h[b];
+    const size_t base = (size_t)b * a.S;
+    const uint8_t *s = a.blk + base;
+    const uint32_t *sa = a.sa + base, *headp = a.headp + base;
+    uint32_t *cl = a.clist + base * 2;
+    uint8_t *tf = a.tflag + base;
+    __shared__ uint32_t sh_min, sh_bad, sh_d0;
+    __shared__ uint32_t ls[1024 / 64 + 2];
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) {
+        a.chain[b * 4] = 0;
+        sh_min = 0xFFFFFFFFu;
+        sh_bad = 0;
+        sh_d0 = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    if (h >= H_DONE || n < 16) return;
+    const uint32_t w0 = a.rank[base + rslot(0)];
+    if (w0 & RANK_RESOLVED) return;
+    const uint32_t head = w0 & 0xFFFFFu;
+    // 1. candidate: the smallest positive member of suffix 0's group (SA positions head .. while the head stays)
+    {
+        uint32_t mn = 0xFFFFFFFFu;
+        for (uint32_t e = head + tid; e < n && headp[e] == head; e += 1024) {
+            const uint32_t i = sa[e];
+            if (i > 0) mn = min(mn, i);
+        }
+        if (mn != 0xFFFFFFFFu) atomicMin(&sh_min, mn);
+    }
+    __syncthreads();
+    const uint32_t p = sh_min;
+    if (p == 0xFFFFFFFFu || 2ull * p > n) return;
+    const uint32_t r = n % p;
+    if (r == 0) return;
+    // 2. is p a period of the text?  (S[u] == S[u + p] for every u < n - p)
+    {
+        bool bad = false;
+        for (uint32_t u = tid; u < n - p && !bad; u += 1024) bad = s[u] != s[u + p];
+        if (bad) sh_bad = 1;
+    }
+    __syncthreads();
+    if (sh_bad) return;
+    // 3. direction: first d with w[(r + d) mod p] != w[d]
+    {
+        for (uint32_t d = tid; d < p; d += 1024) {
+            uint32_t x = r + d;
+            if (x >= p) x -= p;
+            if (s[x] != s[d]) {
+                atomicMin(&sh_d0, d);
+                break;
+            }
+        }
+    }
+    // flags of the tail rotations n-p+1 .. n-1 (slot a - (n-p+1)): tf[k] = leads the order, tf[p + k] = has a plainly
+    // congruent neighbour (2p <= n <= S)
+    for (uint32_t k = tid; k < 2 * p; k += 1024) tf[k] = 0;
+    __syncthreads();
+    const uint32_t d0 = sh_d0;
+    if (d0 == 0xFFFFFFFFu) return; // (cannot happen for a minimal period with r != 0)
+    const uint32_t xr = r + d0 >= p ? r + d0 - p : r + d0;
+    const bool asc = s[xr] < s[d0]; // the rotation that keeps reading (smaller index) is the smaller one
+    // 4. every group a chain?  adjacent members x, y of a group: x = y (mod p), or one of them a wrapped tail whose
+    //    effective index (a - n) is congruent to the other
+    const uint32_t tail0 = n - p + 1;
+    {
+        bool bad = false;
+        for (uint32_t e = 1 + tid; e < n; e += 1024) {
+            if (headp[e] != headp[e - 1]) continue;
+            const uint32_t x = sa[e - 1], y = sa[e];
+            const uint32_t mx = x % p, my = y % p;
+            if (mx == my) {
+                if (x >= tail0) tf[p + x - tail0] = 1;
+                if (y >= tail0) tf[p + y - tail0] = 1;
+                continue;
+            }
+            // x - n = x + (p - r) (mod p)
+            const bool xt = x >= tail0 && n - x <= h, yt = y >= tail0 && n - y <= h;
+            const uint32_t ex = (mx + p - r) % p, ey = (my + p - r) % p;
+            if (xt && !(y >= tail0) && ex == my) {
+                tf[x - tail0] = 1;
+            } else if (yt && !(x >= tail0) && ey == mx) {
+                tf[y - tail0] = 1;
+            } else {
+                bad = true;
+                break;
+            }
+        }
+        if (bad) sh_bad = 1;
+    }
+    __syncthreads();
+    if (sh_bad) return;
+    // a leading tail must not ALSO have a plainly congruent neighbour (its group would mix two phases through it)
+    {
+        bool bad = false;
+        for (uint32_t k = tid; k < p - 1 && !bad; k += 1024) bad = tf[k] && tf[p + k];
+        if (bad) sh_bad = 1;
+    }
+    __syncthreads();
+    if (sh_bad) return;
+    // 5. the tails in two ascending lists: leaders at cl[0 ..), the others at cl[p ..)
+    uint32_t c2 = 0, c1 = 0;
+    for (uint32_t k0 = 0; k0 < p - 1; k0 += 1024) {
+        const uint32_t k = k0 + tid;
+        const bool valid = k < p - 1;
+        const bool lead = valid && tf[k] != 0;
+        uint32_t t2, t1;
+        const uint32_t o2 = block_excl_add(lead ? 1u : 0u, ls, &t2);
+        const uint32_t o1 = block_excl_add(valid && !lead ? 1u : 0u, ls, &t1);
+        if (lead) cl[c2 + o2] = tail0 + k;
+        if (valid && !lead) cl[p + c1 + o1] = tail0 + k;
+        c2 += t2;
+        c1 += t1;
+    }
+    if (tid == 0) {
+        a.chain[b * 4 + 1] = p;
+        a.chain[b * 4 + 2] = c2;
+        a.chain[b * 4] = 1u | (asc ? 2u : 0u);
+        a.st_h[b] = H_DONE;
+    }
+}
+
 // ---- round bookkeeping on the device ---------------------------------------------------------------
 // One workgroup, one thread per block.  Consumes the counters the previous round left (c_big, c_small,
 // c_tail, c_prog; after the initial refine: `first`), decides every block's mode and depth, builds this
@@ -1811,6 +1975,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     a.lst = all;
     a.shift = 20;
     a.gst = reinterpret_cast<u64 *>(bt.tagg); // (flag_tiles / flag_carry use it after the initial sort only)
+    a.chain = bt.chain;
+    a.clist = reinterpret_cast<const uint32_t *>(bt.listD); // (a block in SWEEP mode has no small-group lists)
     a.src = nullptr;
     a.dst = bufA;
     a.look = reinterpret_cast<u64 *>(bt.hist);
@@ -1973,6 +2139,12 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             r0.cpass = ++a.pass;
             r0.lst = Lst{bt.actS, bt.nlist + L_S, B};
             launch_refine(ctx, r0, nS, nmax, true);
+        }
+        {
+            // near-periodic blocks are finished in this round (period_probe sets their depth to "h >= n")
+            ProbeArgs pr{bt.rle, bt.n, bt.rank, bt.sa, bt.headp, bt.st_h, bt.chain, reinterpret_cast<uint32_t *>(bt.listD),
+                         bt.flg, bt.S, Lst{bt.actS, bt.nlist + L_S, B}};
+            period_probe<<<dim3(nS), 1024, 0, st>>>(pr);
         }
         a.lst = Lst{bt.actS, bt.nlist + L_S, B};
         a.cnt = bt.n; // enumerate SA positions

@@ -98,6 +98,7 @@ struct Batch {
     uint32_t *c_nolist; // produced by a round: refine did not write the block's lists (SWEEP mode, mostly large groups)
     uint32_t *c_groups; // groups of the block after the initial sort (refine_one<init>; round_begin picks the first mode)
     uint32_t *scratch;  // a row nobody reads
+    uint32_t *chain;    // [B][4] near-periodic blocks: flags, period, leading tails (period_probe, bwt.hip)
     uint32_t *gateS, *gateA, *gateR, *gateT;     // this round: sorted-list length per path (0 = not on that path)
     uint32_t *actS, *actA, *actR, *actT, *actQ;  // this round: ids of the blocks on each path (Q: TAIL at depth x4)
     uint32_t *nlist;    // [8] lengths of those lists (S, A, R, T, Q)

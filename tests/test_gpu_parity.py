@@ -734,3 +734,39 @@ def test_streaming_public_api_chunked_reader(oracle):
     w = io.BytesIO()
     assert banzai_amd.encode(Dribble(d), w, 9) == len(d)
     assert w.getvalue() == oracle.encode(d, 9)
+
+
+def test_near_periodic_blocks_vs_oracle(oracle, ctx9):
+    """BASELINE config 5, the near-periodic part: a word repeated and cut off inside a repetition (periods 2, 3, 1024,
+    4099; lengths 899,999 / 899,998 / 450,000), plus words whose own structure mixes phases in the early groups, words
+    with a damaged repetition (no period: the probe must refuse) and exactly periodic blocks: last column and origin
+    pointer equal the oracle's"""
+    rng = np.random.default_rng(99)
+    blocks = []
+    for p in (2, 3, 1024, 4099):
+        w = rng.integers(0, 256, p, dtype=np.uint8)
+        while p > 1 and len(set(w.tolist())) < 2:
+            w = rng.integers(0, 256, p, dtype=np.uint8)
+        for n in (899_999, 899_998, 450_000):
+            blocks.append(np.tile(w, n // p + 1)[:n].tobytes())
+    # "ab" x 500 + "cd": the first groups hold many phases of the word
+    w = np.frombuffer(b"ab" * 500 + b"cd", dtype=np.uint8)
+    blocks.append(np.tile(w, 900)[:899_999].tobytes())
+    # a low-entropy word: 8-byte prefixes recur inside it
+    w = rng.integers(0, 2, 777, dtype=np.uint8) + 97
+    blocks.append(np.tile(w, 1200)[:899_999].tobytes())
+    blocks.append(np.tile(w, 1200)[:777 * 1000].tobytes())  # exactly periodic
+    # one damaged byte in the middle / near the end: not periodic any more
+    w = rng.integers(0, 256, 1024, dtype=np.uint8)
+    d = np.tile(w, 880)[:899_999].copy()
+    d[450_000] ^= 1
+    blocks.append(d.tobytes())
+    d = np.tile(w, 880)[:899_999].copy()
+    d[899_990] ^= 1
+    blocks.append(d.tobytes())
+    # what RLE1 leaves of one long run: "aaaa" + count, period 5
+    blocks.append((b"\0\0\0\0\xfb" * 180_000)[:899_999])
+    got = ctx9.bwt_batch(blocks)
+    for k, blk in enumerate(blocks):
+        bw, ptr, _ = oracle.bwt(blk)
+        assert got[k][0] == bw and got[k][1] == ptr, (k, len(blk))
