@@ -61,6 +61,7 @@ SIGNATURES = {
     "bzh_set_lanes": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "bzh_set_mode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "bzh_get_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Stats)]),
+    "bzh_debug_fault": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "bzh_get_kernel_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(KStat), ctypes.c_size_t, szp]),
     "bzh_encode": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_size_t, u8p, ctypes.c_size_t, szp, szp]),
     "bzh_encode_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
@@ -182,6 +183,9 @@ class Context:
         s = Stats()
         self.check(lib().bzh_get_stats(self._h, ctypes.byref(s)))
         return s.as_dict()
+
+    def debug_fault(self, kind):
+        self.check(lib().bzh_debug_fault(self._h, kind))
 
     def kernel_stats(self):
         """Per-kernel-class (name, ms, launches, algorithmic bytes) of the last call made with profiling on."""

@@ -114,6 +114,7 @@ struct SortArgs {
     u64 *gst;              // [B][TPB][2] tile status words of GEN_GID's look-back
     const uint32_t *chain; // [B][4] near-periodic blocks (period_probe): flags, period, tails that lead the order
     const uint32_t *clist; // [B][2S] those tails, then the other tails, ascending (the block's listD)
+    uint32_t fault;        // test hook (bzh_debug_fault): 1 = tile 1 of block 0 never publishes its digit counts
 };
 
 constexpr int NBMAX = 256;
@@ -151,6 +152,18 @@ __device__ __forceinline__ bool wg_map(uint32_t T, const Lst &l, uint32_t &b, ui
 static inline uint32_t xcd_grid(uint32_t tiles, uint32_t NB)
 {
     return (tiles & WG_SPREAD) ? (tiles & ~WG_SPREAD) * NB : 8u * ((NB + 7u) / 8u) * tiles;
+}
+
+// The host sizes every launch of a round from a summary that is one round old (bounds, see bwt_run).  A launch that
+// turned out too small would silently skip blocks or tiles; this makes it loud instead (bit 2 of the error word):
+// workgroup 0 compares the list length with the blocks the grid covers, every block's first tile compares the tiles
+// it needs with the tiles launched.
+__device__ __forceinline__ void launch_check(uint32_t T, const Lst &l, uint32_t tile, uint32_t need_tiles, uint32_t *err)
+{
+    if (threadIdx.x != 0) return;
+    const uint32_t tl = T & ~WG_SPREAD;
+    if (blockIdx.x == 0 && (l.ids ? *l.cnt : l.B) > gridDim.x / tl) atomicOr(err, 4u);
+    if (tile == 0 && need_tiles > tl) atomicOr(err, 4u);
 }
 
 // Where the rank of suffix i lives inside the block's rank array.  Periodic blocks visit suffixes at a
@@ -282,6 +295,7 @@ __global__ void __launch_bounds__(SORT_THREADS) active_gen(SortArgs a, uint32_t 
     if (!wg_map(a.T, a.lst, b, tile)) return;
     const uint32_t cnt = a.cnt[b], n = a.n[b], h = a.hb[b];
     const uint32_t ntile = (cnt + SORT_TILE - 1) / SORT_TILE;
+    launch_check(a.T, a.lst, tile, ntile, a.err);
     if (tile >= ntile) return;
     __shared__ uint32_t hh[5 * 256];
     for (int k = threadIdx.x; k < 5 * 256; k += SORT_THREADS) hh[k] = 0;
@@ -423,6 +437,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
     if (!wg_map(a.T, a.lst, b, tile)) return;
     const uint32_t cnt = a.cnt[b], n = a.n[b];
     const uint32_t ntile = (cnt + SORT_TILE - 1) / SORT_TILE;
+    launch_check(a.T, a.lst, tile, ntile, a.err);
     if (tile >= ntile) return;
     const uint32_t h = MODE == GEN_SWEEP ? a.hb[b] : 0u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -545,11 +560,13 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
     }
     uint32_t tile_total;
     const uint32_t ex = block_excl_add(mytot, ls, &tile_total);
+    const bool mute = a.fault == 1u && b == 0u && tile == 1u; // (test hook: this tile's successors must give up, not hang)
     if (threadIdx.x < NB) {
         const uint32_t bin = threadIdx.x;
         binstart[bin] = ex;
-        __hip_atomic_store(a.look + ((size_t)b * a.TPB + tile) * NBMAX + bin, look_word(a.pass, LOOK_LOCAL, mytot),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!mute)
+            __hip_atomic_store(a.look + ((size_t)b * a.TPB + tile) * NBMAX + bin, look_word(a.pass, LOOK_LOCAL, mytot),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t g = ex;
 #pragma unroll
         for (int w = 0; w < NW; w++) {
@@ -580,7 +597,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
             const u64 w = __hip_atomic_load(col + (size_t)t * NBMAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t state = (uint32_t)(w >> 30) & 3u;
             if ((uint32_t)(w >> 32) != a.pass || state == 0) { // predecessor has not published yet
-                if (++spins > (1u << 26)) { // seconds: only a logic error gets here
+                if (++spins > (a.fault ? 1u << 14 : 1u << 26)) { // seconds: only a logic error gets here
                     atomicOr(a.err, 2u);
                     break;
                 }
@@ -591,8 +608,9 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
             if (state == LOOK_GLOBAL) break;
             t--;
         }
-        __hip_atomic_store(col + (size_t)tile * NBMAX, look_word(a.pass, LOOK_GLOBAL, acc + mytot), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+        if (!mute)
+            __hip_atomic_store(col + (size_t)tile * NBMAX, look_word(a.pass, LOOK_GLOBAL, acc + mytot), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         goff[bin] = a.dbase[(size_t)b * DB_STRIDE + a.doff + bin] + acc;
     }
     __syncthreads();
@@ -672,6 +690,7 @@ __global__ void __launch_bounds__(SORT_THREADS) flag_tiles(RefineArgs a)
     if (!wg_map(a.T, a.lst, b, tile)) return;
     const uint32_t cnt = a.cnt[b];
     const uint32_t ntile = (cnt + SORT_TILE - 1) / SORT_TILE;
+    launch_check(a.T, a.lst, tile, ntile, a.err);
     if (tile >= ntile) return;
     const size_t base = (size_t)b * a.S;
     const u64 *list = a.list + base;
@@ -773,6 +792,7 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
     if (!wg_map(a.T, a.lst, b, tile)) return;
     const uint32_t cnt = a.cnt[b];
     const uint32_t ntile = (cnt + SORT_TILE - 1) / SORT_TILE;
+    launch_check(a.T, a.lst, tile, ntile, a.err);
     if (tile >= ntile) return;
     // a block that may enumerate SA positions next round needs SA / group heads at EVERY position and the
     // digit counts of its unresolved ranks; a SPLIT-mode block only needs the final SA entries
@@ -1076,6 +1096,7 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
     if (!wg_map(a.T, a.lst, b, tile)) return;
     const uint32_t cnt = a.cnt[b];
     const uint32_t ntile = (cnt + SORT_TILE - 1) / SORT_TILE;
+    launch_check(a.T, a.lst, tile, ntile, a.err);
     if (tile >= ntile) return;
     const size_t base = (size_t)b * a.S;
     const u64 *list = a.list + base;
@@ -1313,6 +1334,7 @@ __global__ void __launch_bounds__(TR_THREADS) tail_round(TailArgs a)
     if (!wg_map(a.T, a.lst, b, tile)) return;
     const uint32_t len = a.len[b];
     const uint32_t r0 = tile * TR_T;
+    launch_check(a.T, a.lst, tile, (len + TR_T - 1) / TR_T, a.err);
     if (r0 >= len) return;
     const uint32_t r1 = min(len, r0 + (uint32_t)TR_T);
     const uint32_t s_lo = r0 >= (uint32_t)TAIL_G ? r0 - TAIL_G : 0u;
@@ -1976,6 +1998,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     a.shift = 20;
     a.gst = reinterpret_cast<u64 *>(bt.tagg); // (flag_tiles / flag_carry use it after the initial sort only)
     a.chain = bt.chain;
+    a.fault = ctx->debug_fault; // (one batch only)
+    ctx->debug_fault = 0;
     a.clist = reinterpret_cast<const uint32_t *>(bt.listD); // (a block in SWEEP mode has no small-group lists)
     a.src = nullptr;
     a.dst = bufA;
@@ -2243,6 +2267,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             if (trace)
                 fprintf(stderr, "[bzhip] round %u h<=%u unresolved=%llu  S blocks=%u (max %u)  A blocks=%u (max %u)  T blocks=%u (quad %u, max %u)\n",
                         s[0], s[15], (unsigned long long)total, s[1], s[5], s[2], s[6], s[3], s[4], s[7]);
+            if (err) break; // a kernel reported an internal error: nothing after it can be trusted
             if (total == 0) { // nothing was left when round-1 began: it and this round_begin were no-ops
                 finished = true;
                 break;
@@ -2334,17 +2359,19 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             std::swap(cur, oth);
         }
     }
-    if (!finished) { // MAX_ROUNDS is far beyond log2(n) + the rounds queued ahead
+    if (!finished && !err) { // MAX_ROUNDS is far beyond log2(n) + the rounds queued ahead
         HIP_TRY(ctx, bzh_stream_wait(st));
         bzh_set_error(ctx, "BWT: the doubling rounds did not terminate (internal error)");
         return BZH_E_HIP;
     }
+    if (err) HIP_TRY(ctx, bzh_stream_wait(st)); // (what was queued behind the faulty kernel ends before the error is reported)
     // (the last summary read is the one of a round that found nothing to do: every kernel before it has run, so
     // its error word and its sum of unresolved suffixes are final)
     ctx->stats.bwt_active_sum += (uint64_t)s[17] | ((uint64_t)s[18] << 32);
     if (err) {
-        bzh_set_error(ctx, err & 2 ? "BWT: a look-back gave up waiting (internal error)"
-                                   : "BWT: a small-group window saw a group larger than its guarantee (internal error)");
+        bzh_set_error(ctx, err & 4   ? "BWT: a launch was sized for fewer blocks or tiles than the round had (internal error)"
+                           : err & 2 ? "BWT: a look-back gave up waiting (internal error)"
+                                     : "BWT: a small-group window saw a group larger than its guarantee (internal error)");
         return BZH_E_HIP;
     }
 

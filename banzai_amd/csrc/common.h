@@ -233,6 +233,7 @@ struct bzh_ctx {
         size_t h_out_cap = 0;
     } strm;
     bzh_stats stats{};
+    uint32_t debug_fault = 0;         // bzh_debug_fault: fault to inject into the next suffix sort
     uint32_t bwt_epoch = 0;           // calls of bwt_run so far (tags the round summaries in pinned memory)
     std::vector<hipEvent_t> evpool;
     size_t evnext = 0;

@@ -86,6 +86,10 @@ BZH_API int bzh_set_mode(bzh_ctx *ctx, int mode);
  * busy without it and 2 lanes measure the same throughput as 1; kept for experiments. */
 BZH_API int bzh_set_lanes(bzh_ctx *ctx, int lanes);
 BZH_API int bzh_get_stats(const bzh_ctx *ctx, bzh_stats *out);
+/* Test hook: inject a fault into the next suffix sort of this context (kind 1: one tile of the first block never
+ * publishes its look-back status; 0: none).  The call that runs into it returns an error status -- the waits of
+ * the look-backs are bounded -- and the context stays usable.  No counterpart in the reference. */
+BZH_API int bzh_debug_fault(bzh_ctx *ctx, int kind);
 
 /* Per-kernel-class figures of the last whole-path call made with profiling on (bench.py's `roofline.kernels`):
  * HIP-event time of the class's launches on the context's stream, launches issued, and the ALGORITHMIC bytes they

@@ -770,3 +770,57 @@ def test_near_periodic_blocks_vs_oracle(oracle, ctx9):
     for k, blk in enumerate(blocks):
         bw, ptr, _ = oracle.bwt(blk)
         assert got[k][0] == bw and got[k][1] == ptr, (k, len(blk))
+
+
+def test_lookback_give_up_is_an_error_not_a_hang(oracle, native):
+    """a tile that never publishes its look-back status (injected): the tiles behind it give up after a bounded wait,
+    the call returns an error status, and the context encodes correctly afterwards"""
+    import time
+    d = cases.gen(400_000, "text", 3)
+    with native.Context(0, 9, 8) as ctx:
+        ctx.debug_fault(1)
+        t0 = time.perf_counter()
+        with pytest.raises(native.BzhError) as ei:
+            ctx.encode(d)
+        assert time.perf_counter() - t0 < 60
+        assert "look-back gave up" in str(ei.value)
+        assert ctx.encode(d) == oracle.encode(d, 9)
+
+
+def test_stream_beyond_four_gib(native):
+    """more than 2^32 input bytes through bzh_stream_feed (the reference's encode has no length limit, lib/lib.rs:84-132;
+    one plan here has 32-bit positions, so the stream is cut into plans): 16 x 256 MiB of zeros, 64 MiB more, and a
+    text tail; libbz2 decodes the stream back to exactly that, piece by piece"""
+    import bz2
+    from banzai_amd import corpus
+    zeros = np.zeros(256 << 20, dtype=np.uint8)
+    tail = corpus.enwik_synthetic(3_000_000, seed=77)
+    total = 16 * zeros.size + (64 << 20) + tail.size
+    assert total > 1 << 32
+    out = bytearray()
+    with native.Context(0, 9, 64) as ctx:
+        ctx.stream_begin()
+        for _ in range(16):
+            out += ctx.stream_feed(zeros)
+        out += ctx.stream_feed(zeros[:64 << 20])
+        out += ctx.stream_feed(tail, eof=True)
+        assert ctx.stream_consumed() == total
+    assert bytes(out[:4]) == b"BZh9"
+    dec = bz2.BZ2Decompressor()
+    pos, nz = 0, 16 * zeros.size + (64 << 20)
+    data = bytes(out)
+    got_tail = bytearray()
+    feed = data
+    while not dec.eof:
+        piece = dec.decompress(feed, 64 << 20)
+        feed = b""
+        if not piece and dec.needs_input:
+            break
+        if pos + len(piece) <= nz:
+            assert piece.count(0) == len(piece), pos
+        else:
+            k = max(0, nz - pos)
+            assert piece[:k].count(0) == k
+            got_tail += piece[k:]
+        pos += len(piece)
+    assert dec.eof and pos == total and bytes(got_tail) == tail.tobytes()
