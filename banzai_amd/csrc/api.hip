@@ -8,6 +8,7 @@
 //   assemble: "BZh9", stream CRC fold, footer
 #include <stdarg.h>
 #include <algorithm>
+#include <atomic>
 #include <future>
 #include <memory>
 #include <mutex>
@@ -779,6 +780,7 @@ static int encode_range(bzh_ctx *ctx, size_t b0, size_t b1, uint8_t *d_out, size
     }
     const size_t NL = lanes.size();
     HIP_TRY(ctx, bzh_stream_wait(ctx->stream)); // the plan and whatever produced the input
+    const bzh_stats stats_in = ctx->stats;
     const size_t nb = b1 - b0;
     const uint32_t lane_mb = lanes[0]->max_batch;
     size_t njobs = (nb + lane_mb - 1) / lane_mb;
@@ -801,7 +803,7 @@ static int encode_range(bzh_ctx *ctx, size_t b0, size_t b1, uint8_t *d_out, size
         ctx->stats.blocks += j->B;
         jobs.push_back(std::move(j));
     }
-    bzh_stats keep = ctx->stats; // one-lane mode: the lane is ctx itself
+    bzh_stats keep = stats_in; // what the counters were before this call touched them
     for (bzh_ctx *l : lanes) {
         l->profiling = ctx->profiling;
         l->sort_spans.clear();
@@ -817,14 +819,14 @@ static int encode_range(bzh_ctx *ctx, size_t b0, size_t b1, uint8_t *d_out, size
             ctx->stats.bwt_sort_elems = 0;
         }
     }
-    (void)keep;
     // lane k prepares jobs k, k+2, ...; it may reuse its arena only after the job was packed
+    std::atomic<bool> abort{false}; // set when not every lane thread could be started: the ones that did start do nothing
     auto worker = [&](int k) {
         hipSetDevice(ctx->device);
         bool dead = false;
         for (size_t j = k; j < jobs.size(); j += NL) {
             RangeJob &job = *jobs[j];
-            job.status = dead ? BZH_E_STATE : prepare_batch(lanes[k], job);
+            job.status = (dead || abort.load()) ? BZH_E_STATE : prepare_batch(lanes[k], job);
             if (job.status != BZH_OK) dead = true;
             job.ready.set_value();
             job.packed.get_future().wait();
@@ -835,9 +837,12 @@ static int encode_range(bzh_ctx *ctx, size_t b0, size_t b1, uint8_t *d_out, size
         try {
             threads.reserve(NL);
             for (size_t k = 0; k < NL; k++) threads.emplace_back(worker, (int)k);
-        } catch (...) { // no thread to be had: release the workers that did start, then report
+        } catch (...) { // no thread to be had: release the workers that did start (they skip their jobs), then report
+            abort.store(true);
             for (auto &jp : jobs) jp->packed.set_value();
             for (auto &t : threads) t.join();
+            for (bzh_ctx *l : lanes) hipStreamSynchronize(l->stream); // (a job may have been in flight already)
+            ctx->stats = keep;
             bzh_set_error(ctx, "could not start the lane threads");
             return BZH_E_NOMEM;
         }
