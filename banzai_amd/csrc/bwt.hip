@@ -257,21 +257,30 @@ __global__ void __launch_bounds__(1024) byte_count(const uint8_t *blk, const uin
 {
     const uint32_t b = blockIdx.y, n = nn[b];
     const uint8_t *s = blk + (size_t)b * S;
-    const uint32_t per = ((n + BYTE_SEGS - 1) / BYTE_SEGS + 3u) & ~3u; // keeps the dword loads aligned
+    const uint32_t per = ((n + BYTE_SEGS - 1) / BYTE_SEGS + 15u) & ~15u; // keeps the 16-byte loads aligned
     const uint32_t lo = min(n, blockIdx.x * per), hi = min(n, lo + per);
     if (lo >= hi) return;
     __shared__ uint32_t h[16][256];
     for (int k = threadIdx.x; k < 16 * 256; k += 1024) (&h[0][0])[k] = 0;
     __syncthreads();
     uint32_t *mine = h[threadIdx.x >> 6];
-    for (uint32_t i = lo + threadIdx.x * 4; i < hi; i += 4096) {
-        if (i + 4 <= hi) {
-            uint32_t w;
-            __builtin_memcpy(&w, s + i, 4);
-            atomicAdd(&mine[w & 255u], 1u);
-            atomicAdd(&mine[(w >> 8) & 255u], 1u);
-            atomicAdd(&mine[(w >> 16) & 255u], 1u);
-            atomicAdd(&mine[w >> 24], 1u);
+    // 16 bytes a step; equal neighbours (RLE1 leaves runs of up to four, text has its doubled letters) share one add
+    for (uint32_t i = lo + threadIdx.x * 16; i < hi; i += 16384) {
+        if (i + 16 <= hi) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(s + i); // (lo and the block base are 16-byte aligned)
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+            uint32_t cur = w[0] & 255u, cnt = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t c = (w[k >> 2] >> ((k & 3) * 8)) & 255u;
+                if (c != cur) {
+                    atomicAdd(&mine[cur], cnt);
+                    cur = c;
+                    cnt = 0;
+                }
+                cnt++;
+            }
+            atomicAdd(&mine[cur], cnt);
         } else {
             for (uint32_t j = i; j < hi; j++) atomicAdd(&mine[s[j]], 1u);
         }
@@ -638,6 +647,8 @@ struct RefineArgs {
     uint32_t *mode;        // [B] st_mode (flag_carry of the init pass decides the first mode)
     u64 *cstat;          // tile status words of the compaction's look-back (word 192 of the tile's hist row)
     uint32_t cpass;      // pass id in those words
+    u64 *carry;          // refine_one: [B][TPB][2] tile status words of the carry look-back (slot 1 of a pair)
+    uint32_t bpass;      // refine_one<init>: pass id of the rank binning's status words (rows of cstat)
     uint32_t *err;       // bit 1: a look-back gave up
     const uint8_t *blk;  // [B][S] the text (init pass: low half of the 8-byte prefix is compared from it)
     uint32_t *rank;      // [B][S]
@@ -1036,20 +1047,20 @@ constexpr int POS_FAR = INT32_MAX; // "no boundary within reach"
 // Carries of a tile: last group start / last boundary in any earlier tile of the block (-1: none).  Run by one
 // whole wavefront; lane j inspects tile t - j.  Status word: look2_word(pass, state, start + 1, boundary + 1).
 __device__ __forceinline__ void carry_lookback(u64 *st, uint32_t tile, uint32_t pass, int own_gs, int own_bd, bool need_gs,
-                                               int &cg, int &cd, uint32_t *err)
+                                               int &cg, int &cd, uint32_t *err) // st: one word per tile, 2 words apart
 {
     const int lane = threadIdx.x & 63;
     const uint32_t egs = (uint32_t)(own_gs + 1), ebd = (uint32_t)(own_bd + 1);
     uint32_t fg = 0, fb = 0;
     if (tile > 0) {
-        if (lane == 0) __hip_atomic_store(st + (size_t)tile * NBMAX, look2_word(pass, LOOK_LOCAL, egs, ebd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(st + (size_t)tile * 2, look2_word(pass, LOOK_LOCAL, egs, ebd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bool hg = !need_gs, hb = false;
         int t = (int)tile - 1;
         uint32_t spins = 0;
         for (;;) {
             const int idx = t - lane;
             u64 w = look2_word(pass, LOOK_GLOBAL, 0u, 0u); // before tile 0: nothing
-            if (idx >= 0) w = __hip_atomic_load(st + (size_t)idx * NBMAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (idx >= 0) w = __hip_atomic_load(st + (size_t)idx * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t state = (uint32_t)(w >> 42) & 3u;
             const bool ready = (uint32_t)(w >> 44) == (pass & 0xFFFFFu) && state != 0u;
             const uint32_t vg = (uint32_t)(w >> 21) & 0x1FFFFFu, vb = (uint32_t)w & 0x1FFFFFu;
@@ -1083,7 +1094,7 @@ __device__ __forceinline__ void carry_lookback(u64 *st, uint32_t tile, uint32_t 
         }
     }
     if (lane == 0)
-        __hip_atomic_store(st + (size_t)tile * NBMAX, look2_word(pass, LOOK_GLOBAL, max(egs, fg), max(ebd, fb)), __ATOMIC_RELAXED,
+        __hip_atomic_store(st + (size_t)tile * 2, look2_word(pass, LOOK_GLOBAL, max(egs, fg), max(ebd, fb)), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     cg = (int)fg - 1;
     cd = (int)fb - 1;
@@ -1110,6 +1121,8 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
     __shared__ uint32_t lsu[NW + 2];
     __shared__ int s_cg, s_cd, s_hend;
     __shared__ uint32_t s_offS, s_offB;
+    __shared__ uint32_t bh[INIT ? 256 : 1], bcur[INIT ? 256 : 1], bgo[INIT ? 256 : 1]; // rank binning: counts, cursors, offsets
+    if (INIT && threadIdx.x < 256) bh[threadIdx.x] = 0;
     stage_tile(list, tile0, cnt, lds);
     if (threadIdx.x < (uint32_t)TAIL_G) halo[1 + threadIdx.x] = tend + threadIdx.x < cnt ? list[tend + threadIdx.x] : 0ull;
     if (threadIdx.x == (uint32_t)TAIL_G) halo[0] = tile0 ? list[tile0 - 1] : 0ull;
@@ -1163,7 +1176,7 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
     int nxt = block_excl_min_rev(firstbd, l01); // barrier inside: ex0 / ex1 / s_hend visible
     if (wave == 0) {
         int cgi, cdi;
-        carry_lookback(a.cstat + (size_t)b * a.TPB * NBMAX + 192, tile, a.cpass, ex0[SORT_THREADS - 1], ex1[SORT_THREADS - 1], !INIT,
+        carry_lookback(a.carry + (size_t)b * a.TPB * 2 + 1, tile, a.cpass, ex0[SORT_THREADS - 1], ex1[SORT_THREADS - 1], !INIT,
                        cgi, cdi, a.err);
         if (lane == 0) {
             s_cg = cgi;
@@ -1222,9 +1235,10 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
         s_offB = totB ? atomicAdd(&a.c_big[b], totB) : 0u;
     }
     uint32_t *rank = a.rank + base;
-    u64 outv[SORT_ITEMS]; // list record (rank : 20 @40, suffix : 20 @0) or all ones
+    // per element: [class:2 @62][foreign:1 @61][valid:1 @60][head:20 @40][suffix:20 @0]
+    u64 outv[SORT_ITEMS];
 #pragma unroll
-    for (int k = 0; k < SORT_ITEMS; k++) outv[k] = ~0ull;
+    for (int k = 0; k < SORT_ITEMS; k++) outv[k] = 0ull;
     if (q0 < cnt) {
 #pragma unroll
         for (int k = 0; k < SORT_ITEMS; k++) {
@@ -1240,36 +1254,26 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
                 const uint32_t oldr = (uint32_t)(cur >> 40);
                 const uint32_t gbase = INIT ? 0u : (oldr - (uint32_t)cg);
                 const uint32_t head = gbase + (uint32_t)cd;
-                const bool single = c == CLS_SINGLE;
                 // (the last column is emitted from the ranks; a rank that did not move and stays unresolved is in place)
-                const uint32_t word = single ? (head | RANK_RESOLVED) : head;
                 if (INIT)
-                    lds[slot_of(e0 + k)] = ((u64)word << 32) | i; // every suffix gets a rank: binned, then applied (rank_apply)
+                    atomicAdd(&bh[i >> 12], 1u); // every suffix gets a rank: binned by 4096-suffix window, then applied
                 else if (head != oldr) // (see tail_round: a SPLIT-mode block's "resolved" bits have no reader)
-                    rank[rslot(i)] = word;
-                if (!single && !((foreign >> k) & 1u)) outv[k] = ((u64)c << 62) | ((u64)head << 40) | i;
+                    rank[rslot(i)] = c == CLS_SINGLE ? (head | RANK_RESOLVED) : head;
+                outv[k] = ((u64)c << 62) | ((u64)((foreign >> k) & 1u) << 61) | (1ull << 60) | ((u64)head << 40) | i;
             }
         }
     }
     if (__ballot(progress) && lane == 0) a.c_prog[b] = 1u; // same value from everyone
-    if (INIT) { // the (rank word, suffix) pairs of the tile, in list order, as coalesced stores
-        __syncthreads();
-        u64 *rc = recs + base;
-#pragma unroll
-        for (int k = 0; k < SORT_ITEMS; k++) {
-            const uint32_t e = k * SORT_THREADS + threadIdx.x;
-            if (tile0 + e < cnt) rc[tile0 + e] = lds[slot_of(e)];
-        }
-    }
-    __syncthreads(); // every thread is done with the staged tile; s_off* are there
+    __syncthreads(); // every thread is done with the staged tile; s_off* and the bin counts are there
     // records leave through LDS: the tile's small-group records at [0, totS + nH), its large-group records behind them
     {
         uint32_t wS = offS, wB = totS + nH + offB;
 #pragma unroll
         for (int k = 0; k < SORT_ITEMS; k++) {
-            if (outv[k] != ~0ull) {
-                const u64 rec = outv[k] & ~(3ull << 62);
-                if ((outv[k] >> 62) == CLS_SMALL) lds[wS++] = rec;
+            const uint32_t c = (uint32_t)(outv[k] >> 62);
+            if (((outv[k] >> 60) & 3ull) == 1ull && c != CLS_SINGLE) { // valid, not foreign, unresolved
+                const u64 rec = outv[k] & 0x0FFFFFFFFFFFFFFFull;
+                if (c == CLS_SMALL) lds[wS++] = rec;
                 else lds[wB++] = rec;
             }
         }
@@ -1277,6 +1281,19 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
             const uint32_t oldr = (uint32_t)(halo[1 + threadIdx.x] >> 40);
             const uint32_t head = (INIT ? 0u : oldr - (uint32_t)last_gs) + (uint32_t)last_start;
             lds[totS + threadIdx.x] = ((u64)head << 40) | (halo[1 + threadIdx.x] & SUF_MASK);
+        }
+    }
+    // rank binning, step 1 (threads 0..255 = bins): the tile's first slot of every bin, its count to the look-back
+    uint32_t bmine = 0;
+    if (INIT) {
+        if (threadIdx.x < 256) bmine = bh[threadIdx.x];
+        uint32_t btot;
+        const uint32_t bex = block_excl_add(bmine, lsu, &btot);
+        if (threadIdx.x < 256) {
+            bcur[threadIdx.x] = bex;
+            bh[threadIdx.x] = bex; // (from here on: the bin's first slot)
+            __hip_atomic_store(a.cstat + ((size_t)b * a.TPB + tile) * NBMAX + threadIdx.x, look_word(a.bpass, LOOK_LOCAL, bmine),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();
@@ -1287,6 +1304,53 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
         const uint32_t nSm = totS + nH;
         for (uint32_t e = threadIdx.x; e < nSm; e += SORT_THREADS) ts[e] = lds[e];
         for (uint32_t e = threadIdx.x; e < totB; e += SORT_THREADS) bs[e] = lds[nSm + e];
+    }
+    if (!INIT) return;
+    // rank binning, step 2: the (rank word, suffix) pairs of the tile in bin order in LDS; the bins' offsets among the
+    // earlier tiles of the block by look-back (every bin of the block holds exactly its 4096 suffixes, so the bases
+    // need no counting); stores.  rank_apply turns each window into whole lines of the rank array.
+    __syncthreads(); // the list records have left LDS
+#pragma unroll
+    for (int k = 0; k < SORT_ITEMS; k++) {
+        if ((outv[k] >> 60) & 1ull) {
+            const uint32_t i = (uint32_t)(outv[k] & SUF_MASK), head = (uint32_t)(outv[k] >> 40) & 0xFFFFFu;
+            const uint32_t word = (uint32_t)(outv[k] >> 62) == CLS_SINGLE ? (head | RANK_RESOLVED) : head;
+            lds[atomicAdd(&bcur[i >> 12], 1u)] = ((u64)word << 32) | i;
+        }
+    }
+    if (threadIdx.x < 256) {
+        const uint32_t bin = threadIdx.x;
+        u64 *col = a.cstat + (size_t)b * a.TPB * NBMAX + bin;
+        uint32_t acc = 0, spins = 0;
+        int t = (int)tile - 1;
+        while (t >= 0) {
+            const u64 w = __hip_atomic_load(col + (size_t)t * NBMAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t state = (uint32_t)(w >> 30) & 3u;
+            if ((uint32_t)(w >> 32) != a.bpass || state == 0) { // predecessor has not published yet
+                if (++spins > (1u << 26)) { // seconds: only a logic error gets here
+                    atomicOr(a.err, 2u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                continue;
+            }
+            acc += (uint32_t)w & 0x3FFFFFFFu;
+            if (state == LOOK_GLOBAL) break;
+            t--;
+        }
+        __hip_atomic_store(col + (size_t)tile * NBMAX, look_word(a.bpass, LOOK_GLOBAL, acc + bmine), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        bgo[bin] = min(a.n[b], bin * 4096u) + acc;
+    }
+    __syncthreads();
+    {
+        u64 *dst = recs + base;
+        const uint32_t ntl = min((uint32_t)SORT_TILE, cnt - tile0);
+        for (uint32_t e = threadIdx.x; e < ntl; e += SORT_THREADS) {
+            const u64 x = lds[e];
+            const uint32_t d = ((uint32_t)x & (uint32_t)SUF_MASK) >> 12;
+            dst[bgo[d] + (e - bh[d])] = x;
+        }
     }
 }
 
@@ -1904,17 +1968,12 @@ static void launch_refine(bzh_ctx *ctx, RefineArgs &r, uint32_t NB, uint32_t max
 
 // ---- initial ranks: binned by destination, then applied -------------------------------------------------------
 // A 4-byte store to a random slot of a block's 3.6 MB rank array leaves the XCD as a partial 64-byte write: the
-// 100 M stores of the initial refinement cost 6.4 GB of fabric writes.  Instead refine_one<init> leaves (rank word,
-// suffix) pairs in list order; one ordinary radix pass on suffix bits 12..19 gathers the pairs of every 4096-suffix
-// window of the rank array (the bins are full by construction, so the digit bases are known up front); rank_apply
-// places a window's words in LDS and stores them as whole lines.
+// 100 M stores of the initial refinement cost 6.4 GB of fabric writes.  Instead refine_one<init> bins its (rank word,
+// suffix) pairs by suffix bits 12..19 on the way out, exactly as a radix pass would (counts per tile, look-back over
+// the tiles, runs of a bin leave together; the bins are full by construction, so their bases are known up front):
+// the pairs of every 4096-suffix window of the rank array end up together, and rank_apply places a window's words
+// in LDS and stores them as whole lines.
 constexpr uint32_t APPLY_W = 4096;
-__global__ void __launch_bounds__(256) bin_bases(const uint32_t *nn, uint32_t *dbase)
-{
-    const uint32_t b = blockIdx.x, n = nn[b];
-    dbase[(size_t)b * DB_STRIDE + threadIdx.x] = min(n, threadIdx.x * APPLY_W);
-}
-
 __global__ void __launch_bounds__(256) rank_apply(const u64 *binned, const uint32_t *nn, uint32_t *rank, uint32_t S)
 {
     const uint32_t b = blockIdx.y, n = nn[b];
@@ -2066,33 +2125,24 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     r.TPB = bt.TPB;
     r.init = 1;
     r.cstat = reinterpret_cast<u64 *>(bt.hist);
+    r.carry = reinterpret_cast<u64 *>(bt.tagg);
     r.cpass = ++a.pass;
     r.err = bt.errflag;
     r.lst = all;
     // lists of every block + (rank word, suffix) pairs in list order; the blocks that start in SWEEP mode get their
     // SA order and digit bases in round 0 (below)
     {
-        // list in, one pair out per suffix; the list records of the unresolved ones are added when round 0's summary is in
-        KSpan ks(ctx, K_REFINE_INIT, 16 * ntotal);
-        launch_refine_one<true>(ctx, r, B, nmax, bufD);
-    }
-    { // the pairs, binned by 4096-suffix window (into sa|headp, which nobody needs before round 0), become the ranks
+        // list in, one (rank word, suffix) pair out per suffix -- binned by 4096-suffix window of the rank array, into
+        // sa|headp, which nobody needs before round 0 -- plus the list records of the unresolved ones (their bytes are
+        // added when round 0's summary is in); the blocks that start in SWEEP mode get SA order and digit bases in
+        // round 0 (below).  rank_apply then writes the rank array as whole lines.
         u64 *binned = reinterpret_cast<u64 *>(bt.sa);
         static_assert(sizeof(u64) == 2 * sizeof(uint32_t), "sa and headp together hold one 64-bit word per suffix");
-        bin_bases<<<dim3(B), 256, 0, st>>>(bt.n, bt.dbase);
-        a.cnt = bt.n;
-        a.lst = all;
-        a.shift = 12;
-        a.doff = 0;
-        a.src = bufD;
-        a.dst = binned;
-        hipEvent_t e0 = span_begin(ctx);
+        r.bpass = ++a.pass;
         {
-            KSpan ks(ctx, K_RADIX_BIN, 16 * ntotal);
-            launch_pass<8, GEN_LIST>(ctx, a, B, nmax);
+            KSpan ks(ctx, K_REFINE_INIT, 16 * ntotal);
+            launch_refine_one<true>(ctx, r, B, nmax, binned);
         }
-        span_end(ctx, e0);
-        if (ctx->profiling) ctx->stats.bwt_sort_elems += ntotal;
         KSpan ks(ctx, K_RANK_APPLY, 12 * ntotal);
         rank_apply<<<dim3((nmax + APPLY_W - 1) / APPLY_W, B), 256, 0, st>>>(binned, bt.n, bt.rank, bt.S);
     }

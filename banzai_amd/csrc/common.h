@@ -144,13 +144,13 @@ constexpr uint32_t FX_HDR_BYTES = 64 + 6 * 1152; // + up to 6 delta-coded tables
 // class are bracketed by HIP events on the context's stream (KSpan); `bytes` = ALGORITHMIC bytes the launches move
 // (per-element figures in DESIGN.md, element counts from the plan / the round summaries).
 enum KClass : int {
-    K_PLAN = 0, K_CRC, K_RLE1_EMIT, K_BYTE_COUNT, K_RADIX_INIT, K_RADIX_GID, K_REFINE_INIT, K_RADIX_BIN, K_RANK_APPLY,
+    K_PLAN = 0, K_CRC, K_RLE1_EMIT, K_BYTE_COUNT, K_RADIX_INIT, K_RADIX_GID, K_REFINE_INIT, K_RANK_APPLY,
     K_ROUND_BEGIN, K_SWEEP, K_ACTIVE_GEN, K_RADIX_ROUNDS, K_TAIL_ROUND, K_REFINE_ROUNDS, K_BWT_EMIT, K_MTF_LAST,
     K_MTF_WALK, K_RLE2, K_HUFF, K_PACK, K_COUNT
 };
 static const char *const KCLASS_NAME[K_COUNT] = {
     "plan (granules, carries, split)", "crc_tiles", "rle1_emit", "byte_count", "radix_scatter (initial sort)",
-    "radix_scatter<GID> (re-key pass)", "refine_one<init>", "radix_scatter (rank binning)", "rank_apply", "round_begin",
+    "radix_scatter<GID> (re-key pass)", "refine_one<init> (+ rank binning)", "rank_apply", "round_begin",
     "SWEEP path (3 passes + 3-kernel refine)", "active_gen", "radix_scatter (big-list rounds)", "tail_round",
     "refine_one (rounds)", "bwt_emit", "mtf_tile_last + mtf_prefix", "mtf_walk", "rle2 (tiles, block, emit)",
     "huffman (segments, build, header)", "pack_symbols"};
