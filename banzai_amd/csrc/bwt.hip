@@ -517,6 +517,22 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
                 v[k] = ((u64)(text4(txt, i, n) >> 8) << 40) | ((u64)gid << 20) | i;
             }
         }
+    } else if (MODE == GEN_BYTES5 && tile * SORT_TILE + wave * (SORT_ITEMS * 64) + SORT_ITEMS * 64 + 16 <= n) {
+        // The first pass has no order to keep (any order of equal keys does), so a lane takes 16 CONSECUTIVE suffixes
+        // and reads their 20 text bytes with two aligned 16-byte loads instead of one load per suffix.
+        const uint32_t e0 = tile * SORT_TILE + wave * (SORT_ITEMS * 64) + lane * SORT_ITEMS;
+        const uint4 *tp = reinterpret_cast<const uint4 *>(a.blk + (size_t)b * a.S + e0);
+        const uint4 q0 = tp[0], q1 = tp[1];
+        const uint32_t d[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        actmask = 0xFFFFu;
+#pragma unroll
+        for (int k = 0; k < SORT_ITEMS; k++) {
+            const int o = k + 3, wi = o >> 2, sh = (o & 3) * 8; // bytes o .. o+4 of the window = bytes 3..7 of rotation e0+k
+            const u64 lo = ((u64)d[wi + 1] << 32) | d[wi];
+            const uint32_t b3456 = (uint32_t)(lo >> sh);                                            // byte 3 lowest
+            const uint32_t b7 = (uint32_t)((((u64)d[wi + 2] << 32) | d[wi + 1]) >> sh) & 255u;
+            v[k] = ((u64)__builtin_bswap32(b3456) << 28) | ((u64)b7 << 20) | (e0 + k);
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < SORT_ITEMS; k++) {
