@@ -256,6 +256,16 @@ extern "C" void bzh_destroy(bzh_ctx *ctx)
     for (bzh_ctx *l : ctx->lanes)
         if (l->stream) hipStreamSynchronize(l->stream);
     if (ctx->strm.copy_stream) hipStreamSynchronize(ctx->strm.copy_stream);
+    auto drop_side = [](bzh_ctx *c) {
+        if (!c->side_stream) return;
+        hipStreamSynchronize(c->side_stream);
+        hipEventDestroy(c->side_ev[0]);
+        hipEventDestroy(c->side_ev[1]);
+        hipStreamDestroy(c->side_stream);
+        c->side_stream = nullptr;
+    };
+    drop_side(ctx);
+    for (bzh_ctx *l : ctx->lanes) drop_side(l);
     for (hipEvent_t e : ctx->evpool) hipEventDestroy(e);
     for (bzh_ctx *l : ctx->lanes) {
         for (hipEvent_t e : l->evpool) hipEventDestroy(e);

@@ -2259,9 +2259,38 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     };
     // -- SPLIT-mode blocks with large groups: re-key the big list once, then five look-back passes on bits
     //    20..59; gen: cur -> oth, passes: oth -> cur -> oth -> cur -> oth -> cur
+    // The big-list path (re-key + five passes) and the small-group kernel of a round touch different lists, and the
+    // one thing they share -- the rank array, read by the first, written by the second -- keeps both versions of a
+    // word (rank_at), so the two run side by side: the big-list path on a second stream between two events.  (With
+    // profiling on everything stays on one stream, or the per-kernel spans would overlap.)
+    static const bool no_overlap = getenv("BZH_NO_OVERLAP") != nullptr;
+    hipStream_t side = nullptr;
+    if (!ctx->profiling && !no_overlap) {
+        if (!ctx->side_stream) {
+            if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) ctx->side_stream = nullptr;
+            if (ctx->side_stream && (hipEventCreateWithFlags(&ctx->side_ev[0], hipEventDisableTiming) != hipSuccess ||
+                                     hipEventCreateWithFlags(&ctx->side_ev[1], hipEventDisableTiming) != hipSuccess)) {
+                hipStreamDestroy(ctx->side_stream);
+                ctx->side_stream = nullptr;
+            }
+        }
+        side = ctx->side_stream;
+    }
+    bool side_busy = false;
+    auto join_side = [&]() { // the main stream goes on only behind what the side stream was given
+        if (side_busy) hipStreamWaitEvent(st, ctx->side_ev[1], 0);
+        side_busy = false;
+    };
     auto run_A = [&]() {
         const uint32_t gt = (maxA + SORT_TILE - 1) / SORT_TILE;
         if (!nA || !gt) return;
+        hipStream_t sa = st;
+        if (side) {
+            hipEventRecord(ctx->side_ev[0], st);
+            hipStreamWaitEvent(side, ctx->side_ev[0], 0);
+            sa = side;
+            ctx->stream = side; // (launch_pass launches on the context's stream)
+        }
         a.lst = Lst{bt.actA, bt.nlist + L_A, B};
         a.cnt = bt.gateA;
         a.src = cur;
@@ -2269,8 +2298,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         a.T = gt | (nA < 32 ? WG_SPREAD : 0u);
         {
             KSpan ks(ctx, K_ACTIVE_GEN, 0, 2);
-            active_gen<<<dim3(xcd_grid(a.T, nA)), SORT_THREADS, 0, st>>>(a, bt.dtot);
-            active_bases<<<dim3(nA), 256, 0, st>>>(bt.dtot, bt.dbase, a.lst, 5);
+            active_gen<<<dim3(xcd_grid(a.T, nA)), SORT_THREADS, 0, sa>>>(a, bt.dtot);
+            active_bases<<<dim3(nA), 256, 0, sa>>>(bt.dtot, bt.dbase, a.lst, 5);
         }
         u64 *c = oth, *o = cur;
         hipEvent_t e0 = span_begin(ctx);
@@ -2286,6 +2315,11 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             o = t;
         }
         span_end(ctx, e0);
+        if (side) {
+            ctx->stream = st;
+            hipEventRecord(ctx->side_ev[1], side);
+            side_busy = true;
+        }
     };
     // -- small groups: one kernel per form (depth x2 / depth x4); survivors move to the other list buffer
     auto run_T = [&]() {
@@ -2377,6 +2411,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             const uint32_t pA = s[2], pT = s[3], mA = s[6], mT = s[7], cS = s[16];
             nA = pA;
             maxA = mA;
+            join_side();
             if (nS | nA) {
                 r.list = cur;
                 r.big = oth;
@@ -2405,6 +2440,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         run_S(round);
         run_A();
         run_T();
+        join_side();
         // -- every block that went through radix passes: flags, group extents, ranks, routing (SWEEP-mode blocks in
         //    three kernels with SA order and digit counts, the big lists of SPLIT-mode blocks in one)
         if (nS | nA) {
@@ -2425,6 +2461,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             std::swap(cur, oth);
         }
     }
+    join_side();
     if (!finished && !err) { // MAX_ROUNDS is far beyond log2(n) + the rounds queued ahead
         HIP_TRY(ctx, bzh_stream_wait(st));
         bzh_set_error(ctx, "BWT: the doubling rounds did not terminate (internal error)");

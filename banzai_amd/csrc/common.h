@@ -169,6 +169,8 @@ struct bzh_ctx {
     uint32_t S = 0;
     uint32_t max_batch = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;   // second stream of the suffix sort (big-list path beside the small groups)
+    hipEvent_t side_ev[2] = {nullptr, nullptr};
     int profiling = 0;
     int mode = 0;                     // BZH_MODE_REFERENCE / BZH_MODE_FIXED (bzh_set_mode)
     char err[512] = {0};      // last failure (guarded by err_mu: the streaming worker writes it too)
