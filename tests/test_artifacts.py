@@ -16,7 +16,7 @@ def _line(name):
 
 import pytest
 
-ROUNDS = [r for r in ("r01", "r02") if os.path.exists(os.path.join(PROF, f"{r}_bench_n1.json"))]
+ROUNDS = [r for r in ("r01", "r02", "r03") if os.path.exists(os.path.join(PROF, f"{r}_bench_n1.json"))]
 
 
 @pytest.mark.parametrize("rnd", ROUNDS)
@@ -36,6 +36,12 @@ def test_bench_line_contract(rnd):
     if rnd != "r01":  # round 2 on: the whole path next to the dominant class, the PCIe-inclusive rate, other inputs
         assert 0 < r["path_frac"] < 1 and d["value_host_inclusive"]["value"] < d["value"]
         assert all(w.get("bit_exact", True) for w in d["extra_workloads"].values())
+    if rnd not in ("r01", "r02"):  # round 3 on: per-kernel-class table, where the traffic figure comes from, real text
+        assert len(r["kernels"]) >= 6 and all(0 < k["frac"] < 1 for k in r["kernels"] if k["frac"] is not None)
+        assert f"profiles/{rnd}_pmc_traffic.json" in r["traffic_source"]
+        rt = d["extra_workloads"]["real-text-100MB"]
+        assert rt["bytes"] == 100_000_000 and rt["bit_exact"] and rt["rounds"] > 0 and rt["A/n"] > 0
+        assert all(d["extra_workloads"][k]["MB/s"] >= 3000 for k in d["extra_workloads"] if k.startswith("c5-"))
     # value is whole-job throughput of the named workload: bytes per step / time per step
     assert abs(d["value"] - 100_000_000 / d["ms_per_step"] / 1e3) / d["value"] < 0.01
 
