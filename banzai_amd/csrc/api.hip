@@ -144,6 +144,20 @@ static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
     }
     carve(p, bt.chain, NB * 4);
     carve(p, bt.errflag, 64);
+    { // bucket-first initial sort (bwt_msd.h): only levels whose blocks can reach MS_MIN_N bytes ever use it
+        const size_t MB = M >= MS_MIN_N ? NB : 0;
+        carve(p, bt.ms_bgcur, MB * 65536);
+        carve(p, bt.ms_pool, MB * MS_BG_ROW + (size_t)MS_LEVELS * MB * MS_SEG_SLOTS * MS_SEG_ROW);
+        carve(p, bt.ms_segcur, (size_t)MS_LEVELS * MB * MS_SEG_SLOTS * 256);
+        carve(p, bt.ms_units, MB * MS_UNIT_CAP);
+        carve(p, bt.ms_segs, (size_t)(MS_LEVELS + 1) * MB * MS_SEG_SLOTS);
+        carve(p, bt.ms_items, (size_t)(MS_LEVELS + 1) * MB * MS_ITEM_CAP);
+        carve(p, bt.ms_cnt, MS_CNT_WORDS + (size_t)(MS_LEVELS + 1) * NB);
+        carve(p, bt.ms_np, NB);
+        carve(p, bt.ms_old, NB);
+        carve(p, bt.ms_new, NB);
+        carve(p, bt.ms_bincur, NB * 256);
+    }
     carve(p, bt.mtfpos, NB * S);
     carve(p, bt.tilelist, NB * MT * 256);
     carve(p, bt.tinfo, NB * MT * 4);
@@ -231,7 +245,7 @@ extern "C" int bzh_create(bzh_ctx **out, int device, int level, int max_batch)
     ctx->bt.S = probe.S;
     ctx->bt.TPB = probe.TPB;
     ctx->bt.M = ctx->M;
-    if (hipHostMalloc((void **)&ctx->h_pinned, sizeof(uint32_t) * (ctx->max_batch * 8 + 64 + MAX_ROUNDS * SUMMARY_WORDS), hipHostMallocCoherent) != hipSuccess) {
+    if (hipHostMalloc((void **)&ctx->h_pinned, sizeof(uint32_t) * (ctx->max_batch * 8 + 64 + (MAX_ROUNDS + 1) * SUMMARY_WORDS), hipHostMallocCoherent) != hipSuccess) {
         delete ctx;
         return BZH_E_NOMEM;
     }
@@ -730,7 +744,7 @@ static int ensure_lanes(bzh_ctx *ctx)
         layout_batch(l->bt, ctx->arena + (size_t)k * half, lane_mb, ctx->M);
         l->S = l->bt.S;
         if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess ||
-            hipHostMalloc((void **)&l->h_pinned, sizeof(uint32_t) * (lane_mb * 8 + 64 + MAX_ROUNDS * SUMMARY_WORDS), hipHostMallocCoherent) != hipSuccess) {
+            hipHostMalloc((void **)&l->h_pinned, sizeof(uint32_t) * (lane_mb * 8 + 64 + (MAX_ROUNDS + 1) * SUMMARY_WORDS), hipHostMallocCoherent) != hipSuccess) {
             delete l;
             return BZH_E_NOMEM;
         }

@@ -1803,8 +1803,11 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
         const uint32_t gR = bt.gateR[b], gTin = bt.gateT[b], prog = bt.c_prog[b], nolist = bt.c_nolist[b];
         // Round 0: with fewer than one group per 8 suffixes after the 8-byte sort the block is run-heavy / periodic
         // and starts in SWEEP mode; text-like blocks start in SPLIT mode and never pay for SA order by position.
-        uint32_t mode = round == 0 ? (((uint64_t)groups * 8u < n) ? 0u : 1u) : mode_in;
-        h = round == 0 ? 8u : h_in; // the initial sort ordered the rotations by their first 8 bytes
+        // (a block that took the bucket-first initial sort -- bwt_msd.h -- has no SA order by position: SPLIT mode, and
+        // its rotations are ordered by their first 7 bytes, not 8)
+        const bool msd = round == 0 && bt.ms_np[b] != 0u;
+        uint32_t mode = round == 0 ? ((!msd && (uint64_t)groups * 8u < n) ? 0u : 1u) : mode_in;
+        h = round == 0 ? (msd ? 7u : 8u) : h_in; // the initial sort ordered the rotations by their first 8 (7) bytes
         if (round > 0 && (gR | gTin)) { // the block had work in the round before
             const bool wasquad = (gTin & QUAD_BIT) != 0;
             if (!prog && h < n)
@@ -1904,6 +1907,8 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
         }
     }
 }
+
+#include "bwt_msd.h"
 
 // ---- host driver -----------------------------------------------------------------------------------
 // one radix pass = one kernel (look-back scatter)
@@ -2090,32 +2095,71 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     // round state: everything from st_mode to the 64-bit counter (one contiguous carve, see layout_batch)
     HIP_TRY(ctx, hipMemsetAsync(bt.st_mode, 0,
                                 (size_t)((uint8_t *)(bt.stat_A + 1) - (uint8_t *)bt.st_mode), st));
-    {
-        KSpan ks(ctx, K_BYTE_COUNT, ntotal, 2);
-        byte_count<<<dim3(BYTE_SEGS, B), 1024, 0, st>>>(bt.rle, bt.n, bt.dtot, bt.S);
-        active_bases<<<dim3(B), 256, 0, st>>>(bt.dtot, bt.dbase, all, 1);
+    // ---- which blocks take which initial sort (bwt_msd.h): text-like blocks of at least MS_MIN_N bytes the bucket-first
+    // one, repetitive and short blocks the 8 passes below (`oldl`; all of them at levels whose blocks are too short)
+    // (measured in round 4, DESIGN.md section 4.1: bit-exact, but not faster on the headline -- the 8-pass sort stays the
+    // default; BZH_INIT=msd selects the bucket-first path)
+    static const bool init_lsd = []() {
+        const char *e = getenv("BZH_INIT");
+        return !(e && !strcmp(e, "msd"));
+    }();
+    const bool use_msd = ctx->M >= MS_MIN_N && !a.fault;
+    uint32_t nOld = B;
+    Lst oldl = all;
+    u64 *const binned = reinterpret_cast<u64 *>(bt.sa);
+    static_assert(sizeof(u64) == 2 * sizeof(uint32_t), "sa and headp together hold one 64-bit word per suffix");
+    volatile uint32_t *const hrec0 = ctx->h_pinned + (size_t)mb * 8 + 64; // [MAX_ROUNDS + 1][SUMMARY_WORDS]
+    const uint32_t epoch = (++ctx->bwt_epoch & 0xFFFFFFu) << 6;
+    if (use_msd) {
+        BZH_TRY(msd_initial_sort(ctx, B, nmax, ntotal, bufB, bufD, bufA, bufC, binned, init_lsd,
+                                 hrec0 + (size_t)MAX_ROUNDS * SUMMARY_WORDS, epoch + 63u, &nOld));
+        oldl = Lst{bt.ms_old, bt.ms_cnt + MC_OLD, B};
+        a.lst = oldl;
+        if (getenv("BZH_TRACE_ROUNDS")) { // (debugging aid: waits for the device)
+            uint32_t c[MS_CNT_WORDS];
+            if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(c, bt.ms_cnt, sizeof c, hipMemcpyDeviceToHost) == hipSuccess)
+                fprintf(stderr, "[bzhip] initial sort: %u blocks bucket-first, %u blocks 8-pass; %u units; oversized buckets per level %u %u %u %u %u (tiles %u %u %u %u %u)\n",
+                        c[MC_NEW], c[MC_OLD], c[MC_UNITS], c[MC_SEGS + 1], c[MC_SEGS + 2], c[MC_SEGS + 3], c[MC_SEGS + 4], c[MC_SEGS + 5],
+                        c[MC_ITEMS + 1], c[MC_ITEMS + 2], c[MC_ITEMS + 3], c[MC_ITEMS + 4], c[MC_ITEMS + 5]);
+            if (c[24] | c[27])
+                fprintf(stderr, "[bzhip] chunk_finish, 16-cycle ticks over all workgroups: ticket+descriptor %u, load+bucket heads %u, bucket index+vary %u, sort passes %u, suffixes+heads %u, classes %u, lists out %u, ranks out %u\n",
+                        c[24], c[25], c[26], c[27], c[28], c[29], c[30], c[31]);
+        }
+    } else {
+        HIP_TRY(ctx, hipMemsetAsync(bt.ms_np, 0, (size_t)B * sizeof(uint32_t), st));
     }
-    hipEvent_t ev_init = span_begin(ctx);
-    {
-        KSpan ks(ctx, K_RADIX_INIT, 13 * ntotal); // 5 text bytes in, one element out
-        launch_pass<8, GEN_BYTES5>(ctx, a, B, nmax);
-    }
+    const uint64_t ntotal_old = nOld == B ? ntotal : ntotal * nOld / B; // (statistics only)
     u64 *cur = bufA, *oth = bufB;
-    for (int p = 1; p < 8; p++) {
-        a.shift = p < 5 ? 20 + 8 * p : 40 + 8 * (p - 5);
-        a.src = cur;
-        a.dst = oth;
-        KSpan ks(ctx, p == 5 ? K_RADIX_GID : K_RADIX_INIT, (p == 5 ? 20 : 16) * ntotal); // (re-key: + one 4-byte gather)
-        if (p == 5)
-            launch_pass<8, GEN_GID>(ctx, a, B, nmax);
-        else
-            launch_pass<8, GEN_LIST>(ctx, a, B, nmax);
-        u64 *t = cur;
-        cur = oth;
-        oth = t;
+    hipEvent_t ev_init = span_begin(ctx);
+    if (nOld) {
+        {
+            KSpan ks(ctx, K_BYTE_COUNT, ntotal_old, 2);
+            byte_count<<<dim3(BYTE_SEGS, B), 1024, 0, st>>>(bt.rle, bt.n, bt.dtot, bt.S);
+            active_bases<<<dim3(B), 256, 0, st>>>(bt.dtot, bt.dbase, all, 1);
+        }
+        {
+            KSpan ks(ctx, K_RADIX_INIT, 13 * ntotal_old); // 5 text bytes in, one element out
+            launch_pass<8, GEN_BYTES5>(ctx, a, nOld, nmax);
+        }
+        for (int p = 1; p < 8; p++) {
+            a.shift = p < 5 ? 20 + 8 * p : 40 + 8 * (p - 5);
+            a.src = cur;
+            a.dst = oth;
+            KSpan ks(ctx, p == 5 ? K_RADIX_GID : K_RADIX_INIT, (p == 5 ? 20 : 16) * ntotal_old); // (re-key: + one 4-byte gather)
+            if (p == 5)
+                launch_pass<8, GEN_GID>(ctx, a, nOld, nmax);
+            else
+                launch_pass<8, GEN_LIST>(ctx, a, nOld, nmax);
+            u64 *t = cur;
+            cur = oth;
+            oth = t;
+        }
+        if (ctx->profiling) ctx->stats.bwt_sort_elems += 8 * ntotal_old;
+    } else {
+        cur = bufB; // (where the 8 passes leave the sorted list; the big lists are in bufA either way)
+        oth = bufA;
     }
     span_end(ctx, ev_init);
-    if (ctx->profiling) ctx->stats.bwt_sort_elems += 8 * ntotal;
 
     RefineArgs r{};
     r.n = bt.n;
@@ -2144,7 +2188,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     r.carry = reinterpret_cast<u64 *>(bt.tagg);
     r.cpass = ++a.pass;
     r.err = bt.errflag;
-    r.lst = all;
+    r.lst = oldl;
     // lists of every block + (rank word, suffix) pairs in list order; the blocks that start in SWEEP mode get their
     // SA order and digit bases in round 0 (below)
     {
@@ -2152,12 +2196,10 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         // sa|headp, which nobody needs before round 0 -- plus the list records of the unresolved ones (their bytes are
         // added when round 0's summary is in); the blocks that start in SWEEP mode get SA order and digit bases in
         // round 0 (below).  rank_apply then writes the rank array as whole lines.
-        u64 *binned = reinterpret_cast<u64 *>(bt.sa);
-        static_assert(sizeof(u64) == 2 * sizeof(uint32_t), "sa and headp together hold one 64-bit word per suffix");
         r.bpass = ++a.pass;
-        {
-            KSpan ks(ctx, K_REFINE_INIT, 16 * ntotal);
-            launch_refine_one<true>(ctx, r, B, nmax, binned);
+        if (nOld) {
+            KSpan ks(ctx, K_REFINE_INIT, 16 * ntotal_old);
+            launch_refine_one<true>(ctx, r, nOld, nmax, binned);
         }
         KSpan ks(ctx, K_RANK_APPLY, 12 * ntotal);
         rank_apply<<<dim3((nmax + APPLY_W - 1) / APPLY_W, B), 256, 0, st>>>(binned, bt.n, bt.rank, bt.S);
@@ -2187,8 +2229,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     // round + 1 behind a system-scope release: no copy, no event -- the host looks at the word.
     // (The word also carries the number of this call: the round_begin queued last by the call before may still
     // be on its way when this one starts.)
-    volatile uint32_t *hsum = ctx->h_pinned + (size_t)mb * 8 + 64; // [MAX_ROUNDS][SUMMARY_WORDS]
-    const uint32_t epoch = (++ctx->bwt_epoch & 0xFFFFFFu) << 6;
+    volatile uint32_t *hsum = hrec0; // [MAX_ROUNDS][SUMMARY_WORDS] (+ one record of the initial sort's plan)
     auto wait_summary = [&](uint32_t rd, uint32_t *out) -> hipError_t { // normally there already
         volatile uint32_t *rec = hsum + (size_t)rd * SUMMARY_WORDS;
         const uint32_t want = epoch + rd + 1u;
@@ -2349,7 +2390,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         ctx->k_bytes[K_RADIX_ROUNDS] += eA * 5 * 16;
         ctx->k_bytes[K_REFINE_ROUNDS] += eA * 20;                   // record in, rank word, list record out
         ctx->k_bytes[K_TAIL_ROUND] += (tot - eS - eA) * 24;         // record in, key gather, rank word, survivor out
-        if (sm[0] == 0) ctx->k_bytes[K_REFINE_INIT] += tot * 8;     // the list records the initial refinement wrote
+        if (sm[0] == 0) ctx->k_bytes[nOld == B ? K_REFINE_INIT : K_MSD_FINISH] += tot * 8; // the list records the initial refinement wrote
     };
 
     for (uint32_t round = 0; round < (uint32_t)MAX_ROUNDS; round++) {
@@ -2472,7 +2513,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     // its error word and its sum of unresolved suffixes are final)
     ctx->stats.bwt_active_sum += (uint64_t)s[17] | ((uint64_t)s[18] << 32);
     if (err) {
-        bzh_set_error(ctx, err & 4   ? "BWT: a launch was sized for fewer blocks or tiles than the round had (internal error)"
+        bzh_set_error(ctx, err & 8   ? "BWT: the bucket-first initial sort broke one of its invariants (internal error)"
+                           : err & 4 ? "BWT: a launch was sized for fewer blocks or tiles than the round had (internal error)"
                            : err & 2 ? "BWT: a look-back gave up waiting (internal error)"
                                      : "BWT: a small-group window saw a group larger than its guarantee (internal error)");
         return BZH_E_HIP;

@@ -1,0 +1,1100 @@
+// bwt_msd.h -- bucket-first initial sort of the suffix sorter (included by bwt.hip; gfx950 only).
+//
+// Replaces, for text-like blocks, the 8 global radix passes + re-key gather + refine_one<init> of the initial sort
+// (reference contract unchanged: lib/bwt.rs:526-756, tie rule :564-573 -- the initial sort only has to leave an
+// order-consistent ranking of the rotations by a prefix of known minimum depth, the doubling rounds do the rest).
+//
+//   bigram_hist      65,536-bin histogram of the block's 2-byte cyclic prefixes (packed 16-bit LDS counters)
+//   bigram_plan      one workgroup per block: bucket starts (scan), a sampled "is this block repetitive" test (such
+//                    blocks keep the 8-pass path and its SWEEP mode), the work list: buckets of at most MS_TILE
+//                    suffixes become UNITS (small ones packed together by position window), larger ones go to level 1
+//   bigram_scatter   ONE pass from the text to 2-byte buckets: a tile's suffixes are ordered by bigram inside LDS
+//                    (two local counting passes), every run of equal bigrams claims its room in the bucket with one
+//                    atomic add (a first pass has no order to keep) and leaves as a coalesced store.
+//                    element = [bytes 2..6 of the rotation : 40 @20][suffix : 20]
+//   seg_count / seg_plan / seg_scatter   level L = 1..5: every bucket still larger than a tile is split by byte
+//                    1 + L of the rotation (same claim scheme), its sub-buckets become units or level L+1 buckets; what
+//                    is still oversized after byte 6 has all 7 bytes equal: one group, nothing left to sort
+//   chunk_finish     one workgroup per unit: up to 5 + 1 counting passes inside LDS (passes whose digit does not vary
+//                    inside the unit are skipped), group heads and sizes from ballots, then exactly what
+//                    refine_one<init> leaves: (rank word, suffix) pairs binned by 4096-suffix window of the rank array
+//                    (rank_apply turns them into whole lines), small groups to the small-group list, large groups to
+//                    the big list.  Units are whole buckets, so no group crosses a unit: no carries, no look-back.
+// Depth: 2 + 5 = 7 bytes, so a block on this path enters the doubling rounds at h = 7 (round_begin).
+#pragma once
+
+constexpr int MS_THREADS = 512, MS_ITEMS = 16, MS_TILE = 8192, MS_NW = 8;
+constexpr uint32_t MS_SMALL = 4096; // buckets up to this size are packed into shared units ...
+constexpr uint32_t MS_WIN = 4096;   // ... by the 4096-position window they start in (a unit stays below MS_TILE)
+constexpr uint32_t MS_BG = 65536;
+constexpr uint32_t MS_SAMPLES = 4096;
+enum : uint32_t { MC_UNITS = 0, MC_TICKET = 1, MC_PLAN_DONE = 2, MC_OLD = 3, MC_NEW = 4, MC_SEGS = 8, MC_ITEMS = 16 };
+constexpr uint32_t ERR_MSD = 8u; // bit 3 of the error word: an invariant of this file did not hold
+
+struct Msd {
+    const uint8_t *blk;  // [B][S]
+    const uint32_t *n;   // [B]
+    uint32_t S, B;
+    uint32_t *bgcur, *pool, *segcur;
+    uint4 *units, *segs;
+    uint32_t *items, *cnt, *np, *act_old, *act_new, *bincur;
+    u64 *bufX, *bufY;    // partition output of levels 0, 2, 4 / 1, 3, 5
+    u64 *big, *tail, *binned;
+    uint32_t *c_big, *c_small, *c_groups;
+    uint32_t *err;
+    uint32_t force_old;  // every block keeps the 8-pass path (BZH_INIT=lsd)
+    uint32_t dbg;        // timing experiments only (BZH_MSD_DBG): 1 no sort passes, 2 no bucket-index pass, 4 no outputs
+};
+
+__device__ __forceinline__ uint32_t *ms_seg_start_row(const Msd &m, uint32_t L, uint32_t b, uint32_t slot)
+{
+    return m.pool + (size_t)m.B * MS_BG_ROW + (((size_t)(L - 1) * m.B + b) * MS_SEG_SLOTS + slot) * MS_SEG_ROW;
+}
+__device__ __forceinline__ uint32_t *ms_seg_cur_row(const Msd &m, uint32_t L, uint32_t b, uint32_t slot)
+{
+    return m.segcur + (((size_t)(L - 1) * m.B + b) * MS_SEG_SLOTS + slot) * 256;
+}
+__device__ __forceinline__ uint32_t *ms_slot_counter(const Msd &m, uint32_t L, uint32_t b) { return m.cnt + MS_CNT_WORDS + (size_t)L * m.B + b; }
+// unit record: x = block | buffer << 10 | uniform << 11 | table entries << 12, y = first position, z = end, w = table offset
+// in the pool (uniform units: first position of the whole group)
+__device__ __forceinline__ uint4 ms_unit(uint32_t b, uint32_t buf, uint32_t uniform, uint32_t nb, uint32_t s, uint32_t e, uint32_t tbl)
+{
+    return make_uint4(b | (buf << 10) | (uniform << 11) | (nb << 12), s, e, tbl);
+}
+
+// ---- one stable counting pass inside a tile held in registers ------------------------------------------------
+// Item (wave w, step k, lane l) is element w * R * 64 + k * 64 + l of the tile's current order (R = steps per wave,
+// the same for every wave).  Digit of an item: bits sh .. sh+7 of v[k].  Leaves in pos (16 bits per item) the
+// item's slot in the new order.  The ranking is radix_scatter's: match-any by ballots, per-wave LDS counters.
+template <typename T>
+__device__ __forceinline__ void tile_rank(const T (&v)[MS_ITEMS], int sh, int nbits, uint32_t actmask, int R, uint32_t (*cur)[256], uint32_t *ls,
+                                          uint32_t (&pos)[MS_ITEMS / 2])
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t dmask = (1u << nbits) - 1u;
+    for (int k = threadIdx.x; k < MS_NW * 256; k += MS_THREADS) (&cur[0][0])[k] = 0;
+    __syncthreads();
+    uint32_t wr[MS_ITEMS / 2];
+#pragma unroll
+    for (int k = 0; k < MS_ITEMS / 2; k++) wr[k] = 0;
+#pragma unroll
+    for (int k = 0; k < MS_ITEMS; k++) {
+        if (k < R) {
+            const bool act = (actmask >> k) & 1u;
+            const uint32_t d = (uint32_t)(v[k] >> sh) & dmask;
+            const u64 m0 = __ballot(act);
+            uint32_t mlo = (uint32_t)m0, mhi = (uint32_t)(m0 >> 32);
+#pragma unroll
+            for (int bit = 0; bit < 8; bit++) {
+                if (bit < nbits) { // (the same for every lane)
+                    const int om = ((int)(d << (31 - bit))) >> 31;
+                    const u64 bm = __builtin_amdgcn_ballot_w64(om != 0);
+                    mlo &= ~((uint32_t)bm ^ (uint32_t)om);
+                    mhi &= ~((uint32_t)(bm >> 32) ^ (uint32_t)om);
+                }
+            }
+            if (act) {
+                const uint32_t before = cur[wave][d];
+                const uint32_t off = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+                if (off == 0) cur[wave][d] = before + (uint32_t)(__popc(mlo) + __popc(mhi));
+                wr[k >> 1] |= (before + off) << (16 * (k & 1));
+            }
+            asm volatile("" ::: "memory"); // (LDS operations of one wavefront execute in order; see radix_scatter)
+        }
+    }
+    __syncthreads();
+    // digit totals -> exclusive starts (threads 0..255 = digits: four wavefronts scan, their sums meet in LDS)
+    uint32_t mytot = 0, inc = 0;
+    if (threadIdx.x < 256) {
+#pragma unroll
+        for (int w = 0; w < MS_NW; w++) mytot += cur[w][threadIdx.x];
+        inc = wave_incl_add(mytot, lane);
+        if (lane == 63) ls[wave] = inc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        uint32_t g = inc - mytot;
+        for (int w = 0; w < wave; w++) g += ls[w];
+#pragma unroll
+        for (int w = 0; w < MS_NW; w++) {
+            const uint32_t t = cur[w][threadIdx.x];
+            cur[w][threadIdx.x] = g;
+            g += t;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MS_ITEMS / 2; k++) pos[k] = 0;
+#pragma unroll
+    for (int k = 0; k < MS_ITEMS; k++) {
+        if (k < R && ((actmask >> k) & 1u)) pos[k >> 1] |= (cur[wave][(uint32_t)(v[k] >> sh) & dmask] + ((wr[k >> 1] >> (16 * (k & 1))) & 0xFFFFu)) << (16 * (k & 1));
+    }
+}
+
+// A run of equal keys inside one row of 64 sorted items claims its room with ONE atomic add on the key's cursor.
+// `head`: this lane starts a run; `nact`: active lanes of the row (a prefix).  Returns the lane's destination.
+__device__ __forceinline__ uint32_t row_claim(bool act, bool head, uint32_t *cursor, int lane)
+{
+    const u64 hm = __ballot(head), am = __ballot(act);
+    const u64 upto = (2ull << lane) - 1ull; // bits 0..lane (lane 63: all)
+    const u64 below = hm & upto, above = hm & ~upto;
+    const int myhead = below ? 63 - __clzll((long long)below) : 0;
+    const int nexth = above ? __ffsll((long long)above) - 1 : (int)__popcll(am);
+    uint32_t base = 0;
+    if (act && head) base = atomicAdd(cursor, (uint32_t)(nexth - lane));
+    base = (uint32_t)__shfl((int)base, myhead, 64);
+    return base + (uint32_t)(lane - myhead);
+}
+
+// ---- 2-byte histogram -------------------------------------------------------------------------------------------
+constexpr int BGH_SEGS = 16; // a workgroup counts at most ceil(n / 16) + 16 < 65536 positions: 16-bit counters cannot overflow
+__global__ void __launch_bounds__(1024) bigram_hist(Msd m)
+{
+    const uint32_t b = blockIdx.y, n = m.n[b];
+    if (m.force_old || n == 0) return;
+    const uint8_t *s = m.blk + (size_t)b * m.S;
+    const uint32_t per = ((n + BGH_SEGS - 1) / BGH_SEGS + 15u) & ~15u;
+    const uint32_t lo = min(n, blockIdx.x * per), hi = min(n, lo + per);
+    if (lo >= hi) return;
+    __shared__ uint32_t h[MS_BG / 2];
+    for (int k = threadIdx.x * 4; k < (int)(MS_BG / 2); k += 4096) *reinterpret_cast<uint4 *>(&h[k]) = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    // 16 positions a thread and step: one aligned 16-byte load + the byte behind it; equal neighbouring bigrams
+    // (a run of one byte) share one add
+    for (uint32_t i = lo + threadIdx.x * 16; i < hi; i += 16384) {
+        if (i + 17 <= hi || (i + 16 <= hi && i + 16 < n)) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(s + i); // (lo and the block base are 16-byte aligned)
+            const uint32_t w[5] = {q.x, q.y, q.z, q.w, (uint32_t)s[i + 16]};
+            uint32_t curk = 0xFFFFFFFFu, cnt = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t c0 = (w[k >> 2] >> ((k & 3) * 8)) & 255u, c1 = (w[(k + 1) >> 2] >> (((k + 1) & 3) * 8)) & 255u;
+                const uint32_t key = (c0 << 8) | c1;
+                if (key != curk) {
+                    if (cnt) atomicAdd(&h[curk >> 1], cnt << (16 * (curk & 1)));
+                    curk = key;
+                    cnt = 0;
+                }
+                cnt++;
+            }
+            atomicAdd(&h[curk >> 1], cnt << (16 * (curk & 1)));
+        } else {
+            for (uint32_t j = i; j < min(hi, i + 16); j++) {
+                const uint32_t key = ((uint32_t)s[j] << 8) | s[j + 1 < n ? j + 1 : 0];
+                atomicAdd(&h[key >> 1], 1u << (16 * (key & 1)));
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *cur = m.bgcur + (size_t)b * MS_BG;
+    for (int w = threadIdx.x; w < (int)(MS_BG / 2); w += 1024) {
+        const uint32_t v = h[w];
+        if (v & 0xFFFFu) atomicAdd(&cur[2 * w], v & 0xFFFFu);
+        if (v >> 16) atomicAdd(&cur[2 * w + 1], v >> 16);
+    }
+}
+
+// ---- plan of a block ----------------------------------------------------------------------------------------------
+// Units are packed greedily over the non-empty buckets in order: a bucket joins the unit before it unless the unit
+// would exceed MS_TILE suffixes (or, 2-byte level, 256 buckets: the bucket index is one more 8-bit digit); a bucket
+// of more than MS_TILE suffixes is a unit of its own kind: an oversized bucket for the next level.
+__device__ __forceinline__ uint32_t ms_class(uint32_t c) { return c <= MS_SMALL ? 0u : (c <= (uint32_t)MS_TILE ? 1u : 2u); }
+constexpr uint32_t MS_NE_MAX = 8192; // non-empty 2-byte buckets the greedy packing holds in LDS (text has ~1,000-5,000);
+                                     // beyond that (random data: all 65,536, tiny) buckets are packed by position window
+
+// Appends an oversized bucket [s, e) of block b to level L: slot of the block, cleared digit counters, its tiles.
+// Called by ONE thread per bucket.
+__device__ __forceinline__ void ms_push_seg(const Msd &m, uint32_t L, uint32_t b, uint32_t s, uint32_t e)
+{
+    const uint32_t slot = atomicAdd(ms_slot_counter(m, L, b), 1u);
+    if (slot >= MS_SEG_SLOTS) { // more than n / MS_TILE oversized buckets in one level: impossible
+        atomicOr(m.err, ERR_MSD);
+        return;
+    }
+    const uint32_t g = atomicAdd(&m.cnt[MC_SEGS + L], 1u);
+    m.segs[(size_t)L * m.B * MS_SEG_SLOTS + g] = make_uint4(b | (slot << 10), s, e, 0u);
+    uint32_t *row = ms_seg_cur_row(m, L, b, slot);
+    for (int d = 0; d < 256; d += 4) *reinterpret_cast<uint4 *>(row + d) = make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t tiles = (e - s + MS_TILE - 1) / MS_TILE;
+    const uint32_t i0 = atomicAdd(&m.cnt[MC_ITEMS + L], tiles);
+    if (i0 + tiles > m.B * MS_ITEM_CAP) {
+        atomicOr(m.err, ERR_MSD);
+        return;
+    }
+    for (uint32_t t = 0; t < tiles; t++) m.items[(size_t)L * m.B * MS_ITEM_CAP + i0 + t] = g | (t << 20);
+}
+
+__device__ __forceinline__ void ms_push_unit(const Msd &m, uint4 u)
+{
+    const uint32_t i = atomicAdd(&m.cnt[MC_UNITS], 1u);
+    if (i >= m.B * MS_UNIT_CAP) {
+        atomicOr(m.err, ERR_MSD);
+        return;
+    }
+    m.units[i] = u;
+}
+
+__global__ void __launch_bounds__(1024) bigram_plan(Msd m, uint32_t *hsum, uint32_t seq)
+{
+    const uint32_t b = blockIdx.x, n = m.n[b], tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    __shared__ u64 tab[MS_NE_MAX];   // the sample test's hash set, then the non-empty buckets: [bucket:16 @40][size:20 @20][start:20]
+    __shared__ uint2 heads[2048];    // unit heads: (start, bucket | oversized << 17)
+    __shared__ uint32_t ls[20];
+    __shared__ uint32_t s_distinct, s_nheads;
+    bool np = !m.force_old && n > 0 && (n + BGH_SEGS - 1) / BGH_SEGS + 16u < 65536u;
+    const uint8_t *s = m.blk + (size_t)b * m.S;
+    if (np && n >= 32768u) {
+        // Repetitive blocks (runs, a tile laid over and over) are better off with the 8-pass path and its SWEEP mode:
+        // sample 4096 rotations; if fewer than half of their 8-byte prefixes are distinct (fewer than ~2,500 equally
+        // frequent 8-byte strings in the whole block) the block stays there.
+        for (int k = tid; k < (int)MS_NE_MAX; k += 1024) tab[k] = 0ull;
+        if (tid == 0) s_distinct = 0;
+        __syncthreads();
+        const uint32_t stride = n / MS_SAMPLES;
+        uint32_t mine = 0;
+        u64 v[MS_SAMPLES / 1024];
+#pragma unroll
+        for (uint32_t j = 0; j < MS_SAMPLES / 1024; j++) {
+            const uint32_t p = (tid * (MS_SAMPLES / 1024) + j) * stride;
+            v[j] = 0;
+            if (p + 8 <= n) {
+                __builtin_memcpy(&v[j], s + p, 8);
+            } else {
+                for (uint32_t q = 0; q < 8; q++) v[j] |= (u64)s[(p + q) % n] << (8 * q);
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < MS_SAMPLES / 1024; j++) {
+            u64 x = v[j] ^ 0xA5A5A5A5A5A5A5A5ull;
+            if (x == 0) x = 1;
+            uint32_t slot = (uint32_t)((x * 0x9E3779B97F4A7C15ull) >> 51) & (MS_NE_MAX - 1);
+            for (;;) {
+                const u64 old = atomicCAS((unsigned long long *)&tab[slot], 0ull, (unsigned long long)x);
+                if (old == 0ull) {
+                    mine++;
+                    break;
+                }
+                if (old == x) break;
+                slot = (slot + 1) & (MS_NE_MAX - 1);
+            }
+        }
+        mine = wave_reduce_add(mine);
+        if (lane == 0 && mine) atomicAdd(&s_distinct, mine);
+        __syncthreads();
+        np = (uint64_t)s_distinct * 2u >= (uint64_t)MS_SAMPLES;
+    }
+    if (tid == 0) {
+        m.np[b] = np ? 1u : 0u;
+        const uint32_t k = atomicAdd(&m.cnt[np ? MC_NEW : MC_OLD], 1u);
+        (np ? m.act_new : m.act_old)[k] = b;
+    }
+    if (np) {
+        uint32_t *cur = m.bgcur + (size_t)b * MS_BG;
+        uint32_t *st = m.pool + (size_t)b * MS_BG_ROW;
+        const uint32_t k0 = tid * 64;
+        // pass A: my 64 buckets -- suffixes, non-empty buckets
+        uint32_t tot = 0, ne = 0;
+        for (int q = 0; q < 64; q += 4) {
+            const uint4 c4 = *reinterpret_cast<const uint4 *>(cur + k0 + q);
+            tot += c4.x + c4.y + c4.z + c4.w;
+            ne += (c4.x != 0u) + (c4.y != 0u) + (c4.z != 0u) + (c4.w != 0u);
+        }
+        uint32_t all, NE;
+        const uint32_t exT = block_excl_add(tot, ls, &all);
+        const uint32_t exNE = block_excl_add(ne, ls, &NE);
+        if (all != n && tid == 0) atomicOr(m.err, ERR_MSD);
+        const bool greedy = NE <= MS_NE_MAX;
+        // pass B: bucket starts (kept for the finishing kernel) = claim cursors of the partition; the non-empty buckets
+        // in order into LDS (the hash set is no longer needed: every thread passed the barriers of the scans)
+        {
+            uint32_t run = exT, j = exNE;
+            for (int q = 0; q < 64; q += 4) {
+                const uint4 c4 = *reinterpret_cast<const uint4 *>(cur + k0 + q);
+                const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+                uint32_t o[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    o[t] = run;
+                    if (c[t] && greedy) tab[j++] = ((u64)(k0 + q + t) << 40) | ((u64)c[t] << 20) | run;
+                    run += c[t];
+                }
+                *reinterpret_cast<uint4 *>(st + k0 + q) = make_uint4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<uint4 *>(cur + k0 + q) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+            if (tid == 1023) st[MS_BG] = run; // = n
+        }
+        if (tid == 0) s_nheads = 0;
+        __syncthreads();
+        if (greedy) {
+            if (wave == 0) { // one wavefront packs: 64 buckets a step, one ballot round per unit that starts among them
+                uint32_t ubase = 0, uidx = 0, nh = 0;
+                bool open = false, carry_over = false;
+                for (uint32_t i0 = 0; i0 < NE; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    const bool valid = i < NE;
+                    const u64 e = valid ? tab[i] : 0ull;
+                    const uint32_t stt = (uint32_t)e & 0xFFFFFu, c = (uint32_t)(e >> 20) & 0xFFFFFu;
+                    const bool over = valid && c > (uint32_t)MS_TILE;
+                    bool pover = __shfl_up((int)over, 1, 64) != 0;
+                    if (lane == 0) pover = carry_over;
+                    carry_over = __shfl((int)over, 63, 64) != 0;
+                    const uint32_t end = stt + c;
+                    u64 todo = __ballot(valid);
+                    while (todo) {
+                        const bool brk = valid && (!open || over || pover || end - ubase > (uint32_t)MS_TILE || i - uidx >= 256u);
+                        const u64 bm = __ballot(brk) & todo;
+                        if (!bm) break;
+                        const int f = __ffsll((long long)bm) - 1;
+                        ubase = (uint32_t)__shfl((int)stt, f, 64);
+                        uidx = i0 + (uint32_t)f;
+                        open = true;
+                        if (lane == f && nh < 2048u) heads[nh] = make_uint2(stt, (uint32_t)(e >> 40) | ((over ? 2u : 0u) << 17));
+                        nh++;
+                        todo &= ~((2ull << f) - 1ull);
+                    }
+                }
+                if (lane == 0) {
+                    s_nheads = nh;
+                    if (nh > 2048u) atomicOr(m.err, ERR_MSD); // (cannot happen: at most ~n / MS_TILE * 2 + NE / 256 units)
+                }
+            }
+        } else {
+            // position windows (cls 0: at most MS_SMALL suffixes, 1: at most MS_TILE, 2: oversized): a bucket starts a
+            // unit if it is not small, if the bucket before it is not small, if it starts in another MS_WIN window than
+            // the bucket before it, or if it is the 256th since -- a unit of small buckets stays below MS_WIN + MS_SMALL.
+            uint32_t nh = 0, run = exT, rk = exNE;
+            // state of the non-empty bucket before my range: found by walking back through the starts (rare path)
+            bool e1 = false;
+            uint32_t c1 = 0, w1 = 0;
+            if (rk > 0) {
+                int k = (int)k0 - 1;
+                while (k >= 0 && st[k + 1] == st[k]) k--; // (st is complete: barrier above)
+                if (k >= 0) {
+                    e1 = true;
+                    c1 = ms_class(st[k + 1] - st[k]);
+                    w1 = st[k] / MS_WIN;
+                }
+            }
+            uint32_t hoff = 0;
+            for (int pass = 0; pass < 2; pass++) {
+                uint32_t j = 0;
+                bool e2 = e1;
+                uint32_t c2 = c1, w2 = w1, r2 = rk;
+                run = exT;
+                for (int q = 0; q < 64; q++) {
+                    const uint32_t c = st[k0 + q + 1] - st[k0 + q];
+                    if (c) {
+                        const uint32_t cls = ms_class(c), win = run / MS_WIN;
+                        const bool head = !e2 || cls != 0u || c2 != 0u || win != w2 || (r2 & 255u) == 0u;
+                        if (head) {
+                            if (pass == 1 && hoff + j < 2048u) heads[hoff + j] = make_uint2(run, (k0 + q) | (cls << 17));
+                            j++;
+                        }
+                        e2 = true;
+                        c2 = cls;
+                        w2 = win;
+                        r2++;
+                    }
+                    run += c;
+                }
+                if (pass == 0) {
+                    nh = j;
+                    uint32_t nhall;
+                    hoff = block_excl_add(nh, ls, &nhall);
+                    if (tid == 0) {
+                        s_nheads = nhall;
+                        if (nhall > 2048u) atomicOr(m.err, ERR_MSD);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t H = min(s_nheads, 2048u);
+        for (uint32_t i = tid; i < H; i += 1024) {
+            const uint2 hd = heads[i];
+            const uint32_t us = hd.x, uk = hd.y & 0x1FFFFu, cls = hd.y >> 17;
+            const uint32_t ue = i + 1 < H ? heads[i + 1].x : n;
+            const uint32_t uk1 = i + 1 < H ? (heads[i + 1].y & 0x1FFFFu) : MS_BG;
+            if (cls < 2u) {
+                if (ue - us > (uint32_t)MS_TILE) atomicOr(m.err, ERR_MSD);
+                ms_push_unit(m, ms_unit(b, 0u, 0u, uk1 - uk, us, ue, (uint32_t)((size_t)b * MS_BG_ROW + uk)));
+            } else {
+                ms_push_seg(m, 1u, b, us, ue);
+            }
+        }
+    }
+    // the last block to finish tells the host how many blocks keep the 8-pass path
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        const uint32_t d = atomicAdd(&m.cnt[MC_PLAN_DONE], 1u);
+        if (d == gridDim.x - 1) {
+            hsum[0] = atomicAdd(&m.cnt[MC_OLD], 0u);
+            hsum[1] = atomicAdd(&m.cnt[MC_NEW], 0u);
+            __threadfence_system();
+            __hip_atomic_store(hsum + SUMMARY_WORDS - 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// ---- text -> 2-byte buckets in one pass ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(MS_THREADS, 4) bigram_scatter(Msd m, uint32_t T, Lst lst)
+{
+    uint32_t b, tile;
+    if (!wg_map(T, lst, b, tile)) return;
+    const uint32_t n = m.n[b];
+    const uint32_t tile0 = tile * MS_TILE;
+    if (tile0 >= n) return;
+    const uint32_t valid = min((uint32_t)MS_TILE, n - tile0);
+    const uint8_t *s = m.blk + (size_t)b * m.S;
+    __shared__ uint32_t txt[MS_TILE / 4 + 8]; // text bytes tile0 .. tile0 + MS_TILE + 31 (cyclic)
+    __shared__ uint32_t stage[MS_TILE];
+    __shared__ uint32_t cur[MS_NW][256];
+    __shared__ uint32_t ls[MS_NW + 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        const uint32_t p = tile0 + threadIdx.x * 16;
+        uint4 q;
+        if (p + 16 <= n) {
+            q = *reinterpret_cast<const uint4 *>(s + p); // (block base and tile0 are multiples of 16)
+        } else {
+            uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (uint32_t j = 0; j < 16; j++) {
+                uint32_t x = p + j;
+                if (x >= n) x %= n;
+                w[j >> 2] |= (uint32_t)s[x] << (8 * (j & 3));
+            }
+            q = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        *reinterpret_cast<uint4 *>(&txt[threadIdx.x * 4]) = q;
+        if (threadIdx.x < 8) {
+            uint32_t w = 0;
+            for (uint32_t j = 0; j < 4; j++) {
+                uint32_t x = tile0 + MS_TILE + threadIdx.x * 4 + j;
+                if (x >= n) x %= n;
+                w |= (uint32_t)s[x] << (8 * j);
+            }
+            txt[MS_TILE / 4 + threadIdx.x] = w;
+        }
+    }
+    __syncthreads();
+    const uint8_t *tb = reinterpret_cast<const uint8_t *>(txt);
+    // item = [bigram : 16 @13][offset in the tile : 13]
+    uint32_t v[MS_ITEMS];
+    uint32_t actmask = 0;
+#pragma unroll
+    for (int k = 0; k < MS_ITEMS; k++) {
+        const uint32_t p = wave * (MS_ITEMS * 64) + k * 64 + lane;
+        actmask |= (p < valid ? 1u : 0u) << k;
+        v[k] = ((uint32_t)tb[p] << 21) | ((uint32_t)tb[p + 1] << 13) | p; // (branch-free: slots past `valid` are never ranked)
+    }
+    uint32_t pos[MS_ITEMS / 2];
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+        const int sh = 13 + 8 * pass;
+        tile_rank(v, sh, 8, actmask, MS_ITEMS, cur, ls, pos);
+#pragma unroll
+        for (int k = 0; k < MS_ITEMS; k++)
+            if ((actmask >> k) & 1u) stage[(pos[k >> 1] >> (16 * (k & 1))) & 0xFFFFu] = v[k];
+        __syncthreads();
+        if (pass == 0) {
+#pragma unroll
+            for (int k = 0; k < MS_ITEMS; k++) v[k] = stage[wave * (MS_ITEMS * 64) + k * 64 + lane];
+        }
+    }
+    uint32_t *cursor = m.bgcur + (size_t)b * MS_BG;
+    u64 *dst = m.bufX + (size_t)b * m.S;
+#pragma unroll 2
+    for (int k = 0; k < MS_ITEMS; k++) {
+        const uint32_t p = wave * (MS_ITEMS * 64) + k * 64 + lane;
+        const bool act = p < valid;
+        if (__ballot(act) == 0) break; // (the valid positions are a prefix of the tile)
+        const uint32_t it = act ? stage[p] : 0u;
+        const uint32_t bg = it >> 13;
+        const uint32_t pb = (uint32_t)__shfl_up((int)bg, 1, 64);
+        const bool head = act && (lane == 0 || bg != pb);
+        const uint32_t d = row_claim(act, head, cursor + bg, lane);
+        if (act) {
+            const uint32_t off = it & 8191u, a = off + 2u;
+            const u64 w = ((u64)txt[(a >> 2) + 1] << 32) | txt[a >> 2];
+            const u64 x = w >> (8u * (a & 3u)); // byte 2 of the rotation lowest
+            const u64 key40 = __builtin_bswap64(x << 24) & 0xFFFFFFFFFFull;
+            if (d < n)
+                dst[d] = (key40 << 20) | (u64)(tile0 + off);
+            else
+                atomicOr(m.err, ERR_MSD);
+        }
+    }
+}
+
+// ---- oversized buckets, level by level ------------------------------------------------------------------------------
+__device__ __forceinline__ const u64 *ms_level_src(const Msd &m, uint32_t L) { return ((L - 1) & 1u) ? m.bufY : m.bufX; }
+__device__ __forceinline__ u64 *ms_level_dst(const Msd &m, uint32_t L) { return (L & 1u) ? m.bufY : m.bufX; }
+
+__global__ void __launch_bounds__(MS_THREADS) seg_count(Msd m, uint32_t L)
+{
+    const uint32_t nitems = m.cnt[MC_ITEMS + L];
+    const uint32_t shift = 20u + 8u * (MS_LEVELS - L); // level 1: byte 2 of the rotation = bits 52..59
+    __shared__ uint32_t h[MS_NW][256];
+    const int wave = threadIdx.x >> 6;
+    for (uint32_t it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const uint32_t item = m.items[(size_t)L * m.B * MS_ITEM_CAP + it];
+        const uint4 sg = m.segs[(size_t)L * m.B * MS_SEG_SLOTS + (item & 0xFFFFFu)];
+        const uint32_t b = sg.x & 1023u, slot = sg.x >> 10, t = item >> 20;
+        const uint32_t e0 = sg.y + t * MS_TILE, cntv = min((uint32_t)MS_TILE, sg.z - e0);
+        const u64 *src = ms_level_src(m, L) + (size_t)b * m.S + e0;
+        for (int k = threadIdx.x; k < MS_NW * 256; k += MS_THREADS) (&h[0][0])[k] = 0;
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 0; k < MS_ITEMS; k++) {
+            const uint32_t p = k * MS_THREADS + threadIdx.x;
+            if (p < cntv) atomicAdd(&h[wave][(uint32_t)(src[p] >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            uint32_t c = 0;
+#pragma unroll
+            for (int w = 0; w < MS_NW; w++) c += h[w][threadIdx.x];
+            if (c) atomicAdd(ms_seg_cur_row(m, L, b, slot) + threadIdx.x, c);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) seg_plan(Msd m, uint32_t L)
+{
+    const uint32_t nsegs = m.cnt[MC_SEGS + L];
+    const uint32_t tid = threadIdx.x;
+    __shared__ uint32_t ls[8];
+    __shared__ uint2 bk[256];   // (start, count) of every sub-bucket
+    __shared__ uint2 heads[256];
+    __shared__ uint32_t s_H;
+    for (uint32_t g = blockIdx.x; g < nsegs; g += gridDim.x) {
+        const uint4 sg = m.segs[(size_t)L * m.B * MS_SEG_SLOTS + g];
+        const uint32_t b = sg.x & 1023u, slot = sg.x >> 10, s = sg.y, e = sg.z;
+        uint32_t *row = ms_seg_cur_row(m, L, b, slot);
+        uint32_t *strow = ms_seg_start_row(m, L, b, slot);
+        const uint32_t c = row[tid];
+        uint32_t tot;
+        const uint32_t ex = block_excl_add(c, ls, &tot);
+        if (tot != e - s && tid == 0) atomicOr(m.err, ERR_MSD);
+        const uint32_t start = s + ex;
+        strow[tid] = start;
+        if (tid == 0) strow[256] = e;
+        row[tid] = start; // from here on: the claim cursor of the sub-bucket
+        bk[tid] = make_uint2(start, c);
+        __syncthreads();
+        if (tid == 0) { // greedy packing of the (at most 256) sub-buckets, in order
+            uint32_t nh = 0, ubase = 0;
+            bool open = false, pover = false;
+            for (uint32_t d = 0; d < 256; d++) {
+                const uint2 q = bk[d];
+                if (!q.y) continue;
+                const bool over = q.y > (uint32_t)MS_TILE;
+                if (!open || over || pover || q.x + q.y - ubase > (uint32_t)MS_TILE) {
+                    heads[nh++] = make_uint2(q.x, d | ((over ? 2u : 0u) << 17));
+                    ubase = q.x;
+                    open = true;
+                }
+                pover = over;
+            }
+            s_H = nh;
+        }
+        __syncthreads();
+        const uint32_t H = s_H;
+        if (tid < H) {
+            const uint2 hd = heads[tid];
+            const uint32_t us = hd.x, uk = hd.y & 0x1FFFFu, ucls = hd.y >> 17;
+            const uint32_t ue = tid + 1 < H ? heads[tid + 1].x : e;
+            const uint32_t uk1 = tid + 1 < H ? (heads[tid + 1].y & 0x1FFFFu) : 256u;
+            if (ucls < 2u) {
+                if (ue - us > (uint32_t)MS_TILE) atomicOr(m.err, ERR_MSD);
+                ms_push_unit(m, ms_unit(b, L & 1u, 0u, uk1 - uk, us, ue, (uint32_t)(strow + uk - m.pool)));
+            } else if (L < MS_LEVELS) {
+                ms_push_seg(m, L + 1, b, us, ue);
+            } else { // bytes 0..6 all equal: ONE group, in tiles
+                for (uint32_t q = us; q < ue; q += MS_TILE) ms_push_unit(m, ms_unit(b, L & 1u, 1u, 0u, q, min(ue, q + (uint32_t)MS_TILE), us));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(MS_THREADS, 4) seg_scatter(Msd m, uint32_t L)
+{
+    const uint32_t nitems = m.cnt[MC_ITEMS + L];
+    const uint32_t shift = 20u + 8u * (MS_LEVELS - L);
+    __shared__ u64 stage[MS_TILE];
+    __shared__ uint32_t cur[MS_NW][256];
+    __shared__ uint32_t ls[MS_NW + 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const uint32_t item = m.items[(size_t)L * m.B * MS_ITEM_CAP + it];
+        const uint4 sg = m.segs[(size_t)L * m.B * MS_SEG_SLOTS + (item & 0xFFFFFu)];
+        const uint32_t b = sg.x & 1023u, slot = sg.x >> 10, t = item >> 20;
+        const uint32_t e0 = sg.y + t * MS_TILE, cntv = min((uint32_t)MS_TILE, sg.z - e0);
+        const u64 *src = ms_level_src(m, L) + (size_t)b * m.S + e0;
+        u64 *dst = ms_level_dst(m, L) + (size_t)b * m.S;
+        uint32_t *cursor = ms_seg_cur_row(m, L, b, slot);
+        u64 v[MS_ITEMS];
+        uint32_t actmask = 0;
+#pragma unroll
+        for (int k = 0; k < MS_ITEMS; k++) {
+            const uint32_t p = wave * (MS_ITEMS * 64) + k * 64 + lane;
+            actmask |= (p < cntv ? 1u : 0u) << k;
+            v[k] = src[p < cntv ? p : 0u]; // (branch-free; slots past the end are never ranked)
+        }
+        uint32_t pos[MS_ITEMS / 2];
+        tile_rank(v, (int)shift, 8, actmask, MS_ITEMS, cur, ls, pos);
+#pragma unroll
+        for (int k = 0; k < MS_ITEMS; k++)
+            if ((actmask >> k) & 1u) stage[(pos[k >> 1] >> (16 * (k & 1))) & 0xFFFFu] = v[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < MS_ITEMS; k++) {
+            const uint32_t p = wave * (MS_ITEMS * 64) + k * 64 + lane;
+            const bool act = p < cntv;
+            if (__ballot(act) == 0) continue;
+            const u64 x = act ? stage[p] : 0ull;
+            const uint32_t d = (uint32_t)(x >> shift) & 255u;
+            const uint32_t pd = (uint32_t)__shfl_up((int)d, 1, 64);
+            const bool head = act && (lane == 0 || d != pd);
+            const uint32_t at = row_claim(act, head, cursor + d, lane);
+            if (act) {
+                if (at >= sg.y && at < sg.z)
+                    dst[at] = x;
+                else
+                    atomicOr(m.err, ERR_MSD);
+            }
+        }
+        __syncthreads(); // stage and cur are reused by the next tile
+    }
+}
+
+// ---- one unit = whole buckets, at most a tile: sorted, ranked and routed inside one workgroup ----------------------------
+__global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
+{
+    __shared__ u64 stage[MS_TILE];
+    __shared__ uint32_t cur[MS_NW][256];
+    __shared__ u64 HM[128];          // bucket heads by position (bit per slot), later: group heads per row
+    __shared__ u64 rowlast[128];     // key of the last element of every row
+    __shared__ int carryIn[128], nextFirst[128];
+    __shared__ uint32_t rowpre[128], rowS[128], rowB[128];
+    __shared__ uint32_t ls[MS_NW + 2];
+    __shared__ u64 s_or, s_and;
+    // rank binning (after the sort, when the counters of the passes are free): counts, local starts, cursors, offsets
+    uint32_t *const bh = &cur[0][0], *const bl = &cur[1][0], *const bcur = &cur[2][0], *const bgo = &cur[3][0];
+    __shared__ uint32_t s_unit, s_offS, s_offB, s_totS, s_totB;
+    const uint32_t nunits = min(m.cnt[MC_UNITS], m.B * MS_UNIT_CAP);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t tid = threadIdx.x;
+    // (timing experiments, BZH_MSD_DBG & 16: cycles per phase, summed over the units of the workgroup, to cnt[24 ..])
+    long long t_last = 0;
+    uint32_t t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define MS_T(k)                                                 \
+    if ((m.dbg & 16u) && tid == 0) {                            \
+        const long long t_now = clock64();                      \
+        t_acc[k] += (uint32_t)((t_now - t_last) >> 4);          \
+        t_last = t_now;                                         \
+    }
+    for (;;) {
+        if ((m.dbg & 16u) && tid == 0) t_last = clock64();
+        if (tid == 0) s_unit = atomicAdd(&m.cnt[MC_TICKET], 1u);
+        __syncthreads();
+        const uint32_t u = s_unit;
+        if (u >= nunits) break;
+        const uint4 ud = m.units[u];
+        const uint32_t b = ud.x & 1023u, buf = (ud.x >> 10) & 1u, uniform = (ud.x >> 11) & 1u, nb = ud.x >> 12;
+        const uint32_t s = ud.y, e = ud.z, tbl = ud.w, len = e - s;
+        const uint32_t n = m.n[b];
+        if (len == 0 || len > (uint32_t)MS_TILE) {
+            if (tid == 0) atomicOr(m.err, ERR_MSD);
+            __syncthreads();
+            continue;
+        }
+        MS_T(0);
+        const u64 *src = (buf ? m.bufY : m.bufX) + (size_t)b * m.S + s;
+        const int R = (int)((len + 511u) / 512u);       // rows of 64 per wave
+        const uint32_t Lw = (uint32_t)R * 64u;          // positions per wave
+        const uint32_t nrows = (len + 63u) / 64u;       // rows of the unit (row r = positions 64 r ..)
+        // ---- load; bucket index of every position from the bucket starts
+        u64 x[MS_ITEMS];
+        uint32_t suf[MS_ITEMS];
+        uint32_t actmask = 0;
+        if (tid < 128) HM[tid] = 0ull;
+        if (tid == 0) {
+            s_or = 0ull;
+            s_and = ~0ull;
+        }
+        __syncthreads();
+        const bool multi = !uniform && nb > 1u;
+        if (multi) {
+            const uint32_t *tb = m.pool + tbl;
+            for (uint32_t k = tid; k < nb; k += MS_THREADS) {
+                const uint32_t st0 = tb[k], st1 = tb[k + 1];
+                if (st1 > st0) {
+                    const uint32_t p = st0 - s;
+                    if (p < len)
+                        atomicOr((unsigned long long *)&HM[p >> 6], 1ull << (p & 63u));
+                    else
+                        atomicOr(m.err, ERR_MSD);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MS_ITEMS; k++) {
+            const uint32_t p = wave * Lw + k * 64 + lane; // (at most 8191)
+            const bool act = k < R && p < len;
+            actmask |= (act ? 1u : 0u) << k;
+            const u64 w = src[act ? p : 0u]; // (branch-free: slots past the end are never ranked, stored or counted)
+            suf[k] = (uint32_t)(w & SUF_MASK);
+            x[k] = ((w >> 20) << 13) | p;
+        }
+        __syncthreads();
+        uint32_t nbk = 1; // non-empty buckets of the unit
+        if (multi) {
+            const uint32_t pc = tid < 128 ? (uint32_t)__popcll(HM[tid]) : 0u;
+            const uint32_t ex = block_excl_add(pc, ls, &nbk);
+            if (tid < 128) rowpre[tid] = ex;
+            if (nbk > 256u && tid == 0) atomicOr(m.err, ERR_MSD);
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < MS_ITEMS; k++) {
+                if ((actmask >> k) & 1u) {
+                    const uint32_t p = wave * Lw + k * 64 + lane, row = p >> 6;
+                    const uint32_t bi = rowpre[row] + (uint32_t)__popcll(HM[row] & ((2ull << (p & 63u)) - 1ull)) - 1u;
+                    x[k] |= (u64)(bi & 255u) << 53;
+                }
+            }
+        }
+        MS_T(1);
+        // ---- which digits vary inside the unit?  (a level-L unit shares bytes 2 .. 1+L; a single bucket has one index)
+        {
+            u64 o = 0ull, a = ~0ull;
+#pragma unroll
+            for (int k = 0; k < MS_ITEMS; k++) {
+                if ((actmask >> k) & 1u) {
+                    o |= x[k];
+                    a &= x[k];
+                }
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                o |= ((u64)(uint32_t)__shfl_xor((int)(o >> 32), d, 64) << 32) | (uint32_t)__shfl_xor((int)o, d, 64);
+                a &= ((u64)(uint32_t)__shfl_xor((int)(a >> 32), d, 64) << 32) | (uint32_t)__shfl_xor((int)a, d, 64);
+            }
+            if (lane == 0) {
+                atomicOr((unsigned long long *)&s_or, (unsigned long long)o);
+                atomicAnd((unsigned long long *)&s_and, (unsigned long long)a);
+            }
+        }
+        __syncthreads();
+        const u64 vary = uniform ? 0ull : (s_or & ~s_and);
+        MS_T(2);
+        uint32_t pos[MS_ITEMS / 2];
+#pragma unroll 1
+        for (int pass = 0; pass < 6; pass++) {
+            const int sh = pass < 5 ? 13 + 8 * pass : 53;
+            if (((vary >> sh) & 255ull) == 0ull) continue; // (the same for every thread)
+            if ((m.dbg & 1u) || ((m.dbg & 2u) && pass == 5)) continue;
+            const int nbits = pass < 5 ? 8 : max(1, 32 - __clz((int)(min(nbk, 256u) - 1u)));
+            tile_rank(x, sh, nbits, actmask, R, cur, ls, pos);
+#pragma unroll
+            for (int k = 0; k < MS_ITEMS; k++)
+                if ((actmask >> k) & 1u) stage[(pos[k >> 1] >> (16 * (k & 1))) & 0xFFFFu] = x[k];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < MS_ITEMS; k++) x[k] = stage[wave * Lw + k * 64 + lane];
+        }
+        MS_T(3);
+        __syncthreads(); // everybody has its sorted elements; the stage is free
+        if (m.dbg & 4u) continue;
+        // ---- suffixes follow their elements (they stayed in the registers of the slot they were loaded at)
+        {
+            uint32_t *st32 = reinterpret_cast<uint32_t *>(stage);
+#pragma unroll
+            for (int k = 0; k < MS_ITEMS; k++)
+                if ((actmask >> k) & 1u) st32[wave * Lw + k * 64 + lane] = suf[k];
+            // group structure meanwhile: last key of every row
+#pragma unroll
+            for (int k = 0; k < MS_ITEMS; k++) {
+                if (k < R) {
+                    const uint32_t p = wave * Lw + k * 64 + lane;
+                    if (p < len && (lane == 63 || p == len - 1)) rowlast[p >> 6] = x[k] >> 13;
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const uint32_t *st32 = reinterpret_cast<const uint32_t *>(stage);
+#pragma unroll
+            for (int k = 0; k < MS_ITEMS; k++) suf[k] = st32[(uint32_t)x[k] & 8191u];
+        }
+        // group heads: ballot per row; carries across rows through LDS
+        uint32_t nheads = 0;
+#pragma unroll
+        for (int k = 0; k < MS_ITEMS; k++) {
+            if (k < R) {
+                const uint32_t p = wave * Lw + k * 64 + lane, row = p >> 6;
+                const bool act = p < len;
+                const u64 key = x[k] >> 13;
+                u64 prev = ((u64)(uint32_t)__shfl_up((int)(key >> 32), 1, 64) << 32) | (uint32_t)__shfl_up((int)key, 1, 64);
+                if (lane == 0 && act && row > 0) prev = rowlast[row - 1];
+                const bool bd = act && (p == 0 || uniform == 0u) && (p == 0 || key != prev);
+                const u64 hm = __ballot(bd);
+                if (lane == 0 && act) { // (the active positions of a row are a prefix of it)
+                    HM[row] = hm;
+                    carryIn[row] = hm ? (int)(row * 64u) + 63 - __clzll((long long)hm) : -1;        // (last head of the row)
+                    nextFirst[row] = hm ? (int)(row * 64u) + __ffsll((long long)hm) - 1 : INT32_MAX; // (first head of the row)
+                }
+                nheads += lane == 0 ? (uint32_t)__popcll(hm) : 0u;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) { // exclusive prefix max of the last heads, exclusive suffix min of the first heads, over the rows
+            const uint32_t r0 = lane * 2u, r1 = r0 + 1u;
+            const int a0 = r0 < nrows ? carryIn[r0] : -1, a1 = r1 < nrows ? carryIn[r1] : -1;
+            const int f0 = r0 < nrows ? nextFirst[r0] : INT32_MAX, f1 = r1 < nrows ? nextFirst[r1] : INT32_MAX;
+            int inc = max(a0, a1);
+            inc = wave_incl_max(inc, lane);
+            int exm = __shfl_up(inc, 1, 64);
+            if (lane == 0) exm = -1;
+            int sm = min(f0, f1); // inclusive suffix min
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl_down(sm, d, 64);
+                if (lane + d < 64) sm = min(sm, t);
+            }
+            int exs = __shfl_down(sm, 1, 64);
+            if (lane == 63) exs = INT32_MAX;
+            if (r0 < nrows) {
+                carryIn[r0] = exm;
+                nextFirst[r0] = min(f1, exs);
+            }
+            if (r1 < nrows) {
+                carryIn[r1] = max(exm, a0);
+                nextFirst[r1] = exs;
+            }
+        }
+        __syncthreads();
+        MS_T(4);
+        // class of every element, rank words, counts of the two lists
+        uint32_t headg[MS_ITEMS]; // [class:2 @30][rank = first position of the group in the block's order : 20]
+#pragma unroll
+        for (int k = 0; k < MS_ITEMS; k++) {
+            headg[k] = 0;
+            if (k < R) {
+                const uint32_t p = wave * Lw + k * 64 + lane, row = p >> 6;
+                const bool act = p < len;
+                uint32_t c = CLS_SINGLE, hg = 0;
+                if (act) {
+                    if (uniform) {
+                        c = CLS_BIG;
+                        hg = tbl;
+                    } else {
+                        const u64 hm = HM[row];
+                        const u64 upto = (2ull << lane) - 1ull;
+                        const u64 below = hm & upto, above = hm & ~upto;
+                        const int head = below ? (int)(row * 64u) + 63 - __clzll((long long)below) : carryIn[row];
+                        int end = above ? (int)(row * 64u) + __ffsll((long long)above) - 1 : nextFirst[row];
+                        if (end > (int)len) end = (int)len;
+                        const uint32_t size = (uint32_t)(end - head);
+                        c = size == 1u ? CLS_SINGLE : (size <= (uint32_t)TAIL_G ? CLS_SMALL : CLS_BIG);
+                        hg = s + (uint32_t)head;
+                    }
+                }
+                headg[k] = (c << 30) | hg;
+                const u64 mS = __ballot(act && c == CLS_SMALL), mB = __ballot(act && c == CLS_BIG);
+                if (lane == 0 && act) {
+                    rowS[row] = (uint32_t)__popcll(mS);
+                    rowB[row] = (uint32_t)__popcll(mB);
+                }
+            }
+        }
+        if (tid < 256) bh[tid] = 0;
+        nheads = wave_reduce_add(nheads);
+        if (lane == 0 && nheads) atomicAdd(&m.c_groups[b], nheads);
+        __syncthreads();
+        if (wave == 0) { // exclusive scans of the row counts; room in the two lists
+            const uint32_t r0 = lane * 2u, r1 = r0 + 1u;
+            const uint32_t s0 = r0 < nrows ? rowS[r0] : 0u, s1 = r1 < nrows ? rowS[r1] : 0u;
+            const uint32_t b0 = r0 < nrows ? rowB[r0] : 0u, b1 = r1 < nrows ? rowB[r1] : 0u;
+            const uint32_t is = wave_incl_add(s0 + s1, lane), ib = wave_incl_add(b0 + b1, lane);
+            if (r0 < nrows) {
+                rowS[r0] = is - s0 - s1;
+                rowB[r0] = ib - b0 - b1;
+            }
+            if (r1 < nrows) {
+                rowS[r1] = is - s1;
+                rowB[r1] = ib - b1;
+            }
+            if (lane == 63) {
+                s_totS = is;
+                s_totB = ib;
+                s_offS = is ? atomicAdd(&m.c_small[b], is) : 0u;
+                s_offB = ib ? atomicAdd(&m.c_big[b], ib) : 0u;
+            }
+        }
+        // rank binning, step 1: counts per 4096-suffix window (the suffix table in the stage is no longer needed)
+#pragma unroll
+        for (int k = 0; k < MS_ITEMS; k++)
+            if ((actmask >> k) & 1u) atomicAdd(&bh[suf[k] >> 12], 1u);
+        __syncthreads();
+        const uint32_t totS = s_totS, totB = s_totB;
+        MS_T(5);
+        // list records through LDS: small groups at [0, totS), large groups behind them
+#pragma unroll
+        for (int k = 0; k < MS_ITEMS; k++) {
+            if (k < R) {
+                const uint32_t p = wave * Lw + k * 64 + lane, row = p >> 6;
+                const bool act = p < len;
+                const uint32_t c = headg[k] >> 30;
+                const u64 mS = __ballot(act && c == CLS_SMALL), mB = __ballot(act && c == CLS_BIG);
+                if (act && c != CLS_SINGLE) {
+                    const u64 lower = (1ull << lane) - 1ull;
+                    const u64 rec = ((u64)(headg[k] & 0xFFFFFu) << 40) | suf[k];
+                    if (c == CLS_SMALL)
+                        stage[rowS[row] + (uint32_t)__popcll(mS & lower)] = rec;
+                    else
+                        stage[totS + rowB[row] + (uint32_t)__popcll(mB & lower)] = rec;
+                }
+            }
+        }
+        MS_T(6);
+        // rank binning, step 2: local starts of the bins, their room in the block's windows
+        {
+            const uint32_t c = tid < 256 ? bh[tid] : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_excl_add(c, ls, &tot); // (barriers inside: the list records are in place after it)
+            if (tid < 256) {
+                bl[tid] = ex;
+                bcur[tid] = ex;
+                uint32_t g = 0;
+                if (c) {
+                    g = atomicAdd(&m.bincur[(size_t)b * 256 + tid], c);
+                    const uint32_t w0 = tid * 4096u, wcap = w0 < n ? min(4096u, n - w0) : 0u;
+                    if (g + c > wcap) atomicOr(m.err, ERR_MSD);
+                }
+                bgo[tid] = min(n, tid * 4096u) + g;
+            }
+        }
+        {
+            u64 *ts = m.tail + (size_t)b * m.S + s_offS;
+            u64 *bs = m.big + (size_t)b * m.S + s_offB;
+            for (uint32_t q = tid; q < totS; q += MS_THREADS) ts[q] = stage[q];
+            for (uint32_t q = tid; q < totB; q += MS_THREADS) bs[q] = stage[totS + q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < MS_ITEMS; k++) {
+            if ((actmask >> k) & 1u) {
+                const uint32_t c = headg[k] >> 30, hg = headg[k] & 0xFFFFFu;
+                const uint32_t word = c == CLS_SINGLE ? (hg | RANK_RESOLVED) : hg;
+                stage[atomicAdd(&bcur[suf[k] >> 12], 1u)] = ((u64)word << 32) | suf[k];
+            }
+        }
+        __syncthreads();
+        {
+            u64 *dst = m.binned + (size_t)b * m.S;
+            for (uint32_t q = tid; q < len; q += MS_THREADS) {
+                const u64 w = stage[q];
+                const uint32_t d = ((uint32_t)w & (uint32_t)SUF_MASK) >> 12;
+                dst[bgo[d] + (q - bl[d])] = w;
+            }
+        }
+        MS_T(7);
+        __syncthreads(); // the stage, the bins and s_unit are reused by the next unit
+    }
+    if ((m.dbg & 16u) && tid == 0)
+        for (int k = 0; k < 8; k++) atomicAdd(&m.cnt[24 + k], t_acc[k]);
+#undef MS_T
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+// Queues the bucket-first initial sort for every block of the batch that qualifies (bigram_plan decides on the device)
+// and returns, in *n_old, how many blocks keep the 8-pass path (their ids: bt.ms_old[0 .. n_old), count also on the
+// device in bt.ms_cnt[MC_OLD]).  Outputs for the blocks it handles: (rank word, suffix) pairs binned into `binned`,
+// small-group lists in `tail`, big lists in `big`, c_small / c_big / c_groups -- what refine_one<init> leaves.
+// X / Y: the two list buffers the partition levels alternate between (X also receives the 2-byte partition).
+static int msd_initial_sort(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal, u64 *X, u64 *Y, u64 *big, u64 *tail, u64 *binned,
+                            bool force_old, volatile uint32_t *hrec, uint32_t seq, uint32_t *n_old)
+{
+    Batch &bt = ctx->bt;
+    hipStream_t st = ctx->stream;
+    Msd m{};
+    m.blk = bt.rle;
+    m.n = bt.n;
+    m.S = bt.S;
+    m.B = B;
+    m.bgcur = bt.ms_bgcur;
+    m.pool = bt.ms_pool;
+    m.segcur = bt.ms_segcur;
+    m.units = bt.ms_units;
+    m.segs = bt.ms_segs;
+    m.items = bt.ms_items;
+    m.cnt = bt.ms_cnt;
+    m.np = bt.ms_np;
+    m.act_old = bt.ms_old;
+    m.act_new = bt.ms_new;
+    m.bincur = bt.ms_bincur;
+    m.bufX = X;
+    m.bufY = Y;
+    m.big = big;
+    m.tail = tail;
+    m.binned = binned;
+    m.c_big = bt.c_big;
+    m.c_small = bt.c_small;
+    m.c_groups = bt.c_groups;
+    m.err = bt.errflag;
+    m.force_old = force_old ? 1u : 0u;
+    m.dbg = getenv("BZH_MSD_DBG") ? (uint32_t)atoi(getenv("BZH_MSD_DBG")) : 0u;
+    HIP_TRY(ctx, hipMemsetAsync(bt.ms_cnt, 0, (MS_CNT_WORDS + (size_t)(MS_LEVELS + 1) * B) * sizeof(uint32_t), st));
+    HIP_TRY(ctx, hipMemsetAsync(bt.ms_bincur, 0, (size_t)B * 256 * sizeof(uint32_t), st));
+    {
+        KSpan ks(ctx, K_MSD_PLAN, force_old ? 0 : ntotal, 2);
+        if (!force_old) {
+            HIP_TRY(ctx, hipMemsetAsync(bt.ms_bgcur, 0, (size_t)B * MS_BG * sizeof(uint32_t), st));
+            bigram_hist<<<dim3(BGH_SEGS, B), 1024, 0, st>>>(m);
+        }
+        bigram_plan<<<dim3(B), 1024, 0, st>>>(m, const_cast<uint32_t *>(hrec), seq);
+    }
+    if (!force_old) {
+        const Lst nl{bt.ms_new, bt.ms_cnt + MC_NEW, B};
+        const uint32_t tiles = (nmax + MS_TILE - 1) / MS_TILE;
+        const uint32_t T = tiles | (B < 32 ? WG_SPREAD : 0u);
+        {
+            KSpan ks(ctx, K_MSD_SCATTER, 9 * ntotal);
+            bigram_scatter<<<dim3(xcd_grid(T, B)), MS_THREADS, 0, st>>>(m, T, nl);
+        }
+        {
+            KSpan ks(ctx, K_MSD_LEVELS, 0, 3 * MS_LEVELS);
+            for (uint32_t L = 1; L <= MS_LEVELS; L++) {
+                seg_count<<<dim3(1024), MS_THREADS, 0, st>>>(m, L);
+                seg_plan<<<dim3(256), 256, 0, st>>>(m, L);
+                seg_scatter<<<dim3(1024), MS_THREADS, 0, st>>>(m, L);
+            }
+        }
+        {
+            KSpan ks(ctx, K_MSD_FINISH, 16 * ntotal);
+            chunk_finish<<<dim3(512), MS_THREADS, 0, st>>>(m);
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    // how many blocks keep the 8-pass path: bigram_plan's record (it ran long ago: the host waits for the first kernels only)
+    for (uint64_t it = 0, idle = 0; hrec[SUMMARY_WORDS - 1] != seq; it++) {
+        if ((it & 0xFFFu) == 0xFFFu) {
+            const hipError_t e = hipStreamQuery(st);
+            if (e != hipSuccess && e != hipErrorNotReady) HIP_TRY(ctx, e);
+            if (e == hipSuccess && ++idle > 64) {
+                bzh_set_error(ctx, "BWT: the plan of the initial sort never reported (internal error)");
+                return BZH_E_HIP;
+            }
+        }
+        __builtin_ia32_pause();
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    *n_old = hrec[0];
+    return BZH_OK;
+}

@@ -54,6 +54,8 @@ constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS; // 8192 elements per workgr
                                                      // scan overhead per element against 256 x 16, -7 % on the bench)
 constexpr uint32_t RANK_RESOLVED = 0x80000000u;      // suffix is alone in its group
 constexpr int SUMMARY_WORDS = 20; // round summary: see round_begin (bwt.hip)
+constexpr uint32_t MS_BG_ROW = 65552, MS_LEVELS = 5, MS_SEG_SLOTS = 112, MS_SEG_ROW = 264, MS_UNIT_CAP = 4096, MS_ITEM_CAP = 224,
+                   MS_CNT_WORDS = 32, MS_MIN_N = 131072; // (levels whose blocks stay below MS_MIN_N bytes keep the 8-pass path: no tables for them)
 constexpr int MAX_ROUNDS = 30; // depth 8 doubles every round and ends at 2^20; < 31 keeps the rank words' round tags unique
 
 struct BlockDesc { // device-side description of one planned block (mirrors bzh_block + restart info)
@@ -105,6 +107,18 @@ struct Batch {
     uint32_t *summary;  // [SUMMARY_WORDS] what the host reads, one round late
     unsigned long long *stat_A; // [1] sum over rounds of the unresolved suffixes entering them
     uint32_t *errflag; // [1]
+    // bucket-first initial sort (bwt_msd.h): 2-byte buckets, oversized buckets split level by level, every bucket
+    // that fits a tile finished inside one workgroup
+    uint32_t *ms_bgcur;  // [B][65536] bigram counts, then claim cursors of the partition
+    uint32_t *ms_pool;   // bucket starts: [B][MS_BG_ROW] (2-byte buckets), then [MS_LEVELS][B][MS_SEG_SLOTS][MS_SEG_ROW]
+    uint32_t *ms_segcur; // [MS_LEVELS][B][MS_SEG_SLOTS][256] digit counts of an oversized bucket, then claim cursors
+    uint4 *ms_units;     // [B * MS_UNIT_CAP] work list of the finishing kernel
+    uint4 *ms_segs;      // [MS_LEVELS + 1][B * MS_SEG_SLOTS] oversized buckets per level
+    uint32_t *ms_items;  // [MS_LEVELS + 1][B * MS_ITEM_CAP] (oversized bucket, tile) pairs per level
+    uint32_t *ms_cnt;    // [MS_CNT_WORDS + (MS_LEVELS + 1) * B] counters; per-block slot counters of the levels behind them
+    uint32_t *ms_np;     // [B] 1: the block takes the bucket-first path (its first doubling round has depth 7)
+    uint32_t *ms_old, *ms_new; // [B] ids of the blocks on the 8-pass path / on the bucket-first path
+    uint32_t *ms_bincur; // [B][256] rank binning: pairs already claimed in each 4096-suffix window
     // MTF / RLE2
     uint8_t *mtfpos;   // [B][S]   MTF position of every BWT byte
     uint8_t *tilelist; // [B][MT][256] recency list at each MTF tile entry
@@ -146,14 +160,15 @@ constexpr uint32_t FX_HDR_BYTES = 64 + 6 * 1152; // + up to 6 delta-coded tables
 enum KClass : int {
     K_PLAN = 0, K_CRC, K_RLE1_EMIT, K_BYTE_COUNT, K_RADIX_INIT, K_RADIX_GID, K_REFINE_INIT, K_RANK_APPLY,
     K_ROUND_BEGIN, K_SWEEP, K_ACTIVE_GEN, K_RADIX_ROUNDS, K_TAIL_ROUND, K_REFINE_ROUNDS, K_BWT_EMIT, K_MTF_LAST,
-    K_MTF_WALK, K_RLE2, K_HUFF, K_PACK, K_COUNT
+    K_MTF_WALK, K_RLE2, K_HUFF, K_PACK, K_MSD_PLAN, K_MSD_SCATTER, K_MSD_LEVELS, K_MSD_FINISH, K_COUNT
 };
 static const char *const KCLASS_NAME[K_COUNT] = {
     "plan (granules, carries, split)", "crc_tiles", "rle1_emit", "byte_count", "radix_scatter (initial sort)",
     "radix_scatter<GID> (re-key pass)", "refine_one<init> (+ rank binning)", "rank_apply", "round_begin",
     "SWEEP path (3 passes + 3-kernel refine)", "active_gen", "radix_scatter (big-list rounds)", "tail_round",
     "refine_one (rounds)", "bwt_emit", "mtf_tile_last + mtf_prefix", "mtf_walk", "rle2 (tiles, block, emit)",
-    "huffman (segments, build, header)", "pack_symbols"};
+    "huffman (segments, build, header)", "pack_symbols", "bigram_hist + bigram_plan", "bigram_scatter (2-byte buckets)",
+    "seg_count/plan/scatter (oversized buckets)", "chunk_finish (bucket sort + ranks in LDS)"};
 
 struct Timer {
     hipEvent_t a = nullptr, b = nullptr;
