@@ -9,6 +9,8 @@ Everything is computed by hand-written HIP kernels behind the C ABI in include/b
 (libbzhip.so); there is no CPU path.  `reader` is any object with .read(), `writer` any object
 with .write() (the Rust signature takes BufRead / BufWriter<W>).
 """
+import io
+
 from . import _native
 
 __all__ = ["encode", "encode_file", "Context", "BzhError"]
@@ -39,13 +41,27 @@ def encode(reader, writer, level, device=0):
     # incremental ingestion (the reference pulls from fill_buf as it goes, lib/rle.rs:30-92): input is
     # handed to the GPU in chunks, finished stream bytes are written as soon as they are final
     ctx.stream_begin()
+    # one reusable buffer: a reader with readinto() fills it in place (no bytes object per chunk); finished stream
+    # bytes go to the writer as a view of the context's output buffer (no copy on this side either)
+    buf = bytearray(READ_CHUNK) if hasattr(reader, "readinto") else None
     while True:
-        chunk = reader.read(READ_CHUNK)
-        if not isinstance(chunk, (bytes, bytearray, memoryview)):
-            raise TypeError("reader.read() must return bytes")
+        chunk = None
+        if buf is not None:
+            try:
+                got = reader.readinto(buf)
+            except (NotImplementedError, io.UnsupportedOperation):  # e.g. a RawIOBase subclass that only defines read()
+                buf = None
+            else:
+                if got is None:
+                    raise TypeError("reader.readinto() must return a byte count (blocking reader expected)")
+                chunk = memoryview(buf)[:got]
+        if chunk is None:
+            chunk = reader.read(READ_CHUNK)
+            if not isinstance(chunk, (bytes, bytearray, memoryview)):
+                raise TypeError("reader.read() must return bytes")
         eof = len(chunk) == 0
-        out = ctx.stream_feed(chunk, eof)
-        if out:
+        out = ctx.stream_feed_view(chunk, eof)
+        if len(out):
             writer.write(out)
         if eof:
             break

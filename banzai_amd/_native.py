@@ -417,5 +417,17 @@ class Context:
                                          self._sbuf.size, ctypes.byref(got)))
         return self._sbuf[:got.value].tobytes()
 
+    def stream_feed_view(self, data, eof=False):
+        """as stream_feed, but returns a memoryview of the context's output buffer (valid until the next feed)"""
+        n = len(data)
+        a = np.frombuffer(data, dtype=np.uint8) if n else np.zeros(1, np.uint8)
+        need = int(lib().bzh_stream_bound(self._h, n))
+        if self._sbuf is None or self._sbuf.size < need:
+            self._sbuf = np.empty(need, dtype=np.uint8)
+        got = ctypes.c_size_t(0)
+        self.check(lib().bzh_stream_feed(self._h, ptr(a), n, 1 if eof else 0, ptr(self._sbuf), self._sbuf.size,
+                                         ctypes.byref(got)))
+        return memoryview(self._sbuf)[:got.value]
+
     def stream_consumed(self):
         return int(lib().bzh_stream_consumed(self._h))

@@ -296,6 +296,8 @@ extern "C" void bzh_destroy(bzh_ctx *ctx)
     for (int k = 0; k < 2; k++)
         if (ctx->strm.d_buf[k]) hipFree(ctx->strm.d_buf[k]);
     if (ctx->strm.h_out) hipHostFree(ctx->strm.h_out);
+    for (int k = 0; k < 2; k++)
+        if (ctx->strm.d_out[k]) hipFree(ctx->strm.d_out[k]);
     if (ctx->strm.copy_stream) hipStreamDestroy(ctx->strm.copy_stream);
     delete ctx;
 }
@@ -1365,7 +1367,8 @@ static void stream_pass(bzh_ctx *ctx)
         size_t raw = 0;
         for (size_t k = 0; k < F; k++) raw += ctx->plan_blocks[k].in_len;
         const size_t dcap = (raw + raw / 4 + (F + 2) * 4096 + 65536) & ~(size_t)3;
-        BZH_TRY(ensure_stage(ctx, ctx->d_stage_out, ctx->stage_out_size, dcap));
+        BZH_TRY(ensure_stage(ctx, s.d_out[p.obuf], s.d_out_cap[p.obuf], dcap));
+        uint8_t *d_o = s.d_out[p.obuf];
         uint8_t seed_be[4];
         put_be32(seed_be, p.seed);
         uint32_t seed;
@@ -1373,27 +1376,24 @@ static void stream_pass(bzh_ctx *ctx)
         memset(&ctx->stats, 0, sizeof ctx->stats);
         ctx->sort_spans.clear();
         ctx->evnext = 0;
-        BZH_TRY(encode_range(ctx, 0, F, ctx->d_stage_out, ctx->stage_out_size & ~(size_t)3, p.phase, &p.nbits,
-                             p.phase ? &seed : nullptr));
+        kstats_reset(ctx);
+        BZH_TRY(encode_range(ctx, 0, F, d_o, s.d_out_cap[p.obuf] & ~(size_t)3, p.phase, &p.nbits, p.phase ? &seed : nullptr));
         const uint64_t bits_in_buf = p.phase + p.nbits;
         const size_t full_words = (size_t)(bits_in_buf / 32);
-        if (full_words * 4 + 8 > s.h_out_cap) {
-            if (s.h_out) hipHostFree(s.h_out);
-            s.h_out = nullptr;
-            s.h_out_cap = 0;
-            const size_t want = align_up(full_words * 4 + full_words / 2 + 4096, 4096);
-            if (hipHostMalloc((void **)&s.h_out, want) != hipSuccess) {
-                bzh_set_error(ctx, "hipHostMalloc(%zu) failed", want);
+        if (!s.h_out) {
+            if (hipHostMalloc((void **)&s.h_out, 4096) != hipSuccess) {
+                bzh_set_error(ctx, "hipHostMalloc(4096) failed");
                 return BZH_E_NOMEM;
             }
-            s.h_out_cap = want;
+            s.h_out_cap = 4096;
         }
-        const size_t nbytes = full_words * 4 + ((bits_in_buf & 31u) ? 4 : 0);
-        if (nbytes) HIP_TRY(ctx, hipMemcpyAsync(s.h_out, ctx->d_stage_out, nbytes, hipMemcpyDeviceToHost, st));
+        // the whole words stay on the device until the caller's next feed collects them; only the partial word behind
+        // them (it seeds the next pass) comes back now
+        if (bits_in_buf & 31u) HIP_TRY(ctx, hipMemcpyAsync(s.h_out, d_o + full_words * 4, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, bzh_stream_wait(st));
         p.out_bytes = full_words * 4;
         if (bits_in_buf & 31u) {
-            const uint8_t *w = s.h_out + full_words * 4;
+            const uint8_t *w = s.h_out;
             p.lastw = ((uint32_t)w[0] << 24) | ((uint32_t)w[1] << 16) | ((uint32_t)w[2] << 8) | w[3];
         }
         for (size_t k = 0; k < F; k++) p.crcs.push_back(ctx->plan_blocks[k].crc);
@@ -1449,6 +1449,21 @@ extern "C" int bzh_stream_feed(bzh_ctx *ctx, const uint8_t *in, size_t n, int eo
     // 2. take the results of the pass in flight: its bits are final now
     size_t left = 0;
     const uint8_t *tail = nullptr;
+    struct Done {
+        int obuf;
+        size_t bytes;
+    } done[2];
+    int ndone = 0;
+    // the finished passes' words: device -> the caller's buffer (called with the next pass already running)
+    auto drain = [&]() -> int {
+        for (int k = 0; k < ndone; k++) {
+            HIP_TRY(ctx, hipMemcpyAsync(out + opos, s.d_out[done[k].obuf], done[k].bytes, hipMemcpyDeviceToHost, s.copy_stream));
+            opos += done[k].bytes;
+        }
+        if (ndone) HIP_TRY(ctx, bzh_stream_wait(s.copy_stream));
+        ndone = 0;
+        return BZH_OK;
+    };
     auto collect = [&]() -> int {
         stream_join(ctx);
         s.inflight = false;
@@ -1457,8 +1472,7 @@ extern "C" int bzh_stream_feed(bzh_ctx *ctx, const uint8_t *in, size_t n, int eo
             s.active = false;
             return p.rc;
         }
-        memcpy(out + opos, s.h_out, p.out_bytes);
-        opos += p.out_bytes;
+        if (p.out_bytes) done[ndone++] = {p.obuf, p.out_bytes};
         if (p.nbits) {
             s.carry_word = p.lastw;
             s.bitpos += p.nbits;
@@ -1487,17 +1501,21 @@ extern "C" int bzh_stream_feed(bzh_ctx *ctx, const uint8_t *in, size_t n, int eo
         p.eof = eof != 0;
         p.phase = (uint32_t)(s.bitpos & 31u);
         p.seed = s.carry_word;
+        p.obuf = s.osel;
+        s.osel ^= 1;
         s.inflight = true;
         s.worker = std::thread(stream_pass, ctx);
         s.fill ^= 1; // the other buffer is free: its pass was collected above, its tail copied
         s.head = STREAM_HEAD;
         s.pending = 0;
+        BZH_TRY(drain()); // (the pass before this one: its output buffer is the one the pass after this one will use)
         if (!eof) break;
         // 4. end of input: wait for this last pass too (it consumes everything it was given)
         left = 0;
         BZH_TRY(collect());
         if (left == 0) break; // always, at eof; the loop guards against a pass that could not finish its tail
     }
+    BZH_TRY(drain());
 
     if (eof) { // footer + stream CRC (lib/lib.rs:66-70), zero padding to a byte (lib/out.rs:22-28)
         const uint32_t phase = (uint32_t)(s.bitpos & 31u);

@@ -2103,7 +2103,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         const char *e = getenv("BZH_INIT");
         return !(e && !strcmp(e, "msd"));
     }();
-    const bool use_msd = ctx->M >= MS_MIN_N && !a.fault;
+    const bool use_msd = ctx->M >= MS_MIN_N && !a.fault && !init_lsd;
     uint32_t nOld = B;
     Lst oldl = all;
     u64 *const binned = reinterpret_cast<u64 *>(bt.sa);
@@ -2111,7 +2111,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     volatile uint32_t *const hrec0 = ctx->h_pinned + (size_t)mb * 8 + 64; // [MAX_ROUNDS + 1][SUMMARY_WORDS]
     const uint32_t epoch = (++ctx->bwt_epoch & 0xFFFFFFu) << 6;
     if (use_msd) {
-        BZH_TRY(msd_initial_sort(ctx, B, nmax, ntotal, bufB, bufD, bufA, bufC, binned, init_lsd,
+        BZH_TRY(msd_initial_sort(ctx, B, nmax, ntotal, bufB, bufD, bufA, bufC, binned, false,
                                  hrec0 + (size_t)MAX_ROUNDS * SUMMARY_WORDS, epoch + 63u, &nOld));
         oldl = Lst{bt.ms_old, bt.ms_cnt + MC_OLD, B};
         a.lst = oldl;

@@ -235,6 +235,7 @@ struct bzh_ctx {
         bool inflight = false;
         struct Pass {
             int buf = 0;                // which d_buf
+            int obuf = 0;               // which d_out
             size_t off = 0, total = 0;  // input range of the pass
             bool eof = false;
             uint32_t phase = 0, seed = 0; // bit phase / carried bits at the start of the pass
@@ -246,8 +247,13 @@ struct bzh_ctx {
             uint32_t lastw = 0;         // the partial word after them (big-endian value)
             std::vector<uint32_t> crcs; // CRCs of the final blocks, in order
         } pass;
-        uint8_t *h_out = nullptr;       // pinned staging of a pass's output
+        uint8_t *h_out = nullptr;       // pinned: the partial last word of a pass's output
         size_t h_out_cap = 0;
+        // A pass leaves its bits on the device (two buffers, alternating): the next pass is started first, then the
+        // finished one's words go straight to the caller's buffer while the GPU is already at work again.
+        uint8_t *d_out[2] = {nullptr, nullptr};
+        size_t d_out_cap[2] = {0, 0};
+        int osel = 0;
     } strm;
     bzh_stats stats{};
     uint32_t debug_fault = 0;         // bzh_debug_fault: fault to inject into the next suffix sort
