@@ -16,6 +16,8 @@
 // bijective base-2 digits (lib/mtf.rs:46-65) of the zero run that ends just before it, then its
 // own symbol pos+1; offsets by scan; the trailing run and EOB are written by the per-block kernel.
 #include "common.h"
+#include <cstdlib>
+#include <cstring>
 
 constexpr int RLE_THREADS = 256;
 constexpr int RLE_ITEMS = 16;
@@ -261,6 +263,207 @@ __global__ void __launch_bounds__(64) mtf_walk(Batch bt, const int32_t *tlast, u
         walk_tile<4>(s, o, keys, names, lkeys, base_p, tile_len, lane);
 }
 
+// ---- the walk, parallel form: 64 run heads at a time ------------------------------------------------------------
+// mtf_walk above visits the changed bytes of a tile one after the other (a scalar chain per byte: with ~160 byte
+// values and ~45 % changed bytes it is the second most expensive stage of a step).  Here the lanes of the wavefront
+// ARE 64 consecutive run heads (bytes that differ from their predecessor; every other byte has position 0 and leaves
+// the list alone).  With E[s] = position of symbol s in the recency list when the chunk begins:
+//   * a head whose symbol occurred before in the chunk, last at lane p: its position is the number of distinct symbols
+//     between p and itself = the lanes u in (p, l) whose own symbol does not occur in (p, u);
+//   * a head whose symbol is new in the chunk: E[c] + the symbols that were behind c in the list and have been seen
+//     since the chunk began = the lanes u < l that are first occurrences with E[c_u] > E[c].
+//   Both are ONE count over the 64 lanes with per-lane bounds (64 steps of a few vector instructions, no dependent
+//   chain); the previous / next occurrence of every lane's symbol come from one match-any (8 ballots).
+//   * the list for the next chunk: a seen symbol's position = the distinct symbols whose last occurrence in the chunk
+//     is later; an unseen symbol moves back by the seen symbols that were behind it.
+// The list at tile entry is the rank of mtf_prefix's keys (lib/mtf.rs:39-43 for the first tile).
+__global__ void __launch_bounds__(64) mtf_walk_par(Batch bt, const int32_t *tlast, uint32_t MT)
+{
+    const uint32_t b = blockIdx.y, tile = blockIdx.x;
+    const uint32_t n = bt.n[b];
+    const uint32_t base_p = tile * MTF_TILE;
+    if (base_p >= n) return;
+    const int lane = threadIdx.x;
+    __shared__ uint8_t names[256];
+    __shared__ uint32_t ls[4];
+    __shared__ uint16_t Etab[256];         // list position of every name
+    __shared__ uint8_t hsym[MTF_TILE];     // names of the run heads, in order
+    __shared__ uint16_t hoff[MTF_TILE];    // their offsets in the tile
+    __shared__ __attribute__((aligned(16))) uint8_t opos[MTF_TILE]; // positions of the tile's bytes
+    const uint32_t num_names = build_names(bt.hasbyte + (size_t)b * 256, names, ls);
+    const int32_t *keys = tlast + ((size_t)b * MT + tile) * 256;
+    const uint8_t *s = bt.bwt + (size_t)b * bt.S + base_p;
+    uint8_t *o = bt.mtfpos + (size_t)b * bt.S + base_p;
+    const uint32_t remain = n - base_p;
+    const uint32_t tile_len = remain < MTF_TILE ? remain : MTF_TILE;
+    // ---- list at tile entry: E[name] = names with a larger key
+    int k[4] = {keys[lane], keys[64 + lane], keys[128 + lane], keys[192 + lane]};
+    int front;
+    {
+        uint32_t e[4] = {0, 0, 0, 0};
+        const uint32_t regs = (num_names + 63u) / 64u;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if ((uint32_t)r < regs) {
+                const int cnt = (int)min(64u, num_names - 64u * r);
+                for (int j = 0; j < cnt; j++) {
+                    const int kj = rdlane(k[r], j);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) e[q] += kj > k[q] ? 1u : 0u;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) Etab[q * 64 + lane] = (uint16_t)e[q];
+        // the symbol at the head of the list = the byte before the tile (or name 0 at the start of the block)
+        int best = k[0], bsym = lane;
+#pragma unroll
+        for (int q = 1; q < 4; q++)
+            if (k[q] > best) {
+                best = k[q];
+                bsym = q * 64 + lane;
+            }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const int ob = __shfl_xor(best, d, 64), os = __shfl_xor(bsym, d, 64);
+            if (ob > best) {
+                best = ob;
+                bsym = os;
+            }
+        }
+        front = __builtin_amdgcn_readfirstlane(bsym);
+    }
+    // ---- run heads of the tile, compacted into LDS (two halves of 1024 bytes, 16 bytes a lane)
+    uint32_t H = 0;
+    uint32_t carry_last = (uint32_t)front;
+#pragma unroll 1
+    for (uint32_t cbase = 0; cbase < tile_len; cbase += 1024) {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(s + cbase + lane * 16); // (S is padded: the load stays inside the arena)
+        uint32_t in[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const uint32_t w = in[d];
+            in[d] = (uint32_t)names[w & 255u] | ((uint32_t)names[(w >> 8) & 255u] << 8) | ((uint32_t)names[(w >> 16) & 255u] << 16) |
+                    ((uint32_t)names[w >> 24] << 24);
+        }
+        const uint32_t clen = tile_len - cbase < 1024 ? tile_len - cbase : 1024;
+        uint32_t pw = (uint32_t)__shfl_up((int)in[3], 1, 64);
+        if (lane == 0) pw = carry_last << 24;
+        uint32_t chg = 0;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const uint32_t x = in[d];
+            const uint32_t df = x ^ ((x << 8) | (pw >> 24));
+            chg |= ((df & 0xFFu) ? 1u : 0u) << (4 * d);
+            chg |= ((df & 0xFF00u) ? 2u : 0u) << (4 * d);
+            chg |= ((df & 0xFF0000u) ? 4u : 0u) << (4 * d);
+            chg |= ((df & 0xFF000000u) ? 8u : 0u) << (4 * d);
+            pw = x;
+        }
+        {
+            const uint32_t lo = (uint32_t)lane * 16u;
+            const uint32_t nv = clen > lo ? (clen - lo < 16u ? clen - lo : 16u) : 0u;
+            chg &= (1u << nv) - 1u;
+        }
+        { // name of the chunk's last byte, for the next half's first comparison
+            const uint32_t e = clen - 1;
+            const uint32_t w = (uint32_t)rdlane((int)(((e >> 2) & 3u) == 0 ? in[0] : ((e >> 2) & 3u) == 1 ? in[1] : ((e >> 2) & 3u) == 2 ? in[2] : in[3]),
+                                                (int)(e >> 4));
+            carry_last = (w >> (8 * (e & 3u))) & 255u;
+        }
+        const uint32_t mine = (uint32_t)__popc(chg);
+        const uint32_t inc = wave_incl_add(mine, lane);
+        uint32_t at = H + inc - mine;
+#pragma unroll
+        for (int kb = 0; kb < 16; kb++) {
+            if (chg & (1u << kb)) {
+                hsym[at] = (uint8_t)((in[kb >> 2] >> (8 * (kb & 3))) & 255u);
+                hoff[at] = (uint16_t)(cbase + lane * 16 + kb);
+                at++;
+            }
+        }
+        H += (uint32_t)__shfl((int)inc, 63, 64);
+        *reinterpret_cast<uint4 *>(&opos[cbase + lane * 16]) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    // ---- 64 run heads at a time (one wavefront: program order is enough between the LDS phases)
+#pragma unroll 1
+    for (uint32_t hb = 0; hb < H; hb += 64) {
+        const uint32_t idx = hb + (uint32_t)lane;
+        const bool act = idx < H;
+        const uint32_t c = act ? hsym[idx] : 0u;
+        // lanes with my symbol (match-any over the 8 bits of the name)
+        const unsigned long long am = __ballot(act);
+        uint32_t mlo = (uint32_t)am, mhi = (uint32_t)(am >> 32);
+#pragma unroll
+        for (int bit = 0; bit < 8; bit++) {
+            const int om = ((int)(c << (31 - bit))) >> 31;
+            const unsigned long long bm = __builtin_amdgcn_ballot_w64(om != 0);
+            mlo &= ~((uint32_t)bm ^ (uint32_t)om);
+            mhi &= ~((uint32_t)(bm >> 32) ^ (uint32_t)om);
+        }
+        const unsigned long long same = ((unsigned long long)mhi << 32) | mlo;
+        const unsigned long long lower = (1ull << lane) - 1ull, upto = (2ull << lane) - 1ull;
+        const unsigned long long below = same & lower;
+        const int p = below ? 63 - __clzll((long long)below) : -1; // previous occurrence in the chunk
+        const bool islast = act && (same & ~upto) == 0ull;
+        const int Eown = (int)Etab[c];
+        // A = the lanes below me that are the LAST occurrence of their symbol before me: one lane per distinct symbol
+        // seen so far.  They are all lower lanes except the predecessors q_v of the lanes v below me: a prefix OR of
+        // one bit per lane, six shuffle steps on the two halves of the mask.
+        uint32_t xlo = (act && p >= 0 && p < 32) ? 1u << p : 0u, xhi = (act && p >= 32) ? 1u << (p - 32) : 0u;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t tl = (uint32_t)__shfl_up((int)xlo, d, 64), th = (uint32_t)__shfl_up((int)xhi, d, 64);
+            if (lane >= d) {
+                xlo |= tl;
+                xhi |= th;
+            }
+        }
+        { // exclusive: the predecessors of the lanes strictly below me
+            const uint32_t tl = (uint32_t)__shfl_up((int)xlo, 1, 64), th = (uint32_t)__shfl_up((int)xhi, 1, 64);
+            xlo = lane ? tl : 0u;
+            xhi = lane ? th : 0u;
+        }
+        const unsigned long long A = lower & ~(((unsigned long long)xhi << 32) | xlo);
+        int pos;
+        unsigned long long firsts = __ballot(act && p < 0); // one lane per distinct symbol of the chunk
+        const bool more = hb + 64 < H;
+        int eo[4] = {0, 0, 0, 0}, add[4] = {0, 0, 0, 0};
+        if (more) {
+            eo[0] = (int)Etab[lane];
+            eo[1] = (int)Etab[64 + lane];
+            eo[2] = (int)Etab[128 + lane];
+            eo[3] = (int)Etab[192 + lane];
+        }
+        // a symbol that is new in the chunk: its place in the list at chunk entry + the new symbols before it that were
+        // behind it (one step per distinct symbol; the same steps move the unseen symbols of the list back)
+        int cntB = 0;
+        while (firsts) {
+            const int u = __ffsll((long long)firsts) - 1;
+            firsts &= firsts - 1ull;
+            const int eu = rdlane(Eown, u);
+            cntB += (u < lane && eu > Eown) ? 1 : 0;
+            if (more) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) add[q] += eu > eo[q] ? 1 : 0;
+            }
+        }
+        // a symbol seen before in the chunk, last at lane p: the distinct symbols between p and me
+        pos = p < 0 ? Eown + cntB : (int)__popcll(A & ~((2ull << p) - 1ull));
+        if (act) opos[hoff[idx]] = (uint8_t)pos;
+        if (more) { // the list when the next chunk begins
+#pragma unroll
+            for (int q = 0; q < 4; q++) Etab[q * 64 + lane] = (uint16_t)(eo[q] + add[q]);
+            // (seen symbols are overwritten: position = distinct symbols whose last occurrence comes later)
+            const unsigned long long lasts = __ballot(islast);
+            if (islast) Etab[c] = (uint16_t)__popcll(lasts & ~upto);
+        }
+    }
+    if ((uint32_t)lane * 16u < tile_len) *reinterpret_cast<uint4 *>(o + lane * 16) = *reinterpret_cast<const uint4 *>(&opos[lane * 16]);
+    if (1024u + (uint32_t)lane * 16u < tile_len)
+        *reinterpret_cast<uint4 *>(o + 1024 + lane * 16) = *reinterpret_cast<const uint4 *>(&opos[1024 + lane * 16]);
+}
+
 // ---- RLE2 --------------------------------------------------------------------------------------------
 struct RleTile {
     int first_nz; // global position of the first non-zero MTF position in the tile, -1 if none
@@ -471,7 +674,14 @@ int mtf_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     }
     {
         KSpan ks(ctx, K_MTF_WALK, 2 * ntotal);
-        mtf_walk<<<dim3(mt, B), 64, 0, st>>>(bt, tlast, MT);
+        static const bool serial_walk = []() {
+            const char *e = getenv("BZH_MTF");
+            return e && !strcmp(e, "serial");
+        }();
+        if (serial_walk)
+            mtf_walk<<<dim3(mt, B), 64, 0, st>>>(bt, tlast, MT);
+        else
+            mtf_walk_par<<<dim3(mt, B), 64, 0, st>>>(bt, tlast, MT);
     }
     KSpan ks(ctx, K_RLE2, 4 * ntotal, 3); // positions in twice, symbols (<= n, 2 bytes) out
     rle_tiles<<<dim3(rtiles, B), RLE_THREADS, 0, st>>>(bt, rt);
