@@ -249,6 +249,7 @@ extern "C" int bzh_create(bzh_ctx **out, int device, int level, int max_batch)
         delete ctx;
         return BZH_E_NOMEM;
     }
+    memset(ctx->h_pinned, 0, sizeof(uint32_t) * (ctx->max_batch * 8 + 64 + (MAX_ROUNDS + 1) * SUMMARY_WORDS)); // (no stale sequence words)
     *out = ctx;
     return BZH_OK;
     });
@@ -536,6 +537,8 @@ extern "C" int bzh_bwt_roundtrip_device(bzh_ctx *ctx, size_t b0, size_t b1, uint
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     ctx->evnext = 0; // (the pool is reused from the start by every entry point that takes events)
+    ctx->sort_spans.clear(); // (spans recorded against the old use of those events must not survive the rewind)
+    kstats_reset(ctx);
     BZH_TRY(ensure_arena(ctx, (uint32_t)std::min<size_t>(b1 - b0, ctx->max_batch)));
     unsigned long long *d_acc = ctx->bt.stat_A; // (the forward sort has read it back by the time it is reused)
     unsigned long long total = 0;
@@ -750,6 +753,7 @@ static int ensure_lanes(bzh_ctx *ctx)
             delete l;
             return BZH_E_NOMEM;
         }
+        memset(l->h_pinned, 0, sizeof(uint32_t) * (lane_mb * 8 + 64 + (MAX_ROUNDS + 1) * SUMMARY_WORDS));
         ctx->lanes.push_back(l);
     }
     return BZH_OK;
@@ -1075,7 +1079,28 @@ extern "C" int bzh_encode_range_device(bzh_ctx *ctx, size_t b0, size_t b1, void 
     memset(&ctx->stats, 0, sizeof ctx->stats);
     ctx->stats.ms_plan = keep_plan;
     ctx->sort_spans.clear();
-    kstats_reset(ctx);
+    // the plan's kernel classes (bzh_plan_tables_device / bzh_plan_split_device recorded them) stay in the table: their
+    // spans are turned into milliseconds now, before the event pool is rewound under them
+    double keep_ms[2];
+    uint64_t keep_bytes[2], keep_launch[2];
+    if (!ctx->profiling) {
+        kstats_reset(ctx);
+    } else {
+        HIP_TRY(ctx, bzh_stream_wait(ctx->stream));
+        kstats_collect(ctx);
+        const int cls[2] = {K_PLAN, K_CRC};
+        for (int k = 0; k < 2; k++) {
+            keep_ms[k] = ctx->k_ms[cls[k]];
+            keep_bytes[k] = ctx->k_bytes[cls[k]];
+            keep_launch[k] = ctx->k_launch[cls[k]];
+        }
+        kstats_reset(ctx);
+        for (int k = 0; k < 2; k++) {
+            ctx->k_ms[cls[k]] = keep_ms[k];
+            ctx->k_bytes[cls[k]] = keep_bytes[k];
+            ctx->k_launch[cls[k]] = keep_launch[k];
+        }
+    }
     ctx->evnext = 0;
     *nbits = 0;
     if (b0 == b1) return BZH_OK;

@@ -1899,6 +1899,7 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
 #pragma unroll
         for (int k = 0; k < SUMMARY_WORDS - 1; k++) mine = lane == (uint32_t)k ? words[k] : mine;
         if (lane < (uint32_t)SUMMARY_WORDS - 1) hsum[lane] = mine;
+        __threadfence_system(); // every lane's word is out before lane 0 says so (the release below orders lane 0's own stores)
         if (lane < 6) bt.nlist[lane] = lane == 0 ? tot[0] : lane == 1 ? tot[1] : lane == 2 ? tot[2] : lane == 3 ? tot[3] : lane == 4 ? tot[4] : tot[5];
         if (lane == 0) {
             *bt.stat_A = asum;
@@ -2322,6 +2323,15 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         if (side_busy) hipStreamWaitEvent(st, ctx->side_ev[1], 0);
         side_busy = false;
     };
+    // An error return hands the context back: nothing of this call may still be running on the second stream
+    // against the arena when the next call queues its memsets (bzh_debug_fault promises a usable context).
+    auto fail_wait = [&](hipError_t e) -> int {
+        if (side_busy && side) hipStreamSynchronize(side);
+        side_busy = false;
+        ctx->stream = st;
+        bzh_set_error(ctx, "%s:%d waiting for a round summary -> %s", __FILE__, __LINE__, hipGetErrorString(e));
+        return BZH_E_HIP;
+    };
     auto run_A = [&]() {
         const uint32_t gt = (maxA + SORT_TILE - 1) / SORT_TILE;
         if (!nA || !gt) return;
@@ -2402,7 +2412,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         }
         if (round > 1) {
             // the summary of the PREVIOUS round: where every block stood when that round began
-            HIP_TRY(ctx, wait_summary(round - 1, s));
+            if (const hipError_t we = wait_summary(round - 1, s); we != hipSuccess) return fail_wait(we);
             const uint64_t total = (uint64_t)s[8] | ((uint64_t)s[9] << 32);
             err |= s[14];
             if (trace)
@@ -2433,7 +2443,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             // there and the SWEEP path runs with exact sizes -- or, mostly, not at all.
             run_A();
             run_T();
-            HIP_TRY(ctx, wait_summary(0, s));
+            if (const hipError_t we = wait_summary(0, s); we != hipSuccess) return fail_wait(we);
             const uint64_t total = (uint64_t)s[8] | ((uint64_t)s[9] << 32);
             err |= s[14];
             if (trace)

@@ -824,9 +824,14 @@ int rle1_plan_tables(bzh_ctx *ctx, const uint8_t *d_in, size_t n)
     ctx->plan_blocks.clear();
     ctx->plan_open.clear();
     ctx->plan_crc_ok.clear();
-    ctx->plan_in = d_in;
-    ctx->plan_n = n;
-    if (n == 0) return BZH_OK;
+    // (the buffer becomes the plan's input only once its tables are queued: a failure below must not leave a later
+    // bzh_plan_split_device with a length it accepts and a workspace that is missing or too small)
+    ctx->plan_in = nullptr;
+    ctx->plan_n = 0;
+    if (n == 0) {
+        ctx->plan_in = d_in;
+        return BZH_OK;
+    }
     if (n > 0xFFFF0000ull) {
         bzh_set_error(ctx, "input of %zu bytes exceeds the 32-bit position range of one plan", n);
         return BZH_E_ARG;
@@ -851,6 +856,8 @@ int rle1_plan_tables(bzh_ctx *ctx, const uint8_t *d_in, size_t n)
     plan_granules<<<dim3(pa.ntiles), RL_THREADS, 0, st>>>(pa);
     plan_tc<<<dim3(1), 1024, 0, st>>>(pa);
     HIP_TRY(ctx, hipGetLastError());
+    ctx->plan_in = d_in;
+    ctx->plan_n = n;
     return BZH_OK;
 }
 

@@ -106,9 +106,19 @@ class ShardError(RuntimeError):
     """Raised on EVERY rank when any rank's plan / encode failed (nobody is left waiting in a collective)."""
 
 
-def encode_sharded(engine, dist=None, rank=0, world=1):
+def side_group(dist):
+    """The chain's own process group: `gloo`, CPU tensors.  The 8-byte hand-off from rank to rank (and the -1 that
+    announces a failure) is latency, not bandwidth: over the `nccl` backend it would cost a lazily created
+    point-to-point communicator per neighbour pair and a device synchronisation per hop, on the critical chain of an
+    operation whose whole budget is a third of a millisecond per rank.  NCCL/RCCL keeps the two collectives that move
+    data (one all_gather of the meta rows, one gather of the bit strings).  Collective: every rank calls this once."""
+    return dist.new_group(backend="gloo")
+
+
+def encode_sharded(engine, dist=None, rank=0, world=1, side=None):
     """Run one sharded encode.  Returns the stream length on rank 0 (0 elsewhere).  engine.times (if the engine has
-    the attribute) receives this rank's milliseconds: tables + split, waiting for the chain, encode, gather."""
+    the attribute) receives this rank's milliseconds: tables + split, waiting for the chain, encode, gather.
+    `side`: the process group of the chain hand-off (side_group(dist)); None = the default group, device tensors."""
     import torch
 
     # A rank that fails before the collectives must still take part in them, or the others wait for ever:
@@ -124,9 +134,10 @@ def encode_sharded(engine, dist=None, rank=0, world=1):
     except Exception as e:  # noqa: BLE001 -- whatever it was, the other ranks have to hear about it
         err = e
     t1 = time.perf_counter()
+    hop_dev = "cpu" if side is not None else dev
     if rank > 0:  # (always: the rank before always sends)
-        box = torch.zeros(1, dtype=torch.int64, device=dev)
-        dist.recv(box, src=rank - 1)
+        box = torch.zeros(1, dtype=torch.int64, device=hop_dev)
+        dist.recv(box, src=rank - 1, group=side)
         start = int(box.item())
         if start < 0 and err is None:
             err = ShardError(f"rank {rank}: a rank before this one failed")
@@ -140,15 +151,23 @@ def encode_sharded(engine, dist=None, rank=0, world=1):
     t["ms_plan"] = ((t1 - t0) + (t3 - t2)) * 1e3
     t["ms_wait"] = (t2 - t1) * 1e3
     if world > 1 and rank < world - 1:
-        dist.send(torch.tensor([nxt], dtype=torch.int64, device=dev), dst=rank + 1)
+        dist.send(torch.tensor([nxt], dtype=torch.int64, device=hop_dev), dst=rank + 1, group=side)
     if err is None:
-        try:
-            t3 = time.perf_counter()
-            part, nbits = engine.encode_range(b0, b1)
-            own = engine.crcs(b0, b1)
-            t["ms_encode"] = (time.perf_counter() - t3) * 1e3
-        except Exception as e:  # noqa: BLE001
-            err = e
+        t3 = time.perf_counter()
+        for attempt in (0, 1):
+            try:
+                part, nbits = engine.encode_range(b0, b1)
+                own = engine.crcs(b0, b1)
+                break
+            except Exception as e:  # noqa: BLE001
+                # a slab that turned out too small (worst_case_slab is a heuristic): once more with twice the room
+                if attempt == 0 and is_cap_error(e) and hasattr(engine, "grow"):
+                    engine.grow()
+                    t["retries"] = 1
+                    continue
+                err = e
+                break
+        t["ms_encode"] = (time.perf_counter() - t3) * 1e3
     if hasattr(engine, "times"):
         engine.times = t
     if world == 1:
@@ -173,7 +192,11 @@ def encode_sharded(engine, dist=None, rank=0, world=1):
     if failed:
         raise ShardError(f"sharded encode failed on rank(s) {failed}" + (f"; this rank: {err!r}" if err is not None else ""))
     # gather only as many bytes as the longest bit string needs (whole 32-bit words), not the slab capacity
-    used = min(engine.cap, (max(nb) + 31) // 32 * 4)
+    used = (max(nb) + 31) // 32 * 4
+    if part.numel() < used:  # (another rank's bit string is longer than this rank's slab: pad, the tail is not read)
+        bigger = torch.zeros(used, dtype=torch.uint8, device=part.device)
+        bigger[:part.numel()] = part
+        part = bigger
     send = part[:used]
     slabs = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
     tg = time.perf_counter()
@@ -188,6 +211,17 @@ def encode_sharded(engine, dist=None, rank=0, world=1):
     out_len = engine.assemble(segs, crcs)
     t["ms_gather"] = (time.perf_counter() - tg) * 1e3  # (rank 0: gather + assembly)
     return out_len
+
+
+def is_cap_error(e):
+    """the engine's "output buffer too small" (libbzhip.so: BZH_E_CAP)"""
+    return getattr(e, "status", None) == -4 or getattr(e, "is_cap", False)
+
+
+def min_lookahead(level):
+    """Bytes a rank must hold beyond its own range for its last cut to be settled whatever the input: a block inside
+    one enormous run consumes 255 bytes per 5 of its M output bytes (lib/rle.rs:210-234), plus one more chunk."""
+    return 255 * ((100000 * level - 1) // 5 + 2)
 
 
 def worst_case_slab(n, world, level=9):
@@ -211,6 +245,8 @@ class DeviceEngine:
         self.ctx, self.d_in, self.n, self.d_out = ctx, d_in, n, d_out
         self.lo = lo
         self.resident = n if resident is None else resident
+        if self.lo + self.resident > n or self.resident < 0:
+            raise ValueError("resident range outside the input")
         self.device = d_in.device
         self.cap = seg_cap
         self.times = {}
@@ -218,6 +254,23 @@ class DeviceEngine:
         # RLE1 expands by at most 5/4, so a block of M = 100000*level - 1 output bytes eats at least 0.8 M input
         # bytes (only the stream's last block may be shorter)
         self.min_block = (100000 * ctx.level - 1) * 4 // 5
+
+    def grow(self):
+        """twice the slab (after BZH_E_CAP)"""
+        import torch
+
+        self.cap *= 2
+        self.part = torch.zeros(self.cap, dtype=torch.uint8, device=self.d_in.device)
+
+    def check_lookahead(self, rank, world):
+        """Refuses, up front and by name, a resident range whose look-ahead cannot settle every possible last cut
+        (own_blocks would raise later, on the input that needs it)."""
+        hi = offsets(self.n, world)[rank + 1]
+        have = self.lo + self.resident - hi
+        need = min_lookahead(self.ctx.level)
+        if self.lo + self.resident < self.n and have < need:
+            raise ShardError(f"rank {rank} holds {have} bytes beyond its range; level {self.ctx.level} needs {need} "
+                             f"(sharded.min_lookahead) or the rest of the input")
 
     def tables(self):
         self.ctx.plan_tables_device(self.d_in.data_ptr(), self.resident)

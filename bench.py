@@ -133,15 +133,18 @@ def main():
     ctx.set_stream(stream.cuda_stream)
 
     engine = None
+    side = None
     if world > 1:
         engine = sharded.DeviceEngine(ctx, d_in, total, d_out, sharded.worst_case_slab(total, world, LEVEL), resident=resident,
                                       lo=lo_res)
+        engine.check_lookahead(rank, world)
+        side = sharded.side_group(dist)  # the chain's 8-byte hand-offs: gloo, CPU tensors (the collectives stay on RCCL)
 
     def step():
         """One pass of the hot path; returns the stream length on rank 0."""
         if world == 1:
             return ctx.encode_device(d_in.data_ptr(), total, d_out.data_ptr(), out_cap)
-        return sharded.encode_sharded(engine, dist, rank, world)
+        return sharded.encode_sharded(engine, dist, rank, world, side=side)
 
     def barrier():
         if world > 1:

@@ -824,3 +824,47 @@ def test_stream_beyond_four_gib(native):
             got_tail += piece[k:]
         pos += len(piece)
     assert dec.eof and pos == total and bytes(got_tail) == tail.tobytes()
+
+
+def test_rust_facade_twin(oracle, native, tmp_path):
+    """tests/abi_facade.c = the calling sequence of rust/src/lib.rs (banzai::encode over the C ABI) executed in C: 8 KiB
+    fill_buf slices coalesced into a 4 MiB stage, large slices passed through only while the stage is empty, eof fed with
+    the staged remainder (also when it is empty), bzh_stream_bound before every feed.  Streams equal the oracle's."""
+    import subprocess
+    from banzai_amd import corpus
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "abi_facade"
+    lib_dir = os.path.join(ROOT, "banzai_amd")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-o", str(exe), os.path.join(ROOT, "tests", "abi_facade.c"),
+                           "-L" + lib_dir, "-lbzhip", "-Wl,-rpath," + lib_dir])
+    text = corpus.enwik_synthetic(9_500_000, seed=61).tobytes()
+    jobs = [(9, 8192, text),                                   # BufReader default: every slice goes through the stage
+            (9, 8192, text[:8 * (4 << 20)]),                   # the input ends exactly on a stage boundary: eof with an empty remainder
+            (9, 16 << 20, text),                               # encode_file: slices pass straight through
+            (9, (4 << 20) + 12345, text[:9_000_001]),          # large slices, ragged last one (staged, then eof)
+            (1, 8192, cases.gen(700_000, "longruns", 6)),      # run-heavy, level 1
+            (5, 8192, b""), (9, 8192, b"x"), (2, 1 << 20, cases.gen(1_234_567, "shortruns", 2))]
+    for level, slice_bytes, data in jobs:
+        fin, fout = tmp_path / "in.bin", tmp_path / "out.bz2"
+        fin.write_bytes(data)
+        r = subprocess.run([str(exe), str(level), str(slice_bytes), str(fin), str(fout)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.strip() == f"consumed {len(data)}"
+        assert fout.read_bytes() == oracle.encode(data, level), (level, slice_bytes, len(data))
+
+
+def test_full_size_headline_bit_exact_vs_oracle(oracle, native):
+    """BASELINE config 3 at full size, the whole 100,000,000-byte workload of bench.py against the oracle (not only
+    its size-independent properties): a mismatch shows up as a red test, not as a failed bench run."""
+    import torch
+    from banzai_amd import corpus
+    n = 100_000_000
+    data, _ = corpus.workload(n)
+    want = oracle.encode(data.tobytes(), 9)
+    with native.Context(0, 9, 128) as ctx:
+        d_in = torch.zeros(n + 16, dtype=torch.uint8, device="cuda")
+        d_in[:n] = torch.from_numpy(data).cuda()
+        cap = (n // 2 + (1 << 20)) & ~3
+        d_out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+        ln = ctx.encode_device(d_in.data_ptr(), n, d_out.data_ptr(), cap)
+        assert d_out[:ln].cpu().numpy().tobytes() == want

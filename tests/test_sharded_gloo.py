@@ -95,7 +95,10 @@ def _worker(rank, world, port, data, level, q):
     # 70,000 equal bytes eats them all)
     lo, hi = sharded.resident_range(len(data), rank, world, lookahead=400_000)
     eng = OracleEngine(pyoracle, data, level, cap=len(data) + 4096, lo=lo, resident=hi - lo)
-    n = sharded.encode_sharded(eng, dist, rank, world)
+    # the product's two-group layout: the chain hand-off on its own gloo group (CPU tensors), the collectives on the
+    # default group (nccl on a GPU node, gloo here)
+    side = sharded.side_group(dist)
+    n = sharded.encode_sharded(eng, dist, rank, world, side=side)
     if rank == 0:
         q.put((n, eng.stream))
     dist.barrier()
@@ -140,12 +143,64 @@ def _failing_worker(rank, world, port, data, q):
             raise RuntimeError("slab too small")
         eng.encode_range = boom
     try:
-        sharded.encode_sharded(eng, dist, rank, world)
+        sharded.encode_sharded(eng, dist, rank, world, side=sharded.side_group(dist))
         q.put((rank, "returned"))
     except sharded.ShardError as e:
         q.put((rank, str(e)))
     dist.barrier()
     dist.destroy_process_group()
+
+
+class _SlabTooSmall(RuntimeError):
+    is_cap = True  # what sharded.is_cap_error looks for (libbzhip.so: BZH_E_CAP)
+
+
+def _retry_worker(rank, world, port, data, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from banzai_amd import sharded
+    from oracle import pyoracle
+    lo, hi = sharded.resident_range(len(data), rank, world, lookahead=400_000)
+    small = 2048  # far too small for this rank's bit string: the first encode_range must fail with "cap"
+    eng = OracleEngine(pyoracle, data, 1, cap=small if rank == 1 else len(data) + 4096, lo=lo, resident=hi - lo)
+    grown = []
+    if rank == 1:
+        plain = eng.encode_range
+
+        def capped(b0, b1):
+            if eng.cap < len(data):
+                raise _SlabTooSmall("slab too small")
+            return plain(b0, b1)
+
+        def grow():
+            eng.cap = max(eng.cap * 2, len(data) + 4096)
+            grown.append(eng.cap)
+        eng.encode_range, eng.grow = capped, grow
+    side = sharded.side_group(dist)
+    n = sharded.encode_sharded(eng, dist, rank, world, side=side)
+    q.put((rank, n, eng.stream if rank == 0 else None, len(grown), eng.times.get("retries", 0)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cap_error_is_retried_once_with_a_larger_slab(oracle):
+    """a slab that is too small on one rank (BZH_E_CAP) costs one retry on that rank, not the job: the stream is
+    still the single stream, and rank 0 copes with a bit string longer than its own slab"""
+    data = cases.gen(450_000, "text", 8)
+    want = oracle.encode(data, 1)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_retry_worker, args=(r, 2, port, data, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r[0]: r for r in (q.get(timeout=120) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][1] == len(want) and got[0][2] == want
+    assert got[1][3] == 1 and got[1][4] == 1 and got[0][3] == 0
 
 
 def test_failure_on_one_rank_raises_on_all(oracle):
@@ -200,6 +255,32 @@ def test_chained_ownership_covers_every_block_once(oracle):
     eng = OracleEngine(oracle, data, 1, cap=16, lo=lo, resident=hi - lo)
     with pytest.raises(sharded.ShardError):
         sharded.own_blocks(eng, 0, 4, 0)
+
+
+def test_lookahead_is_validated_up_front():
+    """a DeviceEngine whose look-ahead cannot settle every possible cut is refused by name before any input
+    shows it (no GPU needed: the check only reads sizes)"""
+    from banzai_amd import sharded
+
+    class Ctx:
+        level = 9
+
+    n = 800_000_000
+    need = sharded.min_lookahead(9)
+    assert 45_000_000 < need < (64 << 20)  # the default look-ahead covers the worst case at level 9
+    for look, ok in ((64 << 20, True), (need, True), (need - 1, False), (1 << 20, False)):
+        lo, hi = sharded.resident_range(n, 2, 8, lookahead=look)
+        eng = sharded.DeviceEngine.__new__(sharded.DeviceEngine)
+        eng.ctx, eng.n, eng.lo, eng.resident = Ctx(), n, lo, hi - lo
+        if ok:
+            eng.check_lookahead(2, 8)
+        else:
+            with pytest.raises(sharded.ShardError, match="min_lookahead"):
+                eng.check_lookahead(2, 8)
+    lo, hi = sharded.resident_range(n, 7, 8, lookahead=0)  # the last rank sees the end of the input: nothing to hold
+    eng = sharded.DeviceEngine.__new__(sharded.DeviceEngine)
+    eng.ctx, eng.n, eng.lo, eng.resident = Ctx(), n, lo, hi - lo
+    eng.check_lookahead(7, 8)
 
 
 def test_block_range_partition():
