@@ -60,7 +60,10 @@ __global__ void __launch_bounds__(256) mtf_tile_last(Batch bt, int32_t *tlast, u
     last[threadIdx.x] = -1;
     (void)build_names(bt.hasbyte + (size_t)b * 256, names, ls);
     const uint8_t *s = bt.bwt + (size_t)b * bt.S;
-    const uint32_t p0 = tile * MTF_TILE + threadIdx.x * 8;
+    static_assert(MTF_TILE % 2048 == 0, "256 threads x 8 bytes per sweep");
+#pragma unroll 1
+    for (uint32_t sub = 0; sub < MTF_TILE; sub += 2048) {
+    const uint32_t p0 = tile * MTF_TILE + sub + threadIdx.x * 8;
     if (p0 < n) {
         uint2 w = *reinterpret_cast<const uint2 *>(s + p0);
         // only the last byte of a run inside my 8 bytes can be its symbol's last occurrence among them (after a
@@ -75,6 +78,7 @@ __global__ void __launch_bounds__(256) mtf_tile_last(Batch bt, int32_t *tlast, u
                 if (!more) atomicMax(&last[names[c]], (int)p);
             }
         }
+    }
     }
     __syncthreads();
     tlast[((size_t)b * MT + tile) * 256 + threadIdx.x] = last[threadIdx.x];
@@ -287,9 +291,11 @@ __global__ void __launch_bounds__(64) mtf_walk_par(Batch bt, const int32_t *tlas
     __shared__ uint8_t names[256];
     __shared__ uint32_t ls[4];
     __shared__ uint16_t Etab[256];         // list position of every name
-    __shared__ uint8_t hsym[MTF_TILE];     // names of the run heads, in order
-    __shared__ uint16_t hoff[MTF_TILE];    // their offsets in the tile
-    __shared__ __attribute__((aligned(16))) uint8_t opos[MTF_TILE]; // positions of the tile's bytes
+    // (the tile is walked in halves of 1024 bytes so that a wavefront needs under 5 KB of LDS: the walk is a chain of
+    // dependent steps per wavefront, what hides its latency is the number of wavefronts a compute unit can hold)
+    __shared__ uint8_t hsym[1024];     // names of the run heads of the half, in order
+    __shared__ uint16_t hoff[1024];    // their offsets in the half
+    __shared__ __attribute__((aligned(16))) uint8_t opos[1024]; // positions of the half's bytes
     const uint32_t num_names = build_names(bt.hasbyte + (size_t)b * 256, names, ls);
     const int32_t *keys = tlast + ((size_t)b * MT + tile) * 256;
     const uint8_t *s = bt.bwt + (size_t)b * bt.S + base_p;
@@ -333,8 +339,7 @@ __global__ void __launch_bounds__(64) mtf_walk_par(Batch bt, const int32_t *tlas
         }
         front = __builtin_amdgcn_readfirstlane(bsym);
     }
-    // ---- run heads of the tile, compacted into LDS (two halves of 1024 bytes, 16 bytes a lane)
-    uint32_t H = 0;
+    // ---- half by half: its run heads compacted into LDS (16 bytes a lane), then 64 run heads at a time
     uint32_t carry_last = (uint32_t)front;
 #pragma unroll 1
     for (uint32_t cbase = 0; cbase < tile_len; cbase += 1024) {
@@ -373,19 +378,19 @@ __global__ void __launch_bounds__(64) mtf_walk_par(Batch bt, const int32_t *tlas
         }
         const uint32_t mine = (uint32_t)__popc(chg);
         const uint32_t inc = wave_incl_add(mine, lane);
-        uint32_t at = H + inc - mine;
+        uint32_t at = inc - mine;
 #pragma unroll
         for (int kb = 0; kb < 16; kb++) {
             if (chg & (1u << kb)) {
                 hsym[at] = (uint8_t)((in[kb >> 2] >> (8 * (kb & 3))) & 255u);
-                hoff[at] = (uint16_t)(cbase + lane * 16 + kb);
+                hoff[at] = (uint16_t)(lane * 16 + kb);
                 at++;
             }
         }
-        H += (uint32_t)__shfl((int)inc, 63, 64);
-        *reinterpret_cast<uint4 *>(&opos[cbase + lane * 16]) = make_uint4(0u, 0u, 0u, 0u);
-    }
-    // ---- 64 run heads at a time (one wavefront: program order is enough between the LDS phases)
+        const uint32_t H = (uint32_t)__shfl((int)inc, 63, 64);
+        *reinterpret_cast<uint4 *>(&opos[lane * 16]) = make_uint4(0u, 0u, 0u, 0u);
+        const bool last_half = cbase + 1024 >= tile_len;
+        // 64 run heads at a time (one wavefront: program order is enough between the LDS phases)
 #pragma unroll 1
     for (uint32_t hb = 0; hb < H; hb += 64) {
         const uint32_t idx = hb + (uint32_t)lane;
@@ -427,7 +432,7 @@ __global__ void __launch_bounds__(64) mtf_walk_par(Batch bt, const int32_t *tlas
         const unsigned long long A = lower & ~(((unsigned long long)xhi << 32) | xlo);
         int pos;
         unsigned long long firsts = __ballot(act && p < 0); // one lane per distinct symbol of the chunk
-        const bool more = hb + 64 < H;
+        const bool more = hb + 64 < H || !last_half;
         int eo[4] = {0, 0, 0, 0}, add[4] = {0, 0, 0, 0};
         if (more) {
             eo[0] = (int)Etab[lane];
@@ -459,9 +464,8 @@ __global__ void __launch_bounds__(64) mtf_walk_par(Batch bt, const int32_t *tlas
             if (islast) Etab[c] = (uint16_t)__popcll(lasts & ~upto);
         }
     }
-    if ((uint32_t)lane * 16u < tile_len) *reinterpret_cast<uint4 *>(o + lane * 16) = *reinterpret_cast<const uint4 *>(&opos[lane * 16]);
-    if (1024u + (uint32_t)lane * 16u < tile_len)
-        *reinterpret_cast<uint4 *>(o + 1024 + lane * 16) = *reinterpret_cast<const uint4 *>(&opos[1024 + lane * 16]);
+        if (cbase + (uint32_t)lane * 16u < tile_len) *reinterpret_cast<uint4 *>(o + cbase + lane * 16) = *reinterpret_cast<const uint4 *>(&opos[lane * 16]);
+    }
 }
 
 // ---- RLE2 --------------------------------------------------------------------------------------------

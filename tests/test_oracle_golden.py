@@ -154,3 +154,14 @@ def test_reference_rle1_large_vectors(oracle):
         assert len(d) == c["input_len"] and hashlib.sha256(d).hexdigest() == c["input_sha256"], name
         r, _, used = oracle.rle_one(d, 9)  # every output is shorter than a level-9 block: the bound never bites
         assert used == len(d) and len(r) == c["rle1_len"] and hashlib.sha256(r).hexdigest() == c["rle1_sha256"], name
+
+
+def test_oracle_round_trips_under_sanitizers():
+    """`make -C oracle san`: the oracle and the in-repo decoder built with -fsanitize=address,undefined, 300 seeded
+    encode -> decode round trips over empty / tiny / run-heavy / periodic / random inputs at levels 1-9
+    (the reference's fuzz/fuzz_targets/round_trip.rs:8-22 loop; GPU sanitizers do not exist on this pool)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "-s", "san"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "300 round trips clean" in r.stdout
