@@ -2123,7 +2123,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
                         c[MC_NEW], c[MC_OLD], c[MC_UNITS], c[MC_SEGS + 1], c[MC_SEGS + 2], c[MC_SEGS + 3], c[MC_SEGS + 4], c[MC_SEGS + 5],
                         c[MC_ITEMS + 1], c[MC_ITEMS + 2], c[MC_ITEMS + 3], c[MC_ITEMS + 4], c[MC_ITEMS + 5]);
             if (c[24] | c[27])
-                fprintf(stderr, "[bzhip] chunk_finish, 16-cycle ticks over all workgroups: ticket+descriptor %u, load+bucket heads %u, bucket index+vary %u, sort passes %u, suffixes+heads %u, classes %u, lists out %u, ranks out %u\n",
+                fprintf(stderr, "[bzhip] chunk_finish, 16-cycle ticks over all workgroups: ticket+load+bucket index %u, ranking %u, stage scatter+barrier %u, reload %u, boundaries+classes %u, suffixes+bins %u, lists out %u, ranks out %u\n",
                         c[24], c[25], c[26], c[27], c[28], c[29], c[30], c[31]);
         }
     } else {

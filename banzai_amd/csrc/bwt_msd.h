@@ -43,7 +43,7 @@ struct Msd {
     uint32_t *c_big, *c_small, *c_groups;
     uint32_t *err;
     uint32_t force_old;  // every block keeps the 8-pass path (BZH_INIT=lsd)
-    uint32_t dbg;        // timing experiments only (BZH_MSD_DBG): 1 no sort passes, 2 no bucket-index pass, 4 no outputs
+    uint32_t dbg;        // timing experiments only (BZH_MSD_DBG): 16 = cycles per phase of chunk_finish
 };
 
 __device__ __forceinline__ uint32_t *ms_seg_start_row(const Msd &m, uint32_t L, uint32_t b, uint32_t slot)
@@ -66,14 +66,21 @@ __device__ __forceinline__ uint4 ms_unit(uint32_t b, uint32_t buf, uint32_t unif
 // Item (wave w, step k, lane l) is element w * R * 64 + k * 64 + l of the tile's current order (R = steps per wave,
 // the same for every wave).  Digit of an item: bits sh .. sh+7 of v[k].  Leaves in pos (16 bits per item) the
 // item's slot in the new order.  The ranking is radix_scatter's: match-any by ballots, per-wave LDS counters.
-template <typename T>
-__device__ __forceinline__ void tile_rank(const T (&v)[MS_ITEMS], int sh, int nbits, uint32_t actmask, int R, uint32_t (*cur)[256], uint32_t *ls,
+// Counters: 16 bits are enough (a tile holds 8192 elements), two sets: a pass clears the set of the NEXT pass while it
+// ranks, so a pass costs three barriers (the first pass of a tile needs `cur` cleared by the caller).
+typedef uint16_t MsCnt[MS_NW][256];
+__device__ __forceinline__ void ms_clear(MsCnt &c)
+{
+    reinterpret_cast<uint2 *>(&c[0][0])[threadIdx.x] = make_uint2(0u, 0u); // 512 threads x 8 bytes = 4 KB
+}
+
+template <int NBITS, typename T>
+__device__ __forceinline__ void tile_rank(const T (&v)[MS_ITEMS], int sh, uint32_t actmask, int R, MsCnt &cur, MsCnt &nxt, uint32_t *ls,
                                           uint32_t (&pos)[MS_ITEMS / 2])
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t dmask = (1u << nbits) - 1u;
-    for (int k = threadIdx.x; k < MS_NW * 256; k += MS_THREADS) (&cur[0][0])[k] = 0;
-    __syncthreads();
+    constexpr uint32_t dmask = (1u << NBITS) - 1u;
+    ms_clear(nxt);
     uint32_t wr[MS_ITEMS / 2];
 #pragma unroll
     for (int k = 0; k < MS_ITEMS / 2; k++) wr[k] = 0;
@@ -85,18 +92,16 @@ __device__ __forceinline__ void tile_rank(const T (&v)[MS_ITEMS], int sh, int nb
             const u64 m0 = __ballot(act);
             uint32_t mlo = (uint32_t)m0, mhi = (uint32_t)(m0 >> 32);
 #pragma unroll
-            for (int bit = 0; bit < 8; bit++) {
-                if (bit < nbits) { // (the same for every lane)
-                    const int om = ((int)(d << (31 - bit))) >> 31;
-                    const u64 bm = __builtin_amdgcn_ballot_w64(om != 0);
-                    mlo &= ~((uint32_t)bm ^ (uint32_t)om);
-                    mhi &= ~((uint32_t)(bm >> 32) ^ (uint32_t)om);
-                }
+            for (int bit = 0; bit < NBITS; bit++) { // keep the lanes whose digit agrees with mine in this bit: m & ~(ballot ^ mine)
+                const int om = __builtin_amdgcn_sbfe((int)d, bit, 1);
+                const u64 bm = __builtin_amdgcn_ballot_w64(om != 0);
+                mlo = __builtin_amdgcn_bitop3_b32(mlo, (uint32_t)bm, (uint32_t)om, 0x90);
+                mhi = __builtin_amdgcn_bitop3_b32(mhi, (uint32_t)(bm >> 32), (uint32_t)om, 0x90);
             }
             if (act) {
                 const uint32_t before = cur[wave][d];
                 const uint32_t off = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
-                if (off == 0) cur[wave][d] = before + (uint32_t)(__popc(mlo) + __popc(mhi));
+                if (off == 0) cur[wave][d] = (uint16_t)(before + (uint32_t)(__popc(mlo) + __popc(mhi)));
                 wr[k >> 1] |= (before + off) << (16 * (k & 1));
             }
             asm volatile("" ::: "memory"); // (LDS operations of one wavefront execute in order; see radix_scatter)
@@ -118,7 +123,7 @@ __device__ __forceinline__ void tile_rank(const T (&v)[MS_ITEMS], int sh, int nb
 #pragma unroll
         for (int w = 0; w < MS_NW; w++) {
             const uint32_t t = cur[w][threadIdx.x];
-            cur[w][threadIdx.x] = g;
+            cur[w][threadIdx.x] = (uint16_t)g;
             g += t;
         }
     }
@@ -127,8 +132,42 @@ __device__ __forceinline__ void tile_rank(const T (&v)[MS_ITEMS], int sh, int nb
     for (int k = 0; k < MS_ITEMS / 2; k++) pos[k] = 0;
 #pragma unroll
     for (int k = 0; k < MS_ITEMS; k++) {
-        if (k < R && ((actmask >> k) & 1u)) pos[k >> 1] |= (cur[wave][(uint32_t)(v[k] >> sh) & dmask] + ((wr[k >> 1] >> (16 * (k & 1))) & 0xFFFFu)) << (16 * (k & 1));
+        if (k < R && ((actmask >> k) & 1u)) pos[k >> 1] |= ((uint32_t)cur[wave][(uint32_t)(v[k] >> sh) & dmask] + ((wr[k >> 1] >> (16 * (k & 1))) & 0xFFFFu)) << (16 * (k & 1));
     }
+}
+
+// The FIRST counting pass of a tile has no order to keep (there is no lower digit yet): an element's slot among the
+// elements with its digit may be any -- one LDS atomic per element instead of the ballot ranking (about 100 vector
+// instructions a thread instead of 1,500).  `cnt`: 256 words.  Three barriers; the caller writes the stage behind it.
+template <typename T>
+__device__ __forceinline__ void tile_rank_unordered(const T (&v)[MS_ITEMS], int sh, uint32_t actmask, int R, uint32_t *cnt, uint32_t *ls,
+                                                    uint32_t (&pos)[MS_ITEMS / 2])
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x < 256) cnt[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MS_ITEMS; k++)
+        if (k < R && ((actmask >> k) & 1u)) atomicAdd(&cnt[(uint32_t)(v[k] >> sh) & 255u], 1u);
+    __syncthreads();
+    uint32_t c = 0, inc = 0;
+    if (threadIdx.x < 256) {
+        c = cnt[threadIdx.x];
+        inc = wave_incl_add(c, lane);
+        if (lane == 63) ls[wave] = inc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        uint32_t g = inc - c;
+        for (int w = 0; w < wave; w++) g += ls[w];
+        cnt[threadIdx.x] = g; // from here on: the digit's cursor
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MS_ITEMS / 2; k++) pos[k] = 0;
+#pragma unroll
+    for (int k = 0; k < MS_ITEMS; k++)
+        if (k < R && ((actmask >> k) & 1u)) pos[k >> 1] |= atomicAdd(&cnt[(uint32_t)(v[k] >> sh) & 255u], 1u) << (16 * (k & 1));
 }
 
 // A run of equal keys inside one row of 64 sorted items claims its room with ONE atomic add on the key's cursor.
@@ -450,9 +489,11 @@ __global__ void __launch_bounds__(MS_THREADS, 4) bigram_scatter(Msd m, uint32_t 
     const uint8_t *s = m.blk + (size_t)b * m.S;
     __shared__ uint32_t txt[MS_TILE / 4 + 8]; // text bytes tile0 .. tile0 + MS_TILE + 31 (cyclic)
     __shared__ uint32_t stage[MS_TILE];
-    __shared__ uint32_t cur[MS_NW][256];
+    __shared__ MsCnt cur[2];
+    __shared__ uint32_t ucnt[256];
     __shared__ uint32_t ls[MS_NW + 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    ms_clear(cur[1]);
     {
         const uint32_t p = tile0 + threadIdx.x * 16;
         uint4 q;
@@ -494,7 +535,10 @@ __global__ void __launch_bounds__(MS_THREADS, 4) bigram_scatter(Msd m, uint32_t 
 #pragma unroll 1
     for (int pass = 0; pass < 2; pass++) {
         const int sh = 13 + 8 * pass;
-        tile_rank(v, sh, 8, actmask, MS_ITEMS, cur, ls, pos);
+        if (pass == 0) // (by byte 1: no order to keep yet)
+            tile_rank_unordered(v, sh, actmask, MS_ITEMS, ucnt, ls, pos);
+        else
+            tile_rank<8>(v, sh, actmask, MS_ITEMS, cur[1], cur[0], ls, pos);
 #pragma unroll
         for (int k = 0; k < MS_ITEMS; k++)
             if ((actmask >> k) & 1u) stage[(pos[k >> 1] >> (16 * (k & 1))) & 0xFFFFu] = v[k];
@@ -627,9 +671,12 @@ __global__ void __launch_bounds__(MS_THREADS, 4) seg_scatter(Msd m, uint32_t L)
     const uint32_t nitems = m.cnt[MC_ITEMS + L];
     const uint32_t shift = 20u + 8u * (MS_LEVELS - L);
     __shared__ u64 stage[MS_TILE];
-    __shared__ uint32_t cur[MS_NW][256];
+    __shared__ MsCnt cur[2];
     __shared__ uint32_t ls[MS_NW + 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int par = 0;
+    ms_clear(cur[0]);
+    __syncthreads();
     for (uint32_t it = blockIdx.x; it < nitems; it += gridDim.x) {
         const uint32_t item = m.items[(size_t)L * m.B * MS_ITEM_CAP + it];
         const uint4 sg = m.segs[(size_t)L * m.B * MS_SEG_SLOTS + (item & 0xFFFFFu)];
@@ -647,7 +694,8 @@ __global__ void __launch_bounds__(MS_THREADS, 4) seg_scatter(Msd m, uint32_t L)
             v[k] = src[p < cntv ? p : 0u]; // (branch-free; slots past the end are never ranked)
         }
         uint32_t pos[MS_ITEMS / 2];
-        tile_rank(v, (int)shift, 8, actmask, MS_ITEMS, cur, ls, pos);
+        tile_rank<8>(v, (int)shift, actmask, MS_ITEMS, cur[par], cur[par ^ 1], ls, pos);
+        par ^= 1;
 #pragma unroll
         for (int k = 0; k < MS_ITEMS; k++)
             if ((actmask >> k) & 1u) stage[(pos[k >> 1] >> (16 * (k & 1))) & 0xFFFFu] = v[k];
@@ -674,19 +722,27 @@ __global__ void __launch_bounds__(MS_THREADS, 4) seg_scatter(Msd m, uint32_t L)
 }
 
 // ---- one unit = whole buckets, at most a tile: sorted, ranked and routed inside one workgroup ----------------------------
+// Sort: elements in registers, wave w holding rows of 64 consecutive slots ("striped": what the ballot ranking wants);
+// LDS element = [bucket index in the unit : 8 @53][bytes 2..6 : 40 @13][slot the element was loaded at : 13] -- the suffix
+// stays in the registers of that slot and is fetched through LDS once, after the last pass.
+// After the sort: every thread owns 16 CONSECUTIVE sorted elements ("blocked", as refine_one): group boundaries by
+// comparing neighbours in registers, extents by two workgroup scans, lists and binned rank pairs through LDS.
+constexpr int MS_SLOTS = MS_TILE + MS_TILE / 16;
+__device__ __forceinline__ uint32_t ms_slot(uint32_t e) { return e + (e >> 4); } // (+1 per 16: blocked 8-byte reads stay conflict free)
+
 __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
 {
-    __shared__ u64 stage[MS_TILE];
-    __shared__ uint32_t cur[MS_NW][256];
-    __shared__ u64 HM[128];          // bucket heads by position (bit per slot), later: group heads per row
-    __shared__ u64 rowlast[128];     // key of the last element of every row
-    __shared__ int carryIn[128], nextFirst[128];
-    __shared__ uint32_t rowpre[128], rowS[128], rowB[128];
+    __shared__ u64 stage[MS_SLOTS];
+    __shared__ MsCnt cur[2];         // counters of the passes; afterwards: the bins of the rank binning and a scan row
+    __shared__ u64 HM[128];          // bucket heads by position (bit per slot)
+    __shared__ uint32_t rowpre[128];
     __shared__ uint32_t ls[MS_NW + 2];
+    __shared__ int lmm[MS_NW];
     __shared__ u64 s_or, s_and;
-    // rank binning (after the sort, when the counters of the passes are free): counts, local starts, cursors, offsets
-    uint32_t *const bh = &cur[0][0], *const bl = &cur[1][0], *const bcur = &cur[2][0], *const bgo = &cur[3][0];
-    __shared__ uint32_t s_unit, s_offS, s_offB, s_totS, s_totB;
+    __shared__ uint32_t s_unit, s_offS, s_offB;
+    uint32_t *const bh = reinterpret_cast<uint32_t *>(&cur[0][0][0]); // 4 x 256 words: counts, local starts, cursors, offsets
+    uint32_t *const bl = bh + 256, *const bcur = bh + 512, *const bgo = bh + 768;
+    int *const exh = reinterpret_cast<int *>(&cur[1][0][0]);           // 512 ints: last boundary at or before every thread's range
     const uint32_t nunits = min(m.cnt[MC_UNITS], m.B * MS_UNIT_CAP);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t tid = threadIdx.x;
@@ -714,12 +770,10 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
             __syncthreads();
             continue;
         }
-        MS_T(0);
         const u64 *src = (buf ? m.bufY : m.bufX) + (size_t)b * m.S + s;
-        const int R = (int)((len + 511u) / 512u);       // rows of 64 per wave
-        const uint32_t Lw = (uint32_t)R * 64u;          // positions per wave
-        const uint32_t nrows = (len + 63u) / 64u;       // rows of the unit (row r = positions 64 r ..)
-        // ---- load; bucket index of every position from the bucket starts
+        const int R = (int)((len + 511u) / 512u); // rows of 64 per wave
+        const uint32_t Lw = (uint32_t)R * 64u;    // slots per wave
+        // ---- load; bucket index of every slot from the bucket starts
         u64 x[MS_ITEMS];
         uint32_t suf[MS_ITEMS];
         uint32_t actmask = 0;
@@ -728,6 +782,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
             s_or = 0ull;
             s_and = ~0ull;
         }
+        ms_clear(cur[0]);
         __syncthreads();
         const bool multi = !uniform && nb > 1u;
         if (multi) {
@@ -769,7 +824,6 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
                 }
             }
         }
-        MS_T(1);
         // ---- which digits vary inside the unit?  (a level-L unit shares bytes 2 .. 1+L; a single bucket has one index)
         {
             u64 o = 0ull, a = ~0ull;
@@ -791,179 +845,131 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
             }
         }
         __syncthreads();
+        MS_T(0);
         const u64 vary = uniform ? 0ull : (s_or & ~s_and);
-        MS_T(2);
         uint32_t pos[MS_ITEMS / 2];
+        int par = 0;
+        bool staged = false;
 #pragma unroll 1
         for (int pass = 0; pass < 6; pass++) {
             const int sh = pass < 5 ? 13 + 8 * pass : 53;
             if (((vary >> sh) & 255ull) == 0ull) continue; // (the same for every thread)
-            if ((m.dbg & 1u) || ((m.dbg & 2u) && pass == 5)) continue;
-            const int nbits = pass < 5 ? 8 : max(1, 32 - __clz((int)(min(nbk, 256u) - 1u)));
-            tile_rank(x, sh, nbits, actmask, R, cur, ls, pos);
+            tile_rank<8>(x, sh, actmask, R, cur[par], cur[par ^ 1], ls, pos); // (ONE call site: the kernel has to fit the instruction cache)
+            par ^= 1;
+            MS_T(1);
 #pragma unroll
             for (int k = 0; k < MS_ITEMS; k++)
-                if ((actmask >> k) & 1u) stage[(pos[k >> 1] >> (16 * (k & 1))) & 0xFFFFu] = x[k];
+                if ((actmask >> k) & 1u) stage[ms_slot((pos[k >> 1] >> (16 * (k & 1))) & 0xFFFFu)] = x[k];
             __syncthreads();
+            MS_T(2);
+            staged = true;
+            bool again = false; // is there another pass?  (then the striped registers are refilled)
+            for (int q = pass + 1; q < 6; q++) again |= ((vary >> (q < 5 ? 13 + 8 * q : 53)) & 255ull) != 0ull;
+            if (again) {
 #pragma unroll
-            for (int k = 0; k < MS_ITEMS; k++) x[k] = stage[wave * Lw + k * 64 + lane];
+                for (int k = 0; k < MS_ITEMS; k++) x[k] = stage[ms_slot((wave * Lw + k * 64 + lane) & 8191u)];
+            }
+        }
+        if (!staged) { // nothing to sort (one key): the blocked phase still reads the elements from the stage
+#pragma unroll
+            for (int k = 0; k < MS_ITEMS; k++)
+                if ((actmask >> k) & 1u) stage[ms_slot(wave * Lw + k * 64 + lane)] = x[k];
+            __syncthreads();
         }
         MS_T(3);
-        __syncthreads(); // everybody has its sorted elements; the stage is free
-        if (m.dbg & 4u) continue;
-        // ---- suffixes follow their elements (they stayed in the registers of the slot they were loaded at)
+        // ---- blocked: my 16 consecutive sorted elements, group boundaries, extents
+        const uint32_t e0 = tid * MS_ITEMS;
+        uint32_t lidx[MS_ITEMS / 2]; // the slots my elements were loaded at, 16 bits each
+        uint32_t bdm = 0;            // bit k: element e0 + k starts a group
+        {
+            u64 prevk = e0 ? (stage[ms_slot(e0 - 1)] >> 13) : 0ull;
+#pragma unroll
+            for (int k = 0; k < MS_ITEMS / 2; k++) lidx[k] = 0;
+#pragma unroll
+            for (int k = 0; k < MS_ITEMS; k++) {
+                const uint32_t q = e0 + k;
+                const u64 yk = stage[ms_slot(q & 8191u)];
+                const u64 key = yk >> 13;
+                lidx[k >> 1] |= ((uint32_t)yk & 8191u) << (16 * (k & 1));
+                if (q < len && (q == 0 || (!uniform && key != prevk))) bdm |= 1u << k;
+                prevk = key;
+            }
+        }
+        const int lastbd = bdm ? (int)e0 + 31 - __clz((int)bdm) : -1;
+        const int firstbd = bdm ? (int)e0 + __ffs((int)bdm) - 1 : INT32_MAX;
+        const int incl = block_incl_max(lastbd, lmm);
+        exh[tid] = incl;
+        int nxt = block_excl_min_rev(firstbd, lmm); // (barrier inside: exh is visible after it; every thread has read its elements)
+        const int cd = tid ? exh[tid - 1] : -1;
+        if (nxt == INT32_MAX) nxt = (int)len;
+        // the suffixes follow their elements: table of the slots' suffixes over the (now free) stage
         {
             uint32_t *st32 = reinterpret_cast<uint32_t *>(stage);
 #pragma unroll
             for (int k = 0; k < MS_ITEMS; k++)
                 if ((actmask >> k) & 1u) st32[wave * Lw + k * 64 + lane] = suf[k];
-            // group structure meanwhile: last key of every row
+        }
+        if (tid < 256) bh[tid] = 0; // (the pass counters are free: the last pass ended behind barriers)
+        {
+            const uint32_t nheads = wave_reduce_add((uint32_t)__popc(bdm));
+            if (lane == 0 && nheads) atomicAdd(&m.c_groups[b], nheads);
+        }
+        // class and rank of element k from the boundary bits: [class : 2 @30][first position of its group in the block's order : 20]
+        auto class_head = [&](int k) -> uint32_t {
+            const uint32_t below = bdm & ((2u << k) - 1u), above = k < 15 ? bdm >> (k + 1) : 0u;
+            const int head = below ? (int)e0 + 31 - __clz((int)below) : cd;
+            const int end = above ? (int)e0 + k + __ffs((int)above) : nxt;
+            const uint32_t size = (uint32_t)(end - head);
+            uint32_t c = size == 1u ? CLS_SINGLE : (size <= (uint32_t)TAIL_G ? CLS_SMALL : CLS_BIG);
+            uint32_t hp = s + (uint32_t)head;
+            if (uniform) { // one tile of a group that spans several units
+                c = CLS_BIG;
+                hp = tbl;
+            }
+            return (c << 30) | hp;
+        };
+        uint32_t nS = 0, nB = 0;
 #pragma unroll
-            for (int k = 0; k < MS_ITEMS; k++) {
-                if (k < R) {
-                    const uint32_t p = wave * Lw + k * 64 + lane;
-                    if (p < len && (lane == 63 || p == len - 1)) rowlast[p >> 6] = x[k] >> 13;
-                }
+        for (int k = 0; k < MS_ITEMS; k++) {
+            if (e0 + k < len) {
+                const uint32_t c = class_head(k) >> 30;
+                nS += c == CLS_SMALL;
+                nB += c == CLS_BIG;
             }
         }
-        __syncthreads();
+        uint32_t totS, totB;
+        const uint32_t offS = block_excl_add(nS, ls, &totS); // (barriers inside: the suffix table is complete behind them)
+        const uint32_t offB = block_excl_add(nB, ls, &totB);
+        if (tid == 0) {
+            s_offS = totS ? atomicAdd(&m.c_small[b], totS) : 0u;
+            s_offB = totB ? atomicAdd(&m.c_big[b], totB) : 0u;
+        }
+        MS_T(4);
+        uint32_t sf[MS_ITEMS];
         {
             const uint32_t *st32 = reinterpret_cast<const uint32_t *>(stage);
 #pragma unroll
-            for (int k = 0; k < MS_ITEMS; k++) suf[k] = st32[(uint32_t)x[k] & 8191u];
-        }
-        // group heads: ballot per row; carries across rows through LDS
-        uint32_t nheads = 0;
-#pragma unroll
-        for (int k = 0; k < MS_ITEMS; k++) {
-            if (k < R) {
-                const uint32_t p = wave * Lw + k * 64 + lane, row = p >> 6;
-                const bool act = p < len;
-                const u64 key = x[k] >> 13;
-                u64 prev = ((u64)(uint32_t)__shfl_up((int)(key >> 32), 1, 64) << 32) | (uint32_t)__shfl_up((int)key, 1, 64);
-                if (lane == 0 && act && row > 0) prev = rowlast[row - 1];
-                const bool bd = act && (p == 0 || uniform == 0u) && (p == 0 || key != prev);
-                const u64 hm = __ballot(bd);
-                if (lane == 0 && act) { // (the active positions of a row are a prefix of it)
-                    HM[row] = hm;
-                    carryIn[row] = hm ? (int)(row * 64u) + 63 - __clzll((long long)hm) : -1;        // (last head of the row)
-                    nextFirst[row] = hm ? (int)(row * 64u) + __ffsll((long long)hm) - 1 : INT32_MAX; // (first head of the row)
-                }
-                nheads += lane == 0 ? (uint32_t)__popcll(hm) : 0u;
+            for (int k = 0; k < MS_ITEMS; k++) {
+                sf[k] = st32[(lidx[k >> 1] >> (16 * (k & 1))) & 0xFFFFu];
+                if (e0 + k < len) atomicAdd(&bh[sf[k] >> 12], 1u);
             }
         }
-        __syncthreads();
-        if (wave == 0) { // exclusive prefix max of the last heads, exclusive suffix min of the first heads, over the rows
-            const uint32_t r0 = lane * 2u, r1 = r0 + 1u;
-            const int a0 = r0 < nrows ? carryIn[r0] : -1, a1 = r1 < nrows ? carryIn[r1] : -1;
-            const int f0 = r0 < nrows ? nextFirst[r0] : INT32_MAX, f1 = r1 < nrows ? nextFirst[r1] : INT32_MAX;
-            int inc = max(a0, a1);
-            inc = wave_incl_max(inc, lane);
-            int exm = __shfl_up(inc, 1, 64);
-            if (lane == 0) exm = -1;
-            int sm = min(f0, f1); // inclusive suffix min
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int t = __shfl_down(sm, d, 64);
-                if (lane + d < 64) sm = min(sm, t);
-            }
-            int exs = __shfl_down(sm, 1, 64);
-            if (lane == 63) exs = INT32_MAX;
-            if (r0 < nrows) {
-                carryIn[r0] = exm;
-                nextFirst[r0] = min(f1, exs);
-            }
-            if (r1 < nrows) {
-                carryIn[r1] = max(exm, a0);
-                nextFirst[r1] = exs;
-            }
-        }
-        __syncthreads();
-        MS_T(4);
-        // class of every element, rank words, counts of the two lists
-        uint32_t headg[MS_ITEMS]; // [class:2 @30][rank = first position of the group in the block's order : 20]
-#pragma unroll
-        for (int k = 0; k < MS_ITEMS; k++) {
-            headg[k] = 0;
-            if (k < R) {
-                const uint32_t p = wave * Lw + k * 64 + lane, row = p >> 6;
-                const bool act = p < len;
-                uint32_t c = CLS_SINGLE, hg = 0;
-                if (act) {
-                    if (uniform) {
-                        c = CLS_BIG;
-                        hg = tbl;
-                    } else {
-                        const u64 hm = HM[row];
-                        const u64 upto = (2ull << lane) - 1ull;
-                        const u64 below = hm & upto, above = hm & ~upto;
-                        const int head = below ? (int)(row * 64u) + 63 - __clzll((long long)below) : carryIn[row];
-                        int end = above ? (int)(row * 64u) + __ffsll((long long)above) - 1 : nextFirst[row];
-                        if (end > (int)len) end = (int)len;
-                        const uint32_t size = (uint32_t)(end - head);
-                        c = size == 1u ? CLS_SINGLE : (size <= (uint32_t)TAIL_G ? CLS_SMALL : CLS_BIG);
-                        hg = s + (uint32_t)head;
-                    }
-                }
-                headg[k] = (c << 30) | hg;
-                const u64 mS = __ballot(act && c == CLS_SMALL), mB = __ballot(act && c == CLS_BIG);
-                if (lane == 0 && act) {
-                    rowS[row] = (uint32_t)__popcll(mS);
-                    rowB[row] = (uint32_t)__popcll(mB);
-                }
-            }
-        }
-        if (tid < 256) bh[tid] = 0;
-        nheads = wave_reduce_add(nheads);
-        if (lane == 0 && nheads) atomicAdd(&m.c_groups[b], nheads);
-        __syncthreads();
-        if (wave == 0) { // exclusive scans of the row counts; room in the two lists
-            const uint32_t r0 = lane * 2u, r1 = r0 + 1u;
-            const uint32_t s0 = r0 < nrows ? rowS[r0] : 0u, s1 = r1 < nrows ? rowS[r1] : 0u;
-            const uint32_t b0 = r0 < nrows ? rowB[r0] : 0u, b1 = r1 < nrows ? rowB[r1] : 0u;
-            const uint32_t is = wave_incl_add(s0 + s1, lane), ib = wave_incl_add(b0 + b1, lane);
-            if (r0 < nrows) {
-                rowS[r0] = is - s0 - s1;
-                rowB[r0] = ib - b0 - b1;
-            }
-            if (r1 < nrows) {
-                rowS[r1] = is - s1;
-                rowB[r1] = ib - b1;
-            }
-            if (lane == 63) {
-                s_totS = is;
-                s_totB = ib;
-                s_offS = is ? atomicAdd(&m.c_small[b], is) : 0u;
-                s_offB = ib ? atomicAdd(&m.c_big[b], ib) : 0u;
-            }
-        }
-        // rank binning, step 1: counts per 4096-suffix window (the suffix table in the stage is no longer needed)
-#pragma unroll
-        for (int k = 0; k < MS_ITEMS; k++)
-            if ((actmask >> k) & 1u) atomicAdd(&bh[suf[k] >> 12], 1u);
-        __syncthreads();
-        const uint32_t totS = s_totS, totB = s_totB;
+        __syncthreads(); // the table has been read; the bin counts are complete
         MS_T(5);
         // list records through LDS: small groups at [0, totS), large groups behind them
+        {
+            uint32_t wS = offS, wB = totS + offB;
 #pragma unroll
-        for (int k = 0; k < MS_ITEMS; k++) {
-            if (k < R) {
-                const uint32_t p = wave * Lw + k * 64 + lane, row = p >> 6;
-                const bool act = p < len;
-                const uint32_t c = headg[k] >> 30;
-                const u64 mS = __ballot(act && c == CLS_SMALL), mB = __ballot(act && c == CLS_BIG);
-                if (act && c != CLS_SINGLE) {
-                    const u64 lower = (1ull << lane) - 1ull;
-                    const u64 rec = ((u64)(headg[k] & 0xFFFFFu) << 40) | suf[k];
-                    if (c == CLS_SMALL)
-                        stage[rowS[row] + (uint32_t)__popcll(mS & lower)] = rec;
-                    else
-                        stage[totS + rowB[row] + (uint32_t)__popcll(mB & lower)] = rec;
+            for (int k = 0; k < MS_ITEMS; k++) {
+                if (e0 + k < len) {
+                    const uint32_t ch = class_head(k), c = ch >> 30;
+                    const u64 rec = ((u64)(ch & 0xFFFFFu) << 40) | sf[k];
+                    if (c == CLS_SMALL) stage[wS++] = rec;
+                    if (c == CLS_BIG) stage[wB++] = rec;
                 }
             }
         }
-        MS_T(6);
-        // rank binning, step 2: local starts of the bins, their room in the block's windows
+        // rank binning: local starts of the bins, their room in the block's windows
         {
             const uint32_t c = tid < 256 ? bh[tid] : 0u;
             uint32_t tot;
@@ -987,12 +993,13 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
             for (uint32_t q = tid; q < totB; q += MS_THREADS) bs[q] = stage[totS + q];
         }
         __syncthreads();
+        MS_T(6);
 #pragma unroll
         for (int k = 0; k < MS_ITEMS; k++) {
-            if ((actmask >> k) & 1u) {
-                const uint32_t c = headg[k] >> 30, hg = headg[k] & 0xFFFFFu;
-                const uint32_t word = c == CLS_SINGLE ? (hg | RANK_RESOLVED) : hg;
-                stage[atomicAdd(&bcur[suf[k] >> 12], 1u)] = ((u64)word << 32) | suf[k];
+            if (e0 + k < len) {
+                const uint32_t ch = class_head(k), c = ch >> 30, head = ch & 0xFFFFFu;
+                const uint32_t word = c == CLS_SINGLE ? (head | RANK_RESOLVED) : head;
+                stage[atomicAdd(&bcur[sf[k] >> 12], 1u)] = ((u64)word << 32) | sf[k];
             }
         }
         __syncthreads();
