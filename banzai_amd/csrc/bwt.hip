@@ -1784,6 +1784,9 @@ __global__ void __launch_bounds__(1024) period_probe(ProbeArgs a)
 //                10/11 sum of the S lists, 12/13 sum of the A lists, 14 error flag, 15 largest depth in use,
 //                16 S blocks whose refine writes lists this round (the only ones that can leave SWEEP mode next round),
 //                17/18 sum over the rounds so far of the unresolved suffixes entering them, 19 sequence word (last)
+#ifndef QUAD_DIV
+#define QUAD_DIV 10u
+#endif
 constexpr uint32_t QUAD_BIT = 0x80000000u; // in st_ntail-derived gates: this round runs at depth x4
 enum ListId : int { L_S = 0, L_A = 1, L_R = 2, L_T = 3, L_Q = 4, L_P = 5 };
 
@@ -1864,7 +1867,7 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
     }
     // a block with small groups only may look three h-blocks ahead (depth 4h, three gathers per suffix):
     // worth it once few suffixes are left -- in the block, or in the whole batch -- when rounds are latency-bound
-    const bool few = (uint64_t)gT * 10u < n || (uint64_t)sum[0] * 10ull < sum[3];
+    const bool few = (uint64_t)gT * QUAD_DIV < n || (uint64_t)sum[0] * QUAD_DIV < sum[3];
     const uint32_t quad = (valid && gA == 0u && gT != 0u && few && h < (1u << 28)) ? 1u : 0u;
     if (valid) bt.gateT[b] = gT | (quad ? QUAD_BIT : 0u);
     // order-preserving lists: position = listed blocks in lower lanes + in earlier wavefronts
