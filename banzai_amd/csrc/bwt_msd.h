@@ -84,6 +84,8 @@ __device__ __forceinline__ void tile_rank(const T (&v)[MS_ITEMS], int sh, uint32
     uint32_t wr[MS_ITEMS / 2];
 #pragma unroll
     for (int k = 0; k < MS_ITEMS / 2; k++) wr[k] = 0;
+    // (tried: the match masks of four steps side by side, then their counter updates -- more independent work per
+    // wavefront, but 7 % slower: the masks of four steps cost more registers than the schedule gains)
 #pragma unroll
     for (int k = 0; k < MS_ITEMS; k++) {
         if (k < R) {
@@ -737,12 +739,11 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
     __shared__ u64 HM[128];          // bucket heads by position (bit per slot)
     __shared__ uint32_t rowpre[128];
     __shared__ uint32_t ls[MS_NW + 2];
-    __shared__ int lmm[MS_NW];
+    __shared__ int lmm[MS_NW], lmn[MS_NW];
     __shared__ u64 s_or, s_and;
     __shared__ uint32_t s_unit, s_offS, s_offB;
     uint32_t *const bh = reinterpret_cast<uint32_t *>(&cur[0][0][0]); // 4 x 256 words: counts, local starts, cursors, offsets
     uint32_t *const bl = bh + 256, *const bcur = bh + 512, *const bgo = bh + 768;
-    int *const exh = reinterpret_cast<int *>(&cur[1][0][0]);           // 512 ints: last boundary at or before every thread's range
     const uint32_t nunits = min(m.cnt[MC_UNITS], m.B * MS_UNIT_CAP);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t tid = threadIdx.x;
@@ -755,12 +756,17 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
         t_acc[k] += (uint32_t)((t_now - t_last) >> 4);          \
         t_last = t_now;                                         \
     }
+    // Global atomics return after one to two microseconds: the ticket of the NEXT unit, the room claimed in the two lists
+    // and in the rank windows are requested as soon as their arguments exist and consumed as late as possible.
+    uint32_t pend_ticket = 0;
+    if (tid == 0) pend_ticket = atomicAdd(&m.cnt[MC_TICKET], 1u);
     for (;;) {
         if ((m.dbg & 16u) && tid == 0) t_last = clock64();
-        if (tid == 0) s_unit = atomicAdd(&m.cnt[MC_TICKET], 1u);
+        if (tid == 0) s_unit = pend_ticket;
         __syncthreads();
         const uint32_t u = s_unit;
         if (u >= nunits) break;
+        if (tid == 0) pend_ticket = atomicAdd(&m.cnt[MC_TICKET], 1u);
         const uint4 ud = m.units[u];
         const uint32_t b = ud.x & 1023u, buf = (ud.x >> 10) & 1u, uniform = (ud.x >> 11) & 1u, nb = ud.x >> 12;
         const uint32_t s = ud.y, e = ud.z, tbl = ud.w, len = e - s;
@@ -810,11 +816,16 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
         __syncthreads();
         uint32_t nbk = 1; // non-empty buckets of the unit
         if (multi) {
-            const uint32_t pc = tid < 128 ? (uint32_t)__popcll(HM[tid]) : 0u;
-            const uint32_t ex = block_excl_add(pc, ls, &nbk);
-            if (tid < 128) rowpre[tid] = ex;
-            if (nbk > 256u && tid == 0) atomicOr(m.err, ERR_MSD);
+            if (wave == 0) { // bucket heads before every row of 64 slots: one wavefront, two rows a lane
+                const uint32_t p0 = (uint32_t)__popcll(HM[2 * lane]), p1 = (uint32_t)__popcll(HM[2 * lane + 1]);
+                const uint32_t inc = wave_incl_add(p0 + p1, lane);
+                rowpre[2 * lane] = inc - p0 - p1;
+                rowpre[2 * lane + 1] = inc - p1;
+                if (lane == 63) ls[0] = inc;
+            }
             __syncthreads();
+            nbk = ls[0];
+            if (nbk > 256u && tid == 0) atomicOr(m.err, ERR_MSD);
 #pragma unroll
             for (int k = 0; k < MS_ITEMS; k++) {
                 if ((actmask >> k) & 1u) {
@@ -897,11 +908,27 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
         }
         const int lastbd = bdm ? (int)e0 + 31 - __clz((int)bdm) : -1;
         const int firstbd = bdm ? (int)e0 + __ffs((int)bdm) - 1 : INT32_MAX;
-        const int incl = block_incl_max(lastbd, lmm);
-        exh[tid] = incl;
-        int nxt = block_excl_min_rev(firstbd, lmm); // (barrier inside: exh is visible after it; every thread has read its elements)
-        const int cd = tid ? exh[tid - 1] : -1;
-        if (nxt == INT32_MAX) nxt = (int)len;
+        // last boundary before my range / first boundary behind it: one pair of wave scans, one barrier
+        int cd, nxt;
+        {
+            int imax = lastbd, imin = firstbd; // inclusive prefix max / inclusive suffix min inside the wavefront
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int tu = __shfl_up(imax, d, 64), td = __shfl_down(imin, d, 64);
+                if (lane >= d) imax = max(imax, tu);
+                if (lane + d < 64) imin = min(imin, td);
+            }
+            if (lane == 63) lmm[wave] = imax;
+            if (lane == 0) lmn[wave] = imin;
+            int emax = __shfl_up(imax, 1, 64), emin = __shfl_down(imin, 1, 64);
+            if (lane == 0) emax = -1;
+            if (lane == 63) emin = INT32_MAX;
+            __syncthreads(); // (every thread has read its elements from the stage by now, too)
+            for (int w = 0; w < wave; w++) emax = max(emax, lmm[w]);
+            for (int w = wave + 1; w < MS_NW; w++) emin = min(emin, lmn[w]);
+            cd = emax;
+            nxt = emin == INT32_MAX ? (int)len : emin;
+        }
         // the suffixes follow their elements: table of the slots' suffixes over the (now free) stage
         {
             uint32_t *st32 = reinterpret_cast<uint32_t *>(stage);
@@ -937,12 +964,19 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
                 nB += c == CLS_BIG;
             }
         }
-        uint32_t totS, totB;
-        const uint32_t offS = block_excl_add(nS, ls, &totS); // (barriers inside: the suffix table is complete behind them)
-        const uint32_t offB = block_excl_add(nB, ls, &totB);
+        uint32_t totS, totB, offS, offB;
+        { // both compaction offsets in one scan: 16 bits each (a unit holds at most 8192 records)
+            uint32_t tot2;
+            const uint32_t off2 = block_excl_add(nS | (nB << 16), ls, &tot2); // (barriers inside: the suffix table is complete behind them)
+            offS = off2 & 0xFFFFu;
+            offB = off2 >> 16;
+            totS = tot2 & 0xFFFFu;
+            totB = tot2 >> 16;
+        }
+        uint32_t pendS = 0, pendB = 0;
         if (tid == 0) {
-            s_offS = totS ? atomicAdd(&m.c_small[b], totS) : 0u;
-            s_offB = totB ? atomicAdd(&m.c_big[b], totB) : 0u;
+            pendS = totS ? atomicAdd(&m.c_small[b], totS) : 0u;
+            pendB = totB ? atomicAdd(&m.c_big[b], totB) : 0u;
         }
         MS_T(4);
         uint32_t sf[MS_ITEMS];
@@ -970,20 +1004,19 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
             }
         }
         // rank binning: local starts of the bins, their room in the block's windows
+        uint32_t pendG = 0;
+        const uint32_t binc = tid < 256 ? bh[tid] : 0u;
+        if (tid == 0) {
+            s_offS = pendS;
+            s_offB = pendB;
+        }
         {
-            const uint32_t c = tid < 256 ? bh[tid] : 0u;
             uint32_t tot;
-            const uint32_t ex = block_excl_add(c, ls, &tot); // (barriers inside: the list records are in place after it)
+            const uint32_t ex = block_excl_add(binc, ls, &tot); // (barriers inside: the list records and offsets are in place after it)
             if (tid < 256) {
                 bl[tid] = ex;
                 bcur[tid] = ex;
-                uint32_t g = 0;
-                if (c) {
-                    g = atomicAdd(&m.bincur[(size_t)b * 256 + tid], c);
-                    const uint32_t w0 = tid * 4096u, wcap = w0 < n ? min(4096u, n - w0) : 0u;
-                    if (g + c > wcap) atomicOr(m.err, ERR_MSD);
-                }
-                bgo[tid] = min(n, tid * 4096u) + g;
+                if (binc) pendG = atomicAdd(&m.bincur[(size_t)b * 256 + tid], binc);
             }
         }
         {
@@ -991,6 +1024,11 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
             u64 *bs = m.big + (size_t)b * m.S + s_offB;
             for (uint32_t q = tid; q < totS; q += MS_THREADS) ts[q] = stage[q];
             for (uint32_t q = tid; q < totB; q += MS_THREADS) bs[q] = stage[totS + q];
+        }
+        if (tid < 256) {
+            const uint32_t w0 = tid * 4096u, wcap = w0 < n ? min(4096u, n - w0) : 0u;
+            if (binc && pendG + binc > wcap) atomicOr(m.err, ERR_MSD);
+            bgo[tid] = min(n, tid * 4096u) + pendG;
         }
         __syncthreads();
         MS_T(6);
