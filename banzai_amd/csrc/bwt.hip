@@ -2099,13 +2099,28 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     // round state: everything from st_mode to the 64-bit counter (one contiguous carve, see layout_batch)
     HIP_TRY(ctx, hipMemsetAsync(bt.st_mode, 0,
                                 (size_t)((uint8_t *)(bt.stat_A + 1) - (uint8_t *)bt.st_mode), st));
-    // ---- which blocks take which initial sort (bwt_msd.h): text-like blocks of at least MS_MIN_N bytes the bucket-first
-    // one, repetitive and short blocks the 8 passes below (`oldl`; all of them at levels whose blocks are too short)
-    // (measured in round 4, DESIGN.md section 4.1: bit-exact, but not faster on the headline -- the 8-pass sort stays the
-    // default; BZH_INIT=msd selects the bucket-first path)
+    // The second stream of the suffix sort (created once): the big-list path of a round runs on it beside the small-group
+    // kernel, and so do the 8 passes of the blocks that keep them when the rest of the batch takes the bucket-first
+    // initial sort.  (With profiling on everything stays on one stream, or the per-kernel spans would overlap.)
+    static const bool no_overlap = getenv("BZH_NO_OVERLAP") != nullptr;
+    hipStream_t side = nullptr;
+    if (!ctx->profiling && !no_overlap) {
+        if (!ctx->side_stream) {
+            if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) ctx->side_stream = nullptr;
+            if (ctx->side_stream && (hipEventCreateWithFlags(&ctx->side_ev[0], hipEventDisableTiming) != hipSuccess ||
+                                     hipEventCreateWithFlags(&ctx->side_ev[1], hipEventDisableTiming) != hipSuccess)) {
+                hipStreamDestroy(ctx->side_stream);
+                ctx->side_stream = nullptr;
+            }
+        }
+        side = ctx->side_stream;
+    }
+    // ---- which blocks take which initial sort (bwt_msd.h): text-like blocks the bucket-first one (the plan decides per
+    // block, on the device), repetitive, random and binary blocks the 8 passes below (`oldl`; all blocks at level 1,
+    // whose blocks are too short for the tables to pay).  BZH_INIT=lsd keeps every block on the 8 passes (A/B timing).
     static const bool init_lsd = []() {
         const char *e = getenv("BZH_INIT");
-        return !(e && !strcmp(e, "msd"));
+        return e && !strcmp(e, "lsd");
     }();
     const bool use_msd = ctx->M >= MS_MIN_N && !a.fault && !init_lsd;
     uint32_t nOld = B;
@@ -2116,7 +2131,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     const uint32_t epoch = (++ctx->bwt_epoch & 0xFFFFFFu) << 6;
     if (use_msd) {
         BZH_TRY(msd_initial_sort(ctx, B, nmax, ntotal, bufB, bufD, bufA, bufC, binned, false,
-                                 hrec0 + (size_t)MAX_ROUNDS * SUMMARY_WORDS, epoch + 63u, &nOld));
+                                 hrec0 + (size_t)MAX_ROUNDS * SUMMARY_WORDS, epoch + 63u, &nOld, side ? ctx->side_ev[0] : nullptr));
         oldl = Lst{bt.ms_old, bt.ms_cnt + MC_OLD, B};
         a.lst = oldl;
         if (getenv("BZH_TRACE_ROUNDS")) { // (debugging aid: waits for the device)
@@ -2135,11 +2150,20 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     const uint64_t ntotal_old = nOld == B ? ntotal : ntotal * nOld / B; // (statistics only)
     u64 *cur = bufA, *oth = bufB;
     hipEvent_t ev_init = span_begin(ctx);
+    // A mixed batch: the few blocks on the 8 passes cannot fill the device (one block alone takes ~3 ms for them), so
+    // they run on the second stream beside the bucket-first kernels of the others, from the plan's end on.
+    const bool old_beside = use_msd && side && nOld && nOld < B;
+    hipStream_t so = st;
+    if (old_beside) {
+        hipStreamWaitEvent(side, ctx->side_ev[0], 0);
+        so = side;
+        ctx->stream = side; // (launch_pass / launch_refine_one launch on the context's stream)
+    }
     if (nOld) {
         {
             KSpan ks(ctx, K_BYTE_COUNT, ntotal_old, 2);
-            byte_count<<<dim3(BYTE_SEGS, B), 1024, 0, st>>>(bt.rle, bt.n, bt.dtot, bt.S);
-            active_bases<<<dim3(B), 256, 0, st>>>(bt.dtot, bt.dbase, all, 1);
+            byte_count<<<dim3(BYTE_SEGS, B), 1024, 0, so>>>(bt.rle, bt.n, bt.dtot, bt.S);
+            active_bases<<<dim3(B), 256, 0, so>>>(bt.dtot, bt.dbase, all, 1);
         }
         {
             KSpan ks(ctx, K_RADIX_INIT, 13 * ntotal_old); // 5 text bytes in, one element out
@@ -2204,6 +2228,11 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         if (nOld) {
             KSpan ks(ctx, K_REFINE_INIT, 16 * ntotal_old);
             launch_refine_one<true>(ctx, r, nOld, nmax, binned);
+        }
+        if (old_beside) { // the main stream goes on only behind the second stream's work
+            ctx->stream = st;
+            hipEventRecord(ctx->side_ev[1], side);
+            hipStreamWaitEvent(st, ctx->side_ev[1], 0);
         }
         KSpan ks(ctx, K_RANK_APPLY, 12 * ntotal);
         rank_apply<<<dim3((nmax + APPLY_W - 1) / APPLY_W, B), 256, 0, st>>>(binned, bt.n, bt.rank, bt.S);
@@ -2308,19 +2337,6 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     // one thing they share -- the rank array, read by the first, written by the second -- keeps both versions of a
     // word (rank_at), so the two run side by side: the big-list path on a second stream between two events.  (With
     // profiling on everything stays on one stream, or the per-kernel spans would overlap.)
-    static const bool no_overlap = getenv("BZH_NO_OVERLAP") != nullptr;
-    hipStream_t side = nullptr;
-    if (!ctx->profiling && !no_overlap) {
-        if (!ctx->side_stream) {
-            if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) ctx->side_stream = nullptr;
-            if (ctx->side_stream && (hipEventCreateWithFlags(&ctx->side_ev[0], hipEventDisableTiming) != hipSuccess ||
-                                     hipEventCreateWithFlags(&ctx->side_ev[1], hipEventDisableTiming) != hipSuccess)) {
-                hipStreamDestroy(ctx->side_stream);
-                ctx->side_stream = nullptr;
-            }
-        }
-        side = ctx->side_stream;
-    }
     bool side_busy = false;
     auto join_side = [&]() { // the main stream goes on only behind what the side stream was given
         if (side_busy) hipStreamWaitEvent(st, ctx->side_ev[1], 0);

@@ -5,9 +5,10 @@
 // order-consistent ranking of the rotations by a prefix of known minimum depth, the doubling rounds do the rest).
 //
 //   bigram_hist      65,536-bin histogram of the block's 2-byte cyclic prefixes (packed 16-bit LDS counters)
-//   bigram_plan      one workgroup per block: bucket starts (scan), a sampled "is this block repetitive" test (such
-//                    blocks keep the 8-pass path and its SWEEP mode), the work list: buckets of at most MS_TILE
-//                    suffixes become UNITS (small ones packed together by position window), larger ones go to level 1
+//   bigram_plan      one workgroup per block: bucket starts (scan); which blocks qualify -- a sampled "is this block
+//                    repetitive" test (such blocks keep the 8-pass path and its SWEEP mode) and at most MS_NE_MAX
+//                    non-empty buckets (text-like: random / binary blocks keep it too); the work list: buckets of at
+//                    most MS_TILE suffixes become UNITS (neighbours packed together greedily), larger ones go to level 1
 //   bigram_scatter   ONE pass from the text to 2-byte buckets: a tile's suffixes are ordered by bigram inside LDS
 //                    (two local counting passes), every run of equal bigrams claims its room in the bucket with one
 //                    atomic add (a first pass has no order to keep) and leaves as a coalesced store.
@@ -24,8 +25,6 @@
 #pragma once
 
 constexpr int MS_THREADS = 512, MS_ITEMS = 16, MS_TILE = 8192, MS_NW = 8;
-constexpr uint32_t MS_SMALL = 4096; // buckets up to this size are packed into shared units ...
-constexpr uint32_t MS_WIN = 4096;   // ... by the 4096-position window they start in (a unit stays below MS_TILE)
 constexpr uint32_t MS_BG = 65536;
 constexpr uint32_t MS_SAMPLES = 4096;
 enum : uint32_t { MC_UNITS = 0, MC_TICKET = 1, MC_PLAN_DONE = 2, MC_OLD = 3, MC_NEW = 4, MC_SEGS = 8, MC_ITEMS = 16 };
@@ -239,9 +238,8 @@ __global__ void __launch_bounds__(1024) bigram_hist(Msd m)
 // Units are packed greedily over the non-empty buckets in order: a bucket joins the unit before it unless the unit
 // would exceed MS_TILE suffixes (or, 2-byte level, 256 buckets: the bucket index is one more 8-bit digit); a bucket
 // of more than MS_TILE suffixes is a unit of its own kind: an oversized bucket for the next level.
-__device__ __forceinline__ uint32_t ms_class(uint32_t c) { return c <= MS_SMALL ? 0u : (c <= (uint32_t)MS_TILE ? 1u : 2u); }
 constexpr uint32_t MS_NE_MAX = 8192; // non-empty 2-byte buckets the greedy packing holds in LDS (text has ~1,000-5,000);
-                                     // beyond that (random data: all 65,536, tiny) buckets are packed by position window
+                                     // a block with more (random / binary data) keeps the 8-pass path
 
 // Appends an oversized bucket [s, e) of block b to level L: slot of the block, cleared digit counters, its tiles.
 // Called by ONE thread per bucket.
@@ -325,27 +323,32 @@ __global__ void __launch_bounds__(1024) bigram_plan(Msd m, uint32_t *hsum, uint3
         __syncthreads();
         np = (uint64_t)s_distinct * 2u >= (uint64_t)MS_SAMPLES;
     }
-    if (tid == 0) {
-        m.np[b] = np ? 1u : 0u;
-        const uint32_t k = atomicAdd(&m.cnt[np ? MC_NEW : MC_OLD], 1u);
-        (np ? m.act_new : m.act_old)[k] = b;
-    }
+    uint32_t NE = 0, exT = 0, exNE = 0;
+    uint32_t *cur = m.bgcur + (size_t)b * MS_BG;
+    const uint32_t k0 = tid * 64;
     if (np) {
-        uint32_t *cur = m.bgcur + (size_t)b * MS_BG;
-        uint32_t *st = m.pool + (size_t)b * MS_BG_ROW;
-        const uint32_t k0 = tid * 64;
-        // pass A: my 64 buckets -- suffixes, non-empty buckets
+        // my 64 buckets -- suffixes, non-empty buckets
         uint32_t tot = 0, ne = 0;
         for (int q = 0; q < 64; q += 4) {
             const uint4 c4 = *reinterpret_cast<const uint4 *>(cur + k0 + q);
             tot += c4.x + c4.y + c4.z + c4.w;
             ne += (c4.x != 0u) + (c4.y != 0u) + (c4.z != 0u) + (c4.w != 0u);
         }
-        uint32_t all, NE;
-        const uint32_t exT = block_excl_add(tot, ls, &all);
-        const uint32_t exNE = block_excl_add(ne, ls, &NE);
+        uint32_t all;
+        exT = block_excl_add(tot, ls, &all);
+        exNE = block_excl_add(ne, ls, &NE);
         if (all != n && tid == 0) atomicOr(m.err, ERR_MSD);
-        const bool greedy = NE <= MS_NE_MAX;
+        // Text has a few thousand distinct 2-byte prefixes; a block with more than MS_NE_MAX of them (random or binary
+        // data: up to all 65,536, tiny) gains nothing from buckets and keeps the 8-pass path as well.
+        np = NE <= MS_NE_MAX;
+    }
+    if (tid == 0) {
+        m.np[b] = np ? 1u : 0u;
+        const uint32_t k = atomicAdd(&m.cnt[np ? MC_NEW : MC_OLD], 1u);
+        (np ? m.act_new : m.act_old)[k] = b;
+    }
+    if (np) {
+        uint32_t *st = m.pool + (size_t)b * MS_BG_ROW;
         // pass B: bucket starts (kept for the finishing kernel) = claim cursors of the partition; the non-empty buckets
         // in order into LDS (the hash set is no longer needed: every thread passed the barriers of the scans)
         {
@@ -357,7 +360,7 @@ __global__ void __launch_bounds__(1024) bigram_plan(Msd m, uint32_t *hsum, uint3
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
                     o[t] = run;
-                    if (c[t] && greedy) tab[j++] = ((u64)(k0 + q + t) << 40) | ((u64)c[t] << 20) | run;
+                    if (c[t]) tab[j++] = ((u64)(k0 + q + t) << 40) | ((u64)c[t] << 20) | run;
                     run += c[t];
                 }
                 *reinterpret_cast<uint4 *>(st + k0 + q) = make_uint4(o[0], o[1], o[2], o[3]);
@@ -367,87 +370,36 @@ __global__ void __launch_bounds__(1024) bigram_plan(Msd m, uint32_t *hsum, uint3
         }
         if (tid == 0) s_nheads = 0;
         __syncthreads();
-        if (greedy) {
-            if (wave == 0) { // one wavefront packs: 64 buckets a step, one ballot round per unit that starts among them
-                uint32_t ubase = 0, uidx = 0, nh = 0;
-                bool open = false, carry_over = false;
-                for (uint32_t i0 = 0; i0 < NE; i0 += 64) {
-                    const uint32_t i = i0 + lane;
-                    const bool valid = i < NE;
-                    const u64 e = valid ? tab[i] : 0ull;
-                    const uint32_t stt = (uint32_t)e & 0xFFFFFu, c = (uint32_t)(e >> 20) & 0xFFFFFu;
-                    const bool over = valid && c > (uint32_t)MS_TILE;
-                    bool pover = __shfl_up((int)over, 1, 64) != 0;
-                    if (lane == 0) pover = carry_over;
-                    carry_over = __shfl((int)over, 63, 64) != 0;
-                    const uint32_t end = stt + c;
-                    u64 todo = __ballot(valid);
-                    while (todo) {
-                        const bool brk = valid && (!open || over || pover || end - ubase > (uint32_t)MS_TILE || i - uidx >= 256u);
-                        const u64 bm = __ballot(brk) & todo;
-                        if (!bm) break;
-                        const int f = __ffsll((long long)bm) - 1;
-                        ubase = (uint32_t)__shfl((int)stt, f, 64);
-                        uidx = i0 + (uint32_t)f;
-                        open = true;
-                        if (lane == f && nh < 2048u) heads[nh] = make_uint2(stt, (uint32_t)(e >> 40) | ((over ? 2u : 0u) << 17));
-                        nh++;
-                        todo &= ~((2ull << f) - 1ull);
-                    }
-                }
-                if (lane == 0) {
-                    s_nheads = nh;
-                    if (nh > 2048u) atomicOr(m.err, ERR_MSD); // (cannot happen: at most ~n / MS_TILE * 2 + NE / 256 units)
+        if (wave == 0) { // one wavefront packs: 64 buckets a step, one ballot round per unit that starts among them
+            uint32_t ubase = 0, uidx = 0, nh = 0;
+            bool open = false, carry_over = false;
+            for (uint32_t i0 = 0; i0 < NE; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                const bool valid = i < NE;
+                const u64 e = valid ? tab[i] : 0ull;
+                const uint32_t stt = (uint32_t)e & 0xFFFFFu, c = (uint32_t)(e >> 20) & 0xFFFFFu;
+                const bool over = valid && c > (uint32_t)MS_TILE;
+                bool pover = __shfl_up((int)over, 1, 64) != 0;
+                if (lane == 0) pover = carry_over;
+                carry_over = __shfl((int)over, 63, 64) != 0;
+                const uint32_t end = stt + c;
+                u64 todo = __ballot(valid);
+                while (todo) {
+                    const bool brk = valid && (!open || over || pover || end - ubase > (uint32_t)MS_TILE || i - uidx >= 256u);
+                    const u64 bm = __ballot(brk) & todo;
+                    if (!bm) break;
+                    const int f = __ffsll((long long)bm) - 1;
+                    ubase = (uint32_t)__shfl((int)stt, f, 64);
+                    uidx = i0 + (uint32_t)f;
+                    open = true;
+                    if (lane == f && nh < 2048u) heads[nh] = make_uint2(stt, (uint32_t)(e >> 40) | ((over ? 2u : 0u) << 17));
+                    nh++;
+                    todo &= ~((2ull << f) - 1ull);
                 }
             }
-        } else {
-            // position windows (cls 0: at most MS_SMALL suffixes, 1: at most MS_TILE, 2: oversized): a bucket starts a
-            // unit if it is not small, if the bucket before it is not small, if it starts in another MS_WIN window than
-            // the bucket before it, or if it is the 256th since -- a unit of small buckets stays below MS_WIN + MS_SMALL.
-            uint32_t nh = 0, run = exT, rk = exNE;
-            // state of the non-empty bucket before my range: found by walking back through the starts (rare path)
-            bool e1 = false;
-            uint32_t c1 = 0, w1 = 0;
-            if (rk > 0) {
-                int k = (int)k0 - 1;
-                while (k >= 0 && st[k + 1] == st[k]) k--; // (st is complete: barrier above)
-                if (k >= 0) {
-                    e1 = true;
-                    c1 = ms_class(st[k + 1] - st[k]);
-                    w1 = st[k] / MS_WIN;
-                }
-            }
-            uint32_t hoff = 0;
-            for (int pass = 0; pass < 2; pass++) {
-                uint32_t j = 0;
-                bool e2 = e1;
-                uint32_t c2 = c1, w2 = w1, r2 = rk;
-                run = exT;
-                for (int q = 0; q < 64; q++) {
-                    const uint32_t c = st[k0 + q + 1] - st[k0 + q];
-                    if (c) {
-                        const uint32_t cls = ms_class(c), win = run / MS_WIN;
-                        const bool head = !e2 || cls != 0u || c2 != 0u || win != w2 || (r2 & 255u) == 0u;
-                        if (head) {
-                            if (pass == 1 && hoff + j < 2048u) heads[hoff + j] = make_uint2(run, (k0 + q) | (cls << 17));
-                            j++;
-                        }
-                        e2 = true;
-                        c2 = cls;
-                        w2 = win;
-                        r2++;
-                    }
-                    run += c;
-                }
-                if (pass == 0) {
-                    nh = j;
-                    uint32_t nhall;
-                    hoff = block_excl_add(nh, ls, &nhall);
-                    if (tid == 0) {
-                        s_nheads = nhall;
-                        if (nhall > 2048u) atomicOr(m.err, ERR_MSD);
-                    }
-                }
+            if (lane == 0) {
+                s_nheads = nh;
+                if (nh > 2048u) atomicOr(m.err, ERR_MSD); // (cannot happen: at most ~n / MS_TILE * 2 + NE / 256 units)
             }
         }
         __syncthreads();
@@ -1064,7 +1016,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
 // small-group lists in `tail`, big lists in `big`, c_small / c_big / c_groups -- what refine_one<init> leaves.
 // X / Y: the two list buffers the partition levels alternate between (X also receives the 2-byte partition).
 static int msd_initial_sort(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal, u64 *X, u64 *Y, u64 *big, u64 *tail, u64 *binned,
-                            bool force_old, volatile uint32_t *hrec, uint32_t seq, uint32_t *n_old)
+                            bool force_old, volatile uint32_t *hrec, uint32_t seq, uint32_t *n_old, hipEvent_t ev_plan)
 {
     Batch &bt = ctx->bt;
     hipStream_t st = ctx->stream;
@@ -1104,6 +1056,7 @@ static int msd_initial_sort(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t nt
             bigram_hist<<<dim3(BGH_SEGS, B), 1024, 0, st>>>(m);
         }
         bigram_plan<<<dim3(B), 1024, 0, st>>>(m, const_cast<uint32_t *>(hrec), seq);
+        if (ev_plan) hipEventRecord(ev_plan, st); // (what the blocks that keep the 8 passes wait for, on the second stream)
     }
     if (!force_old) {
         const Lst nl{bt.ms_new, bt.ms_cnt + MC_NEW, B};

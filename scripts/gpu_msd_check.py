@@ -1,4 +1,5 @@
-"""The opt-in bucket-first initial sort (BZH_INIT=msd, banzai_amd/csrc/bwt_msd.h) against the oracle: last column + origin
+"""The two initial sorts of the suffix sorter (argv[1] = msd: bucket-first, banzai_amd/csrc/bwt_msd.h, the default; lsd: the 8
+passes for every block) against the oracle: last column + origin
 pointer of single blocks and whole streams at levels 2, 5 and 9 (level 1's blocks keep the 8-pass path), over inputs
 that reach every part of it -- text (units of packed small buckets, oversized buckets split level by level), runs of
 one byte (a bucket that stays oversized through all five levels: the "one group" units), repetitive blocks (kept on
@@ -8,7 +9,7 @@ read once per process.  Exit code 1 on any mismatch."""
 import os
 import sys
 
-os.environ["BZH_INIT"] = "msd"
+os.environ["BZH_INIT"] = sys.argv[1] if len(sys.argv) > 1 else "msd"  # "msd": bucket-first where the plan allows it (the default); "lsd": 8 passes everywhere
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from banzai_amd import _native as nv, corpus
@@ -40,5 +41,5 @@ for level, d in streams:
         if ctx.encode(d) != po.encode(d, level):
             bad += 1
             print("STREAM MISMATCH level", level, len(d))
-print("bucket-first initial sort:", len(blocks), "blocks,", len(streams), "streams, mismatches:", bad)
+print("initial sort", os.environ["BZH_INIT"] + ":", len(blocks), "blocks,", len(streams), "streams, mismatches:", bad)
 sys.exit(1 if bad else 0)

@@ -870,13 +870,15 @@ def test_full_size_headline_bit_exact_vs_oracle(oracle, native):
         assert d_out[:ln].cpu().numpy().tobytes() == want
 
 
-def test_bucket_first_initial_sort(native):
-    """the opt-in initial sort of bwt_msd.h (BZH_INIT=msd) is bit-exact against the oracle on blocks and streams that reach
-    every part of it (scripts/gpu_msd_check.py, a process of its own: the switch is read once per process)"""
+@pytest.mark.parametrize("init", ["msd", "lsd"])
+def test_both_initial_sorts(native, init):
+    """the bucket-first initial sort of bwt_msd.h (the default for text-like blocks) and the 8-pass sort forced on every
+    block (BZH_INIT=lsd) are both bit-exact against the oracle on blocks and streams that reach every part of them
+    (scripts/gpu_msd_check.py, a process of its own: the switch is read once per process)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_msd_check.py")], capture_output=True, text=True,
-                       timeout=900, env=dict(os.environ, BZH_INIT="msd"))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_msd_check.py"), init], capture_output=True, text=True,
+                       timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "mismatches: 0" in r.stdout
