@@ -92,6 +92,8 @@ __device__ __forceinline__ void tile_rank(const T (&v)[MS_ITEMS], int sh, uint32
             const uint32_t d = (uint32_t)(v[k] >> sh) & dmask;
             const u64 m0 = __ballot(act);
             uint32_t mlo = (uint32_t)m0, mhi = (uint32_t)(m0 >> 32);
+            // (tried: comparing only the bits that vary inside the tile -- text leaves two or three bits of a byte constant
+            // inside a bucket -- with a loop over the set bits of a mask: the loop costs more than the skipped rounds save)
 #pragma unroll
             for (int bit = 0; bit < NBITS; bit++) { // keep the lanes whose digit agrees with mine in this bit: m & ~(ballot ^ mine)
                 const int om = __builtin_amdgcn_sbfe((int)d, bit, 1);
@@ -817,7 +819,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
         for (int pass = 0; pass < 6; pass++) {
             const int sh = pass < 5 ? 13 + 8 * pass : 53;
             if (((vary >> sh) & 255ull) == 0ull) continue; // (the same for every thread)
-            tile_rank<8>(x, sh, actmask, R, cur[par], cur[par ^ 1], ls, pos); // (ONE call site: the kernel has to fit the instruction cache)
+            tile_rank<8>(x, sh, actmask, R, cur[par], cur[par ^ 1], ls, pos);
             par ^= 1;
             MS_T(1);
 #pragma unroll
@@ -907,14 +909,14 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
             }
             return (c << 30) | hp;
         };
+        uint32_t hg[MS_ITEMS]; // (computed once per element)
         uint32_t nS = 0, nB = 0;
 #pragma unroll
         for (int k = 0; k < MS_ITEMS; k++) {
-            if (e0 + k < len) {
-                const uint32_t c = class_head(k) >> 30;
-                nS += c == CLS_SMALL;
-                nB += c == CLS_BIG;
-            }
+            hg[k] = e0 + k < len ? class_head(k) : 0u;
+            const uint32_t c = hg[k] >> 30;
+            nS += (e0 + k < len && c == CLS_SMALL) ? 1u : 0u;
+            nB += (e0 + k < len && c == CLS_BIG) ? 1u : 0u;
         }
         uint32_t totS, totB, offS, offB;
         { // both compaction offsets in one scan: 16 bits each (a unit holds at most 8192 records)
@@ -948,7 +950,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
 #pragma unroll
             for (int k = 0; k < MS_ITEMS; k++) {
                 if (e0 + k < len) {
-                    const uint32_t ch = class_head(k), c = ch >> 30;
+                    const uint32_t ch = hg[k], c = ch >> 30;
                     const u64 rec = ((u64)(ch & 0xFFFFFu) << 40) | sf[k];
                     if (c == CLS_SMALL) stage[wS++] = rec;
                     if (c == CLS_BIG) stage[wB++] = rec;
@@ -987,7 +989,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
 #pragma unroll
         for (int k = 0; k < MS_ITEMS; k++) {
             if (e0 + k < len) {
-                const uint32_t ch = class_head(k), c = ch >> 30, head = ch & 0xFFFFFu;
+                const uint32_t ch = hg[k], c = ch >> 30, head = ch & 0xFFFFFu;
                 const uint32_t word = c == CLS_SINGLE ? (head | RANK_RESOLVED) : head;
                 stage[atomicAdd(&bcur[sf[k] >> 12], 1u)] = ((u64)word << 32) | sf[k];
             }
