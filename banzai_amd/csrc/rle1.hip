@@ -107,6 +107,23 @@ __device__ __forceinline__ uint32_t start_mask(const uint8_t *in, uint64_t n, ui
     return mask;
 }
 
+// Is one of the thread's `valid` bytes at p0 the 4th (or later) of equal bytes in a row?  `mask` = its run starts.
+// Byte q is such a byte iff bytes q-2, q-1 and q all do NOT start a run (the two flags before the thread's 16 come
+// from the 3 bytes before p0; p0 is a multiple of 16).  Text has few runs of four: a wavefront without one emits
+// every byte as one literal -- no run offsets modulo 255, no count bytes.
+__device__ __forceinline__ bool has_run_of_four(const uint8_t *in, uint64_t p0, uint32_t valid, uint32_t mask)
+{
+    uint32_t before = 0; // bit 1: byte p0-1 does not start a run, bit 0: byte p0-2 does not
+    if (valid && p0 >= 4) {
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(in + p0 - 4);
+        const uint32_t b1 = (w >> 8) & 255u, b2 = (w >> 16) & 255u, b3 = w >> 24;
+        before = (b3 == b2 ? 2u : 0u) | (b2 == b1 ? 1u : 0u);
+    }
+    const uint32_t vm = valid >= 16 ? 0xFFFFu : ((1u << valid) - 1u);
+    const uint32_t ext = ((~mask & vm) << 2) | before;
+    return (ext & (ext >> 1) & (ext >> 2)) != 0u;
+}
+
 // ---- plan sweep 1: first / last run start of every tile ------------------------------------------------
 __global__ void __launch_bounds__(RL_THREADS) plan_starts(PlanArrays pa)
 {
@@ -236,16 +253,19 @@ __global__ void __launch_bounds__(RL_THREADS) plan_granules(PlanArrays pa)
     const uint32_t rst = pa.lrs[tile]; // exclusive prefix max (NONE32 only for tile 0, whose byte 0 starts a run)
     const int carry = threadIdx.x ? exm[threadIdx.x - 1] : -1;
     const uint32_t rs_in = carry >= 0 ? (uint32_t)tile0 + (uint32_t)carry : rst;
-    uint32_t cur_rs = rs_in, tsum = 0;
+    uint32_t cur_rs = rs_in, tsum = valid; // (a wavefront without a run of four: one literal per byte)
+    if (__ballot(has_run_of_four(pa.in, p0, valid, mask)) != 0ull) {
+        tsum = 0;
 #pragma unroll
-    for (int k = 0; k < RL_ITEMS; k++) {
-        if ((uint32_t)k < valid) {
-            const uint32_t p = (uint32_t)p0 + k;
-            if (mask & (1u << k)) cur_rs = p;
-            const uint32_t byte = (v[k >> 2] >> ((k & 3) * 8)) & 255u;
-            const uint32_t nb = ((uint32_t)k + 1 < valid) ? ((v[((k + 1) & 15) >> 2] >> (((k + 1) & 3) * 8)) & 255u) : nextb;
-            const uint32_t kk = (p - cur_rs) % 255u;
-            tsum += (kk < 4u ? 1u : 0u) + ((kk >= 3u && (kk == 254u || nb != byte)) ? 1u : 0u);
+        for (int k = 0; k < RL_ITEMS; k++) {
+            if ((uint32_t)k < valid) {
+                const uint32_t p = (uint32_t)p0 + k;
+                if (mask & (1u << k)) cur_rs = p;
+                const uint32_t byte = (v[k >> 2] >> ((k & 3) * 8)) & 255u;
+                const uint32_t nb = ((uint32_t)k + 1 < valid) ? ((v[((k + 1) & 15) >> 2] >> (((k + 1) & 3) * 8)) & 255u) : nextb;
+                const uint32_t kk = (p - cur_rs) % 255u;
+                tsum += (kk < 4u ? 1u : 0u) + ((kk >= 3u && (kk == 254u || nb != byte)) ? 1u : 0u);
+            }
         }
     }
     uint32_t tot;
@@ -371,8 +391,54 @@ __device__ __forceinline__ uint32_t next_start_after(const PlanArrays &pa, uint3
     return pa.nrsg[g + 1 <= pa.ngran ? g + 1 : pa.ngran];
 }
 
-__global__ void __launch_bounds__(64) plan_split(PlanArrays pa)
+// The split is one chain of dependent table reads per block, by one wavefront that nothing else on the device keeps
+// company: the tables were written by other XCDs, so every read goes to memory.  A second wavefront runs ahead and
+// touches what the split is about to read -- for 64 blocks at a time, a lane each: a block ends where the canonical
+// RLE1 offset has grown by M (less the few bytes a cut gives away, which add up: the window reaches further back for
+// later blocks), so the tile comes from tc by a few secant steps and the granule from the offset inside the tile.
+// Nothing depends on what it reads; a wrong guess (long runs) just warms the wrong lines.
+__device__ void plan_prefetch(const PlanArrays &pa, uint32_t lane)
 {
+    const uint32_t NT = pa.ntiles, NG = pa.ngran, n = (uint32_t)pa.n;
+    if (NT == 0 || NG == 0 || pa.start >= n) return;
+    const uint64_t total = pa.tc[NT];
+    const uint32_t t0 = min(pa.start / RL_TILE, NT - 1u);
+    const uint64_t C0 = pa.tc[t0] + pa.cg[min(pa.start / GRAN, NG - 1u)];
+    uint32_t sink = 0;
+    for (uint32_t k0 = 0; k0 < pa.maxblocks && k0 < 8192u; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        const uint64_t target = C0 + (uint64_t)(k + 1u) * pa.M;
+        if (__ballot(target < total) == 0ull) break;
+        if (target >= total) continue;
+        const long long slope = (long long)(total / NT) + 1; // canonical bytes per tile, on average
+        long long g = (long long)t0 + (long long)(target - C0) / slope;
+#pragma unroll 1
+        for (int it = 0; it < 5; it++) { // (bounded: a guess that does not settle warms the wrong lines, nothing else)
+            g = g < 0 ? 0 : (g > (long long)NT - 1 ? (long long)NT - 1 : g);
+            const long long diff = (long long)target - (long long)pa.tc[g];
+            g += diff >= 0 ? diff / slope : -((-diff + slope - 1) / slope);
+        }
+        g = g < 0 ? 0 : (g > (long long)NT - 1 ? (long long)NT - 1 : g);
+        for (int it = 0; it < 3 && g > 0 && pa.tc[g] > target; it++) g--;
+        const uint64_t base = pa.tc[g];
+        sink ^= (uint32_t)pa.tc[g + 1];
+        const long long gc = g * (long long)GRAN_PER_TILE + (long long)((target > base ? target - base : 0) / GRAN);
+        long long lo = gc - 4 - (long long)(5u * (k + 1u) / GRAN + 2u), hi = gc + 3;
+        lo = lo < 0 ? 0 : lo;
+        hi = hi > (long long)NG - 1 ? (long long)NG - 1 : hi;
+        for (long long q = lo; q <= hi; q += 16) sink ^= pa.cg[q] ^ pa.rsg[q] ^ pa.nrsg[q];
+        sink ^= pa.cg[hi] ^ pa.rsg[hi] ^ pa.nrsg[hi];
+        for (uint64_t a = (uint64_t)lo * GRAN; a < ((uint64_t)hi + 1u) * GRAN && a < n; a += 64) sink ^= pa.in[a];
+    }
+    if (sink == 0x9E3779B9u && lane == 77u) pa.nblocks[1] = sink; // (never: keeps the loads alive)
+}
+
+__global__ void __launch_bounds__(128) plan_split(PlanArrays pa)
+{
+    if (threadIdx.x >= 64) {
+        plan_prefetch(pa, threadIdx.x - 64u);
+        return;
+    }
     const uint32_t lane = threadIdx.x;
     const uint32_t N = (uint32_t)pa.n, M = pa.M, NT = pa.ntiles;
     const uint64_t total = pa.tc[NT];
@@ -528,7 +594,7 @@ __device__ __forceinline__ uint32_t gf_pow_x(const CrcTables &ct, uint64_t e, ui
     return f;
 }
 
-// Workgroup x of block y takes the block's tiles x, x + gridDim.x, ...; `nbp` (optional) = number of valid blocks
+// Workgroup x of block y takes the x-th of gridDim.x equal ranges of the block's tiles; `nbp` (optional) = number of valid blocks
 // on the device (the plan launches this before the host knows how many blocks the split found).
 __global__ void __launch_bounds__(RL_THREADS) crc_tiles(const uint8_t *in, const BlockDesc *blocks, uint32_t *acc,
                                                          const CrcTables *ctp, const uint32_t *nbp)
@@ -536,20 +602,37 @@ __global__ void __launch_bounds__(RL_THREADS) crc_tiles(const uint8_t *in, const
     const uint32_t b = blockIdx.y;
     if (nbp && b >= *nbp) return;
     const BlockDesc d = blocks[b];
-    if ((uint64_t)blockIdx.x * CRC_TILE >= d.in_len) return;
+    if ((uint64_t)blockIdx.x * ((((d.in_len + CRC_TILE - 1) / CRC_TILE) + gridDim.x - 1) / gridDim.x) * CRC_TILE >= d.in_len) return;
     const CrcTables &ct = *ctp;
-    __shared__ uint32_t tab[256];
+    // slicing by four: tab[k][v] = CRC of byte v followed by k zero bytes, so four bytes cost one dependent step
+    // (four independent LDS lookups) instead of four
+    __shared__ uint32_t tab[4][256];
     {
         uint32_t c = threadIdx.x << 24;
 #pragma unroll
         for (int k = 0; k < 8; k++) c = (c << 1) ^ ((c >> 31) ? CRC_POLY : 0u);
-        tab[threadIdx.x] = c;
+        tab[0][threadIdx.x] = c;
     }
     __syncthreads();
+#pragma unroll 1
+    for (int k = 1; k < 4; k++) {
+        const uint32_t c = tab[k - 1][threadIdx.x];
+        tab[k][threadIdx.x] = (c << 8) ^ tab[0][c >> 24];
+        __syncthreads();
+    }
     const uint32_t lane = threadIdx.x & 63;
     __shared__ uint32_t wred[RL_THREADS / 64];
-    for (uint64_t t0 = (uint64_t)blockIdx.x * CRC_TILE; t0 < d.in_len; t0 += (uint64_t)gridDim.x * CRC_TILE) {
+    // this workgroup's tiles are adjacent: their CRCs fold into one value (acc * x^(8 * tile bytes) + tile), which is
+    // shifted to the block's end once -- one power of x and one atomic per workgroup, not per tile
+    const uint64_t ntile = (d.in_len + CRC_TILE - 1) / CRC_TILE;
+    const uint64_t per = (ntile + gridDim.x - 1) / gridDim.x;
+    const uint64_t tA = (uint64_t)blockIdx.x * per, tB = tA + per < ntile ? tA + per : ntile;
+    uint32_t acc_c = 0; // (wavefront 0)
+    uint64_t range_end = 0;
+    for (uint64_t t = tA; t < tB; t++) {
+    const uint64_t t0 = t * CRC_TILE;
     const uint32_t tile_len = d.in_len - t0 < CRC_TILE ? (uint32_t)(d.in_len - t0) : CRC_TILE;
+    range_end = t0 + tile_len;
     // pieces: a ragged first piece of r bytes (if any), then full 32-byte pieces, so that the bytes
     // after every piece are a multiple of 32
     const uint32_t r = tile_len % CRC_PIECE, np = tile_len / CRC_PIECE + (r ? 1u : 0u);
@@ -564,7 +647,17 @@ __global__ void __launch_bounds__(RL_THREADS) crc_tiles(const uint8_t *in, const
             len = CRC_PIECE;
         }
         const uint8_t *p = in + d.in_off + t0 + off;
-        for (uint32_t k = 0; k < len; k++) crc = (crc << 8) ^ tab[(crc >> 24) ^ p[k]];
+        if (len == CRC_PIECE) { // (gfx950 global loads need no alignment: two 16-byte loads of the piece)
+            uint32_t w[8];
+            __builtin_memcpy(w, p, 32);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const uint32_t x = crc ^ __builtin_bswap32(w[q]); // the stream's first byte is the polynomial's highest term
+                crc = tab[3][x >> 24] ^ tab[2][(x >> 16) & 255u] ^ tab[1][(x >> 8) & 255u] ^ tab[0][x & 255u];
+            }
+        } else {
+            for (uint32_t k = 0; k < len; k++) crc = (crc << 8) ^ tab[0][(crc >> 24) ^ p[k]];
+        }
         crc = gf_mul(crc, ct.shift[np - 1 - threadIdx.x]);
     }
 #pragma unroll
@@ -574,11 +667,15 @@ __global__ void __launch_bounds__(RL_THREADS) crc_tiles(const uint8_t *in, const
     if (threadIdx.x < 64) {
         uint32_t c = 0;
         for (int w = 0; w < RL_THREADS / 64; w++) c ^= wred[w];
-        const uint64_t after_tile = d.in_len - t0 - tile_len;
-        const uint32_t pw = gf_pow_x(ct, 8ull * after_tile, lane);
-        if (lane == 0) atomicXor(&acc[b], gf_mul(c, pw));
+        // x^(8 * tile_len): a constant for full tiles (8 * 8192 = 2^16), a power for the block's last, ragged one
+        const uint32_t xp = tile_len == CRC_TILE ? ct.pow2[16] : gf_pow_x(ct, 8ull * tile_len, lane);
+        acc_c = gf_mul(acc_c, xp) ^ c;
     }
     __syncthreads(); // wred is reused by the next tile
+    }
+    if (threadIdx.x < 64 && tB > tA) {
+        const uint32_t pw = gf_pow_x(ct, 8ull * (d.in_len - range_end), lane);
+        if (lane == 0) atomicXor(&acc[b], gf_mul(acc_c, pw));
     }
 }
 
@@ -694,19 +791,24 @@ __global__ void __launch_bounds__(RL_THREADS) rle1_emit_kernel(EmitArgs ea, Batc
     uint32_t cur_rs = rs_in;
     unsigned long long em = 0;
     uint32_t tsum = 0;
+    const bool wave_slow = __ballot(has_run_of_four(ea.in, p0, valid, mask)) != 0ull; // (else: literals only)
+    if (wave_slow) {
 #pragma unroll
-    for (int k = 0; k < RL_ITEMS; k++) {
-        if ((uint32_t)k < valid) {
-            const uint32_t p = (uint32_t)p0 + k;
-            if (mask & (1u << k)) cur_rs = p;
-            const uint32_t byte = (v[k >> 2] >> ((k & 3) * 8)) & 255u;
-            const uint32_t nb = ((uint32_t)k + 1 < valid) ? ((v[((k + 1) & 15) >> 2] >> (((k + 1) & 3) * 8)) & 255u) : nextb;
-            const bool is_last = nb != byte;
-            const uint32_t kk = (p - cur_rs) % 255u;
-            const uint32_t can = (kk < 4u ? 1u : 0u) + ((kk >= 3u && (kk == 254u || is_last)) ? 1u : 0u);
-            em |= (unsigned long long)(can | (is_last ? 4u : 0u)) << (4 * k);
-            tsum += can;
+        for (int k = 0; k < RL_ITEMS; k++) {
+            if ((uint32_t)k < valid) {
+                const uint32_t p = (uint32_t)p0 + k;
+                if (mask & (1u << k)) cur_rs = p;
+                const uint32_t byte = (v[k >> 2] >> ((k & 3) * 8)) & 255u;
+                const uint32_t nb = ((uint32_t)k + 1 < valid) ? ((v[((k + 1) & 15) >> 2] >> (((k + 1) & 3) * 8)) & 255u) : nextb;
+                const bool is_last = nb != byte;
+                const uint32_t kk = (p - cur_rs) % 255u;
+                const uint32_t can = (kk < 4u ? 1u : 0u) + ((kk >= 3u && (kk == 254u || is_last)) ? 1u : 0u);
+                em |= (unsigned long long)(can | (is_last ? 4u : 0u)) << (4 * k);
+                tsum += can;
+            }
         }
+    } else {
+        tsum = valid;
     }
     uint32_t tot;
     uint32_t ps = block_excl_add(tsum, ls, &tot); // canonical bytes of the tile before this thread
@@ -723,6 +825,21 @@ __global__ void __launch_bounds__(RL_THREADS) rle1_emit_kernel(EmitArgs ea, Batc
 
     uint32_t lastend = 0;
     cur_rs = rs_in;
+    if (!wave_slow) { // literals only: a byte's offset is its canonical offset, or its distance from the block's start inside the block's first run
+#pragma unroll
+        for (int k = 0; k < RL_ITEMS; k++) {
+            if ((uint32_t)k < valid) {
+                const uint32_t p = (uint32_t)p0 + k;
+                if (mask & (1u << k)) cur_rs = p;
+                if (p0 + k >= d.in_off && p0 + k < in_end) {
+                    const uint32_t off = cur_rs <= in_off32 ? p - in_off32 : A + (uint32_t)(tc + ps - Ce);
+                    stage[off - obase] = (uint8_t)((v[k >> 2] >> ((k & 3) * 8)) & 255u);
+                    lastend = off + 1u > lastend ? off + 1u : lastend;
+                }
+                ps += 1u;
+            }
+        }
+    } else
 #pragma unroll
     for (int k = 0; k < RL_ITEMS; k++) {
         if ((uint32_t)k < valid) {
@@ -887,7 +1004,7 @@ int rle1_plan_split(bzh_ctx *ctx, size_t start, bool with_crc, size_t stop)
     pa.stop = stop >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)stop;
     {
         KSpan ks(ctx, K_PLAN, 0, 1);
-        plan_split<<<dim3(1), 64, 0, st>>>(pa);
+        plan_split<<<dim3(1), 128, 0, st>>>(pa);
     }
     // The block CRCs are queued right behind the split, over as many blocks as there could be (the kernels read the
     // count on the device), and everything the host needs -- count, descriptors with their CRCs, cut status -- comes
@@ -899,7 +1016,7 @@ int rle1_plan_split(bzh_ctx *ctx, size_t start, bool with_crc, size_t stop)
         HIP_TRY(ctx, hipMemsetAsync(w.crcacc, 0, (size_t)pa.maxblocks * 4, st));
         for (uint32_t k0 = 0; k0 < pa.maxblocks; k0 += 32768) { // grid.y limit
             const uint32_t cnt = pa.maxblocks - k0 < 32768 ? pa.maxblocks - k0 : 32768;
-            crc_tiles<<<dim3(128, cnt), RL_THREADS, 0, st>>>(d_in, pa.blocks + k0, w.crcacc + k0, ct, pa.nblocks);
+            crc_tiles<<<dim3(16, cnt), RL_THREADS, 0, st>>>(d_in, pa.blocks + k0, w.crcacc + k0, ct, pa.nblocks);
         }
         crc_finish<<<dim3(pa.maxblocks), 64, 0, st>>>(pa.blocks, w.crcacc, 0, ct, pa.nblocks);
     }
@@ -950,7 +1067,7 @@ int rle1_plan_crc(bzh_ctx *ctx, size_t b0, size_t b1)
     const uint32_t ctiles = (uint32_t)((maxlen + CRC_TILE - 1) / CRC_TILE);
     for (uint32_t k0 = 0; k0 < nb; k0 += 32768) { // grid.y limit
         const uint32_t cnt = nb - k0 < 32768 ? nb - k0 : 32768;
-        crc_tiles<<<dim3(ctiles, cnt), RL_THREADS, 0, st>>>(ctx->plan_in, pa.blocks + b0 + k0, w.crcacc + b0 + k0, ct, nullptr);
+        crc_tiles<<<dim3((ctiles + 7) / 8, cnt), RL_THREADS, 0, st>>>(ctx->plan_in, pa.blocks + b0 + k0, w.crcacc + b0 + k0, ct, nullptr);
     }
     crc_finish<<<dim3(nb), 64, 0, st>>>(pa.blocks + b0, w.crcacc + b0, nb, ct, nullptr);
     std::vector<BlockDesc> hb(nb);
@@ -1001,7 +1118,7 @@ int crc_device(bzh_ctx *ctx, const uint8_t *d_in, size_t n, uint32_t *crc_out)
     HIP_TRY(ctx, hipMemcpyAsync(dd, &d, sizeof d, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemsetAsync(acc, 0, 4, st));
     const uint32_t ctiles = (uint32_t)((n + CRC_TILE - 1) / CRC_TILE);
-    if (ctiles) crc_tiles<<<dim3(ctiles, 1), RL_THREADS, 0, st>>>(d_in, dd, acc, ct, nullptr);
+    if (ctiles) crc_tiles<<<dim3((ctiles + 7) / 8, 1), RL_THREADS, 0, st>>>(d_in, dd, acc, ct, nullptr);
     crc_finish<<<dim3(1), 64, 0, st>>>(dd, acc, 1, ct, nullptr);
     HIP_TRY(ctx, hipMemcpyAsync(&d, dd, sizeof d, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, bzh_stream_wait(st));
