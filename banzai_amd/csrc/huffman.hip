@@ -149,7 +149,21 @@ __device__ __forceinline__ void heap_insert(HeapMem &h, uint32_t &len, uint32_t 
     HEAP_ORDER();
 }
 
-__device__ __forceinline__ void heap_extract(HeapMem &h, uint32_t &len, uint32_t &oid, uint32_t &opr, uint32_t lane) // :225-267
+// The lanes of a lane's ancestors inside the four levels heap_extract looks at (level 1 = lanes 0-1, 2 = 2-5,
+// 3 = 6-13, 4 = 14-29): a lane is on the path of preferred children iff it is preferred and every ancestor is.
+__device__ __forceinline__ uint64_t heap_ancestors(uint32_t lane)
+{
+    uint32_t l = lane < 2 ? 1u : lane < 6 ? 2u : lane < 14 ? 3u : 4u, o = lane - ((1u << l) - 2u);
+    uint64_t anc = 0;
+    while (l > 1u) {
+        o >>= 1;
+        l--;
+        anc |= 1ull << (((1u << l) - 2u) + o);
+    }
+    return lane < 30 ? anc : ~0ull; // (lanes 30..63 look at nothing and are never on the path)
+}
+
+__device__ __forceinline__ void heap_extract(HeapMem &h, uint32_t &len, uint32_t &oid, uint32_t &opr, uint32_t lane, uint64_t anc) // :225-267
 {
     const uint64_t lk = h.key[len];
     len--;
@@ -174,27 +188,19 @@ __device__ __forceinline__ void heap_extract(HeapMem &h, uint32_t &len, uint32_t
         const uint32_t spr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pr, 0xB1, 0xF, 0xF, false); // sibling: quad_perm [1,0,3,2]
         const bool chosen = (off & 1u) ? (pr < spr) : !(spr < pr);  // right child only if strictly smaller
         const bool cont = ex && !(lpr < pr);                        // the moved element passes this slot
-        const uint64_t cm = __ballot(chosen), gm = __ballot(cont);
-        // the path of preferred children, level by level (scalar)
-        const uint32_t a1 = (cm & 1ull) ? 0u : 1u;
-        const uint32_t l2 = 2u + 2u * a1, a2 = ((cm >> l2) & 1ull) ? l2 : l2 + 1u;
-        const uint32_t l3 = 6u + 2u * (a2 - 2u), a3 = ((cm >> l3) & 1ull) ? l3 : l3 + 1u;
-        const uint32_t l4 = 14u + 2u * (a3 - 6u), a4 = ((cm >> l4) & 1ull) ? l4 : l4 + 1u;
-        uint32_t d = 0;
-        uint64_t pm = 0; // path slots that rise one level
-        uint32_t nh = hole;
-        if ((gm >> a1) & 1ull) {
-            d = 1, pm |= 1ull << a1, nh = (hole << 1) + a1;
-            if ((gm >> a2) & 1ull) {
-                d = 2, pm |= 1ull << a2, nh = (hole << 2) + (a2 - 2u);
-                if ((gm >> a3) & 1ull) {
-                    d = 3, pm |= 1ull << a3, nh = (hole << 3) + (a3 - 6u);
-                    if ((gm >> a4) & 1ull) d = 4, pm |= 1ull << a4, nh = (hole << 4) + (a4 - 14u);
-                }
-            }
+        const uint64_t cm = __ballot(chosen);
+        const bool onpath = lane < 30 && chosen && (cm & anc) == anc; // one lane per level
+        const uint64_t pm = __ballot(onpath), gm = __ballot(onpath && cont);
+        // the element sinks while the path's slots let it pass: d levels (the path's lanes: level 1 in bits 0-1,
+        // 2 in 2-5, 3 in 6-13, 4 in 14-29)
+        const uint32_t g32 = (uint32_t)gm;
+        const uint32_t d = (g32 & 0x3u) ? ((g32 & 0x3Cu) ? ((g32 & 0x3FC0u) ? ((g32 & 0x3FFFC000u) ? 4u : 3u) : 2u) : 1u) : 0u;
+        if (onpath && lvl <= d) h.key[node >> 1] = k; // the passed slots rise one level
+        if (d) {
+            const uint32_t lm = d == 1u ? 0x3u : d == 2u ? 0x3Cu : d == 3u ? 0x3FC0u : 0x3FFFC000u;
+            const uint32_t pl = (uint32_t)__builtin_ctz((uint32_t)pm & lm); // the path's lane at level d
+            hole = (hole << d) + (pl - ((1u << d) - 2u));
         }
-        if ((pm >> lane) & 1ull) h.key[node >> 1] = k;
-        hole = nh;
         HEAP_ORDER();
         if (d < 4) break;
     }
@@ -207,11 +213,12 @@ __device__ __forceinline__ void heap_extract(HeapMem &h, uint32_t &len, uint32_t
 __device__ int build_attempt(HeapMem &h, uint32_t nsyms, uint32_t sh, uint32_t lane, uint32_t (&dep)[(HUF_SYMS + 63) / 64])
 {
     uint32_t nnodes = nsyms + 1, len = 0;
+    const uint64_t anc = heap_ancestors(lane);
     for (uint32_t s = 0; s < nsyms; s++) heap_insert(h, len, s + 1, ((h.fr[s] >> sh) + 1u) << 8, lane);
     for (;;) {
         uint32_t a, c, pa, pc;
-        heap_extract(h, len, a, pa, lane);
-        heap_extract(h, len, c, pc, lane);
+        heap_extract(h, len, a, pa, lane, anc);
+        heap_extract(h, len, c, pc, lane, anc);
         if (nnodes == 2 * nsyms - 1) { // Tree::tie :60-74 -- last tie hangs off the root (id 0)
             if (lane == 0) {
                 h.par[a] = 0;
@@ -277,7 +284,7 @@ __device__ void build_lengths(HeapMem &h, uint32_t nsyms, uint8_t *out, uint32_t
 // sequential loop ends with, in the time of one build instead of up to four (blocks with skewed 258-symbol
 // alphabets need two or three).  Should none fit, the loop carries on from scaling 16.  All lanes of a wavefront work
 // in lock step; the heaps live in LDS.
-constexpr int HB_TRIES = 4;
+constexpr int HB_TRIES = 4; // (measured on the headline: 1 try 991 us, 2 tries 805 us, 4 tries 424 us -- one build takes ~420 us)
 __global__ void __launch_bounds__(64 * 3 * HB_TRIES) huff_build(Batch bt)
 {
     const uint32_t b = blockIdx.x;
