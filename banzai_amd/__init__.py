@@ -41,6 +41,26 @@ def encode(reader, writer, level, device=0):
     # incremental ingestion (the reference pulls from fill_buf as it goes, lib/rle.rs:30-92): input is
     # handed to the GPU in chunks, finished stream bytes are written as soon as they are final
     ctx.stream_begin()
+    # An in-memory reader (io.BytesIO) lends its buffer, as BufRead::fill_buf lends the reference a slice of the
+    # reader's own buffer (lib/rle.rs:30-92): the chunks go to the GPU from where they lie, no copy on this side.
+    if isinstance(reader, io.BytesIO):
+        view = reader.getbuffer()
+        try:
+            pos, end = reader.tell(), len(view)
+            while True:
+                k = min(READ_CHUNK, end - pos)
+                out = ctx.stream_feed_view(view[pos:pos + k], k == 0)
+                pos += k
+                if len(out):
+                    writer.write(out)
+                if k == 0:
+                    break
+        finally:
+            view.release()
+        reader.seek(pos)
+        if hasattr(writer, "flush"):
+            writer.flush()
+        return ctx.stream_consumed()
     # one reusable buffer: a reader with readinto() fills it in place (no bytes object per chunk); finished stream
     # bytes go to the writer as a view of the context's output buffer (no copy on this side either)
     buf = bytearray(READ_CHUNK) if hasattr(reader, "readinto") else None

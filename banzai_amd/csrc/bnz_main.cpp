@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cerrno>
 #include <cstring>
+#include <memory>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -151,19 +153,27 @@ int main(int argc, char **argv)
     st = bzh_stream_begin(ctx);
     if (st != BZH_OK) fail(bzh_strerror(st));
     const size_t CHUNK = (size_t)16 << 20;
-    std::vector<uint8_t> in(CHUNK), out;
+    // plain arrays, not vectors: the output bound is a worst case of a few hundred megabytes of which a feed fills a
+    // fraction -- value-initialising it (and copying it when it grows) cost more than encoding a 100 MB file
+    std::unique_ptr<uint8_t[]> in(new uint8_t[CHUNK]), out;
+    size_t out_cap = 0;
     for (bool eof = false; !eof;) {
-        const size_t k = fread(in.data(), 1, CHUNK, inf);
+        const size_t k = fread(in.get(), 1, CHUNK, inf);
         if (k < CHUNK) {
             if (ferror(inf)) fail("read failed");
             eof = true;
         }
         const size_t cap = bzh_stream_bound(ctx, k); // depends on what is pending and in flight: ask every time
-        if (out.size() < cap) out.resize(cap);
+        if (out_cap < cap) {
+            out.reset(); // (nothing in it is still needed)
+            out_cap = cap + cap / 2;
+            out.reset(new (std::nothrow) uint8_t[out_cap]);
+            if (!out) fail("out of memory");
+        }
         size_t got = 0;
-        st = bzh_stream_feed(ctx, in.data(), k, eof ? 1 : 0, out.data(), out.size(), &got);
+        st = bzh_stream_feed(ctx, in.get(), k, eof ? 1 : 0, out.get(), out_cap, &got);
         if (st != BZH_OK) fail(std::string(bzh_strerror(st)) + ": " + bzh_last_error(ctx));
-        if (got && fwrite(out.data(), 1, got, outf) != got) fail("write failed");
+        if (got && fwrite(out.get(), 1, got, outf) != got) fail("write failed");
     }
     bzh_destroy(ctx);
     if (!in_stdin) fclose(inf);

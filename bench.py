@@ -394,21 +394,9 @@ def main():
             if pool is not None:
                 pool.shutdown()
 
-        # roofline of the dominant kernel class (radix_scatter): algorithmic bytes / HIP-event time, per launch
-        achieved = (SORT_BYTES_PER_ELEM * sort_elems / (sort_ms * 1e-3) / 1e9) if sort_ms > 0 else None
-        # HBM bytes per launch from the committed PMC passes of this same command (FETCH_SIZE / WRITE_SIZE in
-        # separate rocprofv3 runs, corrected as MI355X_MICROARCH.md prescribes); null if not collected
-        traffic = None
-        traffic_source = None
-        try:
-            pmc = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_pmc_traffic.json"))
-            if pmc and world == 1 and seg_bytes == SEGMENT:
-                with open(os.path.join(ROOT, "profiles", pmc[-1])) as f:
-                    traffic = round(json.load(f)["radix_scatter_all"]["hbm_bytes_per_launch"])
-                traffic_source = (f"profiles/{pmc[-1]}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this "
-                                  "command, NOT measured in this run")
-        except Exception:
-            traffic = None
+        # every radix_scatter launch together (the figure rounds 1-3 quoted as the dominant kernel): algorithmic bytes /
+        # HIP-event time
+        achieved_rs = (SORT_BYTES_PER_ELEM * sort_elems / (sort_ms * 1e-3) / 1e9) if sort_ms > 0 else None
         # per-kernel-class roofline: HIP-event time of the class's launches in the profiled pass, algorithmic bytes
         # by DESIGN.md section 4's per-element figures; the six classes that took the most time
         ktable = []
@@ -421,7 +409,33 @@ def main():
                            "alg_bytes_per_step": round(v["alg_bytes"] / args.steps),
                            "achieved_GBs": round(gbs, 1) if gbs else None,
                            "frac": round(gbs / HBM_PEAK_GBS, 4) if gbs else None})
-        ktable = ktable[:8]
+        # the DOMINANT kernel class = the one that took the most time in the profiled pass.  Since the bucket-first initial
+        # sort is the default for text that is chunk_finish -- one launch per step that sorts every bucket inside LDS; its
+        # algorithmic HBM bytes are 8 in + 8 out per suffix + 8 per list record, its bound is LDS / issue, not HBM (the
+        # point of it: the passes it replaces moved 8x the bytes) -- so `frac` against the HBM peak is small by design.
+        # HBM bytes per launch from the committed PMC passes of this same command (FETCH_SIZE / WRITE_SIZE in separate
+        # rocprofv3 runs, corrected as MI355X_MICROARCH.md prescribes); null if not collected
+        dom = ktable[0] if ktable else None
+        dom_launches = dom["launches_per_step"] if dom else 0
+        dom_us = (dom["us_per_step"] / dom_launches) if dom and dom_launches else None
+        dom_bytes = (dom["alg_bytes_per_step"] / dom_launches) if dom and dom_launches else None
+        dom_key = dom["kernel"].split(" ")[0].split("<")[0] if dom else ""
+        traffic = None
+        traffic_source = None
+        try:
+            pmc = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_pmc_traffic.json"))
+            if pmc and world == 1 and seg_bytes == SEGMENT and dom_key:
+                with open(os.path.join(ROOT, "profiles", pmc[-1])) as f:
+                    pk = json.load(f)["kernels"]
+                hit = [v for k, v in pk.items() if k.startswith(dom_key)]
+                nl = sum(v["launches"] for v in hit)
+                if nl:
+                    traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hit) / nl)
+                    traffic_source = (f"profiles/{pmc[-1]}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this "
+                                      f"command (kernels named {dom_key}*), NOT measured in this run")
+        except Exception:
+            traffic = None
+        ktable = ktable[:10]
         path_gbs = alg / (ms_per_step * 1e-3) / 1e9
         result = {
             "metric": "encode MB/s (input) at level 9, enwik8, 1/2/4/8 MI355X; bit-exact vs CPU",
@@ -435,12 +449,20 @@ def main():
                        "blocks_on_rank0": int(nblocks),
                        "parallelism": f"block-sharded x{world}",
                        "input_resident_on_rank0": int(resident)},
-            "roofline": {"bound": "hbm", "kernel": "radix_scatter", "achieved": round(achieved, 1) if achieved else None,
+            "roofline": {"bound": "hbm", "kernel": dom["kernel"] if dom else None,
+                         "achieved": dom["achieved_GBs"] if dom else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
+                         "frac": dom["frac"] if dom else None, "traffic": traffic,
                          "traffic_source": traffic_source, "kernels": ktable,
-                         "launches": int(sort_launches), "avg_launch_us": round(sort_ms * 1e3 / max(1, sort_launches), 2),
-                         "alg_bytes_per_launch": round(SORT_BYTES_PER_ELEM * sort_elems / max(1, sort_launches)),
+                         "launches": int(round(dom_launches * args.steps)) if dom else 0,
+                         "avg_launch_us": round(dom_us, 2) if dom_us else None,
+                         "alg_bytes_per_launch": round(dom_bytes) if dom_bytes else None,
+                         "limited_by": "LDS / instruction issue (an in-LDS sort: HBM sees one read and one write of every "
+                                       "suffix)" if dom_key == "chunk_finish" else None,
+                         "radix_scatter_all": {"achieved": round(achieved_rs, 1) if achieved_rs else None,
+                                               "frac": round(achieved_rs / HBM_PEAK_GBS, 4) if achieved_rs else None,
+                                               "launches": int(sort_launches),
+                                               "avg_launch_us": round(sort_ms * 1e3 / max(1, sort_launches), 2)},
                          "measured_in": "untimed second pass of the same K steps with profiling on "
                                         f"({round(ms_profiled, 3)} ms per step there)",
                          # the whole path by SURVEY 8(d)'s fixed accounting, over the TIMED region (all ranks)

@@ -25,18 +25,20 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 scripts/pmc_summary.py "$OUT" "$TAG" > "$OUT/${TAG}_pmc_traffic.json"
 rm -rf "$OUT/prof" "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE
-# ---- round 4: the opt-in bucket-first initial sort next to the default (same box, same command), its kernel table and
-# the cycles per phase of chunk_finish; the CLI's wall clock; the streaming API's trigger sweep
-python3 bench.py --no-extra --no-cpu --steps 10 > "$OUT/msd_lsd_line.json" 2>/dev/null
-BZH_INIT=msd python3 bench.py --no-extra --no-cpu --steps 10 > "$OUT/msd_msd_line.json" 2>/dev/null
-export BZH_INIT=msd
-rocprofv3 --kernel-trace --stats -d "$OUT/prof_msd" --output-format csv -- python3 bench.py --no-extra --no-cpu --steps 3 > /dev/null 2> "$OUT/prof_msd.err"
-unset BZH_INIT
-cp "$(ls "$OUT"/prof_msd/*/*kernel_stats.csv | head -1)" "$OUT/${TAG}_kernel_stats_msd.csv"
-rm -rf "$OUT/prof_msd"
-BZH_INIT=msd BZH_MSD_DBG=16 BZH_TRACE_ROUNDS=1 python3 scripts/gpu_one.py enwik 2 2> "$OUT/msd_trace.txt" > /dev/null
+# ---- round 4: the bucket-first initial sort (default for text since round 4) next to the 8 radix passes it replaces
+# (BZH_INIT=lsd; same box, same command), the kernel table of the 8-pass run and the cycles per phase of chunk_finish;
+# the CLI's wall clock; the streaming API's trigger sweep; two half-batch lanes against one
+python3 bench.py --no-extra --no-cpu --steps 10 > "$OUT/msd_msd_line.json" 2>/dev/null
+BZH_INIT=lsd python3 bench.py --no-extra --no-cpu --steps 10 > "$OUT/msd_lsd_line.json" 2>/dev/null
+export BZH_INIT=lsd BZH_NO_OVERLAP=1
+rocprofv3 --kernel-trace --stats -d "$OUT/prof_lsd" --output-format csv -- python3 bench.py --no-extra --no-cpu --steps 3 > /dev/null 2> "$OUT/prof_lsd.err"
+unset BZH_INIT BZH_NO_OVERLAP
+cp "$(ls "$OUT"/prof_lsd/*/*kernel_stats.csv | head -1)" "$OUT/${TAG}_kernel_stats_lsd.csv"
+rm -rf "$OUT/prof_lsd"
+BZH_MSD_DBG=16 BZH_TRACE_ROUNDS=1 python3 scripts/gpu_one.py enwik 2 2> "$OUT/msd_trace.txt" > /dev/null
 python3 scripts/msd_ablation.py "$OUT" "$TAG" > "$OUT/${TAG}_msd_ablation.json"
 python3 scripts/cli_wallclock.py "$OUT/${TAG}_cli_wallclock.json" > /dev/null 2>&1
 python3 scripts/gpu_stream_sweep.py > "$OUT/${TAG}_stream_api_sweep.txt" 2>&1
 python3 scripts/gpu_lanes.py > "$OUT/${TAG}_lanes.txt" 2>&1
+rm -f "$OUT"/pmc_*.log "$OUT"/*.err
 ls -la "$OUT"

@@ -1,6 +1,7 @@
-"""profiles/<tag>_msd_ablation.json: the bucket-first initial sort (BZH_INIT=msd) against the default 8-pass sort on the
-bench workload -- both bench lines of ONE box, the kernel table of the msd run (rocprofv3), the plan's unit / level
-counts and chunk_finish's cycles per phase (BZH_MSD_DBG=16).  argv: directory of scripts/collect_profiles.sh, tag"""
+"""profiles/<tag>_msd_ablation.json: the bucket-first initial sort (the default for text) against the 8 radix passes it
+replaces (BZH_INIT=lsd) on the bench workload -- both bench lines of ONE box, the rocprofv3 kernel tables of both runs (the
+bucket-first one is <tag>_kernel_stats_bench_n1.csv), the plan's unit / level counts and chunk_finish's cycles per phase
+(BZH_MSD_DBG=16).  argv: directory of scripts/collect_profiles.sh, tag"""
 import csv, json, os, re, sys
 d, tag = sys.argv[1], sys.argv[2]
 
@@ -11,14 +12,18 @@ def line(name):
 
 lsd, msd = line("msd_lsd_line.json"), line("msd_msd_line.json")
 doc = {"workload": lsd["config"]["workload"],
-       "default_8_pass": {k: lsd[k] for k in ("value", "ms_per_step", "stage_ms_per_step", "bwt_rounds", "A_over_n")},
+       "eight_radix_passes": {k: lsd[k] for k in ("value", "ms_per_step", "stage_ms_per_step", "bwt_rounds", "A_over_n")},
        "bucket_first": {k: msd[k] for k in ("value", "ms_per_step", "stage_ms_per_step", "bwt_rounds", "A_over_n")},
-       "default_kernels_us_per_step": {k["kernel"]: k["us_per_step"] for k in lsd["roofline"]["kernels"]},
+       "eight_radix_passes_kernels_us_per_step": {k["kernel"]: k["us_per_step"] for k in lsd["roofline"]["kernels"]},
        "bucket_first_kernels_us_per_step": {k["kernel"]: k["us_per_step"] for k in msd["roofline"]["kernels"]}}
-rows = list(csv.DictReader(open(os.path.join(d, f"{tag}_kernel_stats_msd.csv"))))
+rows = list(csv.DictReader(open(os.path.join(d, f"{tag}_kernel_stats_bench_n1.csv"))))
 want = ("bigram_hist", "bigram_plan", "bigram_scatter", "seg_count", "seg_plan", "seg_scatter", "chunk_finish", "rank_apply")
 doc["rocprofv3_avg_us"] = {r["Name"].split("(")[0]: {"calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 1)}
                            for r in rows if r["Name"].startswith(want)}
+rows = list(csv.DictReader(open(os.path.join(d, f"{tag}_kernel_stats_lsd.csv"))))
+want = ("void radix_scatter<8, 0>", "void radix_scatter<8, 2>", "void radix_scatter<8, 3>", "void refine_one<true>", "rank_apply", "byte_count")
+doc["rocprofv3_avg_us_eight_radix_passes"] = {r["Name"].split("(")[0].replace("void ", ""): {"calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 1)}
+                                              for r in rows if r["Name"].startswith(want)}
 tr = open(os.path.join(d, "msd_trace.txt")).read()
 m = re.findall(r"initial sort: (\d+) blocks bucket-first, (\d+) blocks 8-pass; (\d+) units; oversized buckets per level (\d+) (\d+) (\d+) (\d+) (\d+) \(tiles (\d+) (\d+) (\d+) (\d+) (\d+)\)", tr)
 if m:
