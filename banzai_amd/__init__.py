@@ -44,19 +44,18 @@ def encode(reader, writer, level, device=0):
     # An in-memory reader (io.BytesIO) lends its buffer, as BufRead::fill_buf lends the reference a slice of the
     # reader's own buffer (lib/rle.rs:30-92): the chunks go to the GPU from where they lie, no copy on this side.
     if isinstance(reader, io.BytesIO):
-        view = reader.getbuffer()
-        try:
-            pos, end = reader.tell(), len(view)
-            while True:
-                k = min(READ_CHUNK, end - pos)
-                out = ctx.stream_feed_view(view[pos:pos + k], k == 0)
-                pos += k
-                if len(out):
-                    writer.write(out)
-                if k == 0:
-                    break
-        finally:
-            view.release()
+        # (getvalue() hands out the bytes object BytesIO holds -- no copy for a reader made from bytes; getbuffer()
+        # would first un-share it, i.e. copy all of it)
+        view = memoryview(reader.getvalue())
+        pos, end = reader.tell(), len(view)
+        while True:
+            k = min(READ_CHUNK, max(0, end - pos))
+            out = ctx.stream_feed_view(view[pos:pos + k], k == 0)
+            pos += k
+            if len(out):
+                writer.write(out)
+            if k == 0:
+                break
         reader.seek(pos)
         if hasattr(writer, "flush"):
             writer.flush()
