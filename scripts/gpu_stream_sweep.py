@@ -1,4 +1,4 @@
-"""Streaming API (bzh_stream_feed) on the bench workload: trigger size sweep, C ABI and the Python facade."""
+"""Streaming API (bzh_stream_feed) on the bench workload: trigger size sweep through the C ABI."""
 import sys, os, time, ctypes, io
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -31,11 +31,4 @@ for chunk_mb in (0, 16, 24, 32, 48, 64):
         else:
             best = dt if best is None or dt < best else best
     print("C ABI, trigger %s MiB, 16 MiB feeds: %.2f ms = %.0f MB/s" % (chunk_mb or "default", best * 1e3, n / best / 1e6), flush=True)
-one = ctx.encode(data.tobytes()) if False else None
-raw = data.tobytes()
-for it in range(3):
-    out = io.BytesIO()
-    t = time.perf_counter()
-    used = banzai_amd.encode(io.BytesIO(raw), out, 9)
-    dt = time.perf_counter() - t
-    print("banzai_amd.encode(BytesIO, BytesIO, 9): %.2f ms = %.0f MB/s  same stream: %s" % (dt * 1e3, n / dt / 1e6, out.getvalue() == ref), flush=True)
+# (banzai_amd.encode over BytesIO is timed by bench.py: value_stream_api.python_encode)
