@@ -882,3 +882,22 @@ def test_both_initial_sorts(native, init):
                        timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "mismatches: 0" in r.stdout
+
+
+@pytest.mark.gpu
+def test_coverage_guided_corpus(oracle, native):
+    """the corpus a coverage-guided fuzzing session of the CPU oracle left (tests/golden/fuzz_corpus.zip, oracle/covfuzz.c)
+    through the HIP path: every stream equal to the oracle's, bit for bit, at the level the input names"""
+    import zipfile
+    with zipfile.ZipFile(os.path.join(os.path.dirname(__file__), "golden", "fuzz_corpus.zip")) as z:
+        items = [(n, z.read(n)) for n in sorted(z.namelist())]
+    ctxs = {}
+    try:
+        for name, blob in items:
+            level, data = 1 + blob[0] % 9, blob[1:]
+            if level not in ctxs:
+                ctxs[level] = native.Context(0, level, 8)
+            assert ctxs[level].encode(data) == oracle.encode(data, level), (name, level, len(data))
+    finally:
+        for c in ctxs.values():
+            c.close()

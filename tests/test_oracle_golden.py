@@ -165,3 +165,35 @@ def test_oracle_round_trips_under_sanitizers():
     r = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "-s", "san"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "300 round trips clean" in r.stdout
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _fuzz_corpus():
+    import zipfile
+    with zipfile.ZipFile(os.path.join(ROOT, "tests", "golden", "fuzz_corpus.zip")) as z:
+        return [(n, z.read(n)) for n in sorted(z.namelist())]
+
+
+def test_coverage_guided_corpus_round_trips_and_agrees_with_the_second_model(oracle):
+    """the minimised corpus of the coverage-guided fuzzing session of the oracle (oracle/covfuzz.c, scripts/covfuzz.sh;
+    the reference fuzzes the same property with libFuzzer, fuzz/fuzz_targets/round_trip.rs:8-22): every input round-trips
+    through the strict decoder and libbz2, the small ones also give the same stream in the independent Python model"""
+    import bz2
+    import json
+    from tests.golden import pymodel
+    rec = json.load(open(os.path.join(ROOT, "tests", "golden", "fuzz_corpus.json")))
+    items = _fuzz_corpus()
+    assert len(items) == rec["kept_inputs"] >= 100 and rec["round_trip_failures"] == 0 and rec["executions"] >= 100_000
+    levels, modelled = set(), 0
+    for name, blob in items:
+        level, data = 1 + blob[0] % 9, blob[1:]
+        levels.add(level)
+        stream = oracle.encode(data, level)
+        assert oracle.decode(stream, cap=len(data) + 64) == data, name
+        assert bz2.decompress(stream) == data, name
+        if len(data) <= 1500:
+            assert pymodel.encode(data, level) == stream, name
+            modelled += 1
+    assert levels == set(range(1, 10)) and modelled >= 30
