@@ -506,18 +506,38 @@ __global__ void __launch_bounds__(MS_THREADS, 4) bigram_scatter(Msd m, uint32_t 
     }
     uint32_t *cursor = m.bgcur + (size_t)b * MS_BG;
     u64 *dst = m.bufX + (size_t)b * m.S;
-#pragma unroll 2
+    // A global atomic returns after one to two microseconds: the claims of all 16 rows are issued first, consumed after
+    // (a row's claim: one atomic add per run of equal bigrams, by the run's first lane).
+    uint32_t its[MS_ITEMS], basev[MS_ITEMS];
+    uint32_t hd[MS_ITEMS / 4]; // the lane of my run's head, 8 bits a row
+#pragma unroll
+    for (int k = 0; k < MS_ITEMS / 4; k++) hd[k] = 0;
+#pragma unroll
     for (int k = 0; k < MS_ITEMS; k++) {
         const uint32_t p = wave * (MS_ITEMS * 64) + k * 64 + lane;
         const bool act = p < valid;
-        if (__ballot(act) == 0) break; // (the valid positions are a prefix of the tile)
-        const uint32_t it = act ? stage[p] : 0u;
-        const uint32_t bg = it >> 13;
+        its[k] = act ? stage[p] : 0u;
+        basev[k] = 0;
+        const uint32_t bg = its[k] >> 13;
         const uint32_t pb = (uint32_t)__shfl_up((int)bg, 1, 64);
         const bool head = act && (lane == 0 || bg != pb);
-        const uint32_t d = row_claim(act, head, cursor + bg, lane);
+        const u64 hm = __ballot(head), am = __ballot(act);
+        if (am == 0ull) continue; // (the valid positions are a prefix of the tile)
+        const u64 upto = (2ull << lane) - 1ull; // bits 0..lane (lane 63: all)
+        const u64 below = hm & upto, above = hm & ~upto;
+        const int myhead = below ? 63 - __clzll((long long)below) : 0;
+        const int nexth = above ? __ffsll((long long)above) - 1 : (int)__popcll(am);
+        hd[k >> 2] |= (uint32_t)myhead << (8 * (k & 3));
+        if (act && head) basev[k] = atomicAdd(cursor + bg, (uint32_t)(nexth - lane));
+    }
+#pragma unroll
+    for (int k = 0; k < MS_ITEMS; k++) {
+        const uint32_t p = wave * (MS_ITEMS * 64) + k * 64 + lane;
+        const bool act = p < valid;
+        const int myhead = (int)((hd[k >> 2] >> (8 * (k & 3))) & 255u);
+        const uint32_t d = (uint32_t)__shfl((int)basev[k], myhead, 64) + (uint32_t)(lane - myhead);
         if (act) {
-            const uint32_t off = it & 8191u, a = off + 2u;
+            const uint32_t off = its[k] & 8191u, a = off + 2u;
             const u64 w = ((u64)txt[(a >> 2) + 1] << 32) | txt[a >> 2];
             const u64 x = w >> (8u * (a & 3u)); // byte 2 of the rotation lowest
             const u64 key40 = __builtin_bswap64(x << 24) & 0xFFFFFFFFFFull;
