@@ -2137,8 +2137,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         if (getenv("BZH_TRACE_ROUNDS")) { // (debugging aid: waits for the device)
             uint32_t c[MS_CNT_WORDS];
             if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(c, bt.ms_cnt, sizeof c, hipMemcpyDeviceToHost) == hipSuccess)
-                fprintf(stderr, "[bzhip] initial sort: %u blocks bucket-first, %u blocks 8-pass; %u units; oversized buckets per level %u %u %u %u %u (tiles %u %u %u %u %u)\n",
-                        c[MC_NEW], c[MC_OLD], c[MC_UNITS], c[MC_SEGS + 1], c[MC_SEGS + 2], c[MC_SEGS + 3], c[MC_SEGS + 4], c[MC_SEGS + 5],
+                fprintf(stderr, "[bzhip] initial sort: %u blocks bucket-first, %u blocks 8-pass; %u units; %.1f %% of the suffixes in oversized 2-byte buckets; oversized buckets per level %u %u %u %u %u (tiles %u %u %u %u %u)\n",
+                        c[MC_NEW], c[MC_OLD], c[MC_UNITS], 100.0 * 1024.0 * c[23] / (double)std::max<uint64_t>(1, ntotal), c[MC_SEGS + 1], c[MC_SEGS + 2], c[MC_SEGS + 3], c[MC_SEGS + 4], c[MC_SEGS + 5],
                         c[MC_ITEMS + 1], c[MC_ITEMS + 2], c[MC_ITEMS + 3], c[MC_ITEMS + 4], c[MC_ITEMS + 5]);
             if (c[24] | c[27])
                 fprintf(stderr, "[bzhip] chunk_finish, 16-cycle ticks over all workgroups: ticket+load+bucket index %u, ranking %u, stage scatter+barrier %u, reload %u, boundaries+classes %u, suffixes+bins %u, lists out %u, ranks out %u\n",

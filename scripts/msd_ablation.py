@@ -25,10 +25,11 @@ want = ("void radix_scatter<8, 0>", "void radix_scatter<8, 2>", "void radix_scat
 doc["rocprofv3_avg_us_eight_radix_passes"] = {r["Name"].split("(")[0].replace("void ", ""): {"calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 1)}
                                               for r in rows if r["Name"].startswith(want)}
 tr = open(os.path.join(d, "msd_trace.txt")).read()
-m = re.findall(r"initial sort: (\d+) blocks bucket-first, (\d+) blocks 8-pass; (\d+) units; oversized buckets per level (\d+) (\d+) (\d+) (\d+) (\d+) \(tiles (\d+) (\d+) (\d+) (\d+) (\d+)\)", tr)
+m = re.findall(r"initial sort: (\d+) blocks bucket-first, (\d+) blocks 8-pass; (\d+) units; ([0-9.]+) % of the suffixes in oversized 2-byte buckets; oversized buckets per level (\d+) (\d+) (\d+) (\d+) (\d+) \(tiles (\d+) (\d+) (\d+) (\d+) (\d+)\)", tr)
 if m:
-    v = [int(x) for x in m[-1]]
-    doc["plan"] = {"blocks_bucket_first": v[0], "blocks_8_pass": v[1], "units": v[2], "oversized_buckets_per_level": v[3:8],
+    v = [int(x) for x in m[-1][:3]] + [int(x) for x in m[-1][4:]]
+    doc["plan"] = {"blocks_bucket_first": v[0], "blocks_8_pass": v[1], "units": v[2],
+                   "pct_of_suffixes_in_oversized_2_byte_buckets": float(m[-1][3]), "oversized_buckets_per_level": v[3:8],
                    "oversized_tiles_per_level": v[8:13]}
 m = re.findall(r"chunk_finish, 16-cycle ticks over all workgroups: (.*)", tr)
 if m:
