@@ -1790,7 +1790,7 @@ __global__ void __launch_bounds__(1024) period_probe(ProbeArgs a)
 constexpr uint32_t QUAD_BIT = 0x80000000u; // in st_ntail-derived gates: this round runs at depth x4
 enum ListId : int { L_S = 0, L_A = 1, L_R = 2, L_T = 3, L_Q = 4, L_P = 5 };
 
-__global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32_t round, uint32_t *actP, uint32_t *hsum, uint32_t seq)
+__global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32_t round, uint32_t *actP, uint32_t *hsum, uint32_t seq, uint32_t sweep_div)
 {
     const uint32_t b = threadIdx.x;
     const bool valid = b < B;
@@ -1804,12 +1804,12 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
         const uint32_t groups = bt.c_groups[b], mode_in = bt.st_mode[b], h_in = bt.st_h[b];
         const uint32_t nbig = bt.c_big[b], ntail = bt.c_tail[b] + bt.c_small[b];
         const uint32_t gR = bt.gateR[b], gTin = bt.gateT[b], prog = bt.c_prog[b], nolist = bt.c_nolist[b];
-        // Round 0: with fewer than one group per 8 suffixes after the 8-byte sort the block is run-heavy / periodic
-        // and starts in SWEEP mode; text-like blocks start in SPLIT mode and never pay for SA order by position.
+        // Round 0: with fewer than one group per `sweep_div` (256) suffixes after the 8-byte sort the block is run-heavy /
+        // periodic and starts in SWEEP mode; text-like blocks start in SPLIT mode and never pay for SA order by position.
         // (a block that took the bucket-first initial sort -- bwt_msd.h -- has no SA order by position: SPLIT mode, and
         // its rotations are ordered by their first 7 bytes, not 8)
         const bool msd = round == 0 && bt.ms_np[b] != 0u;
-        uint32_t mode = round == 0 ? ((!msd && (uint64_t)groups * 8u < n) ? 0u : 1u) : mode_in;
+        uint32_t mode = round == 0 ? ((!msd && (uint64_t)groups * sweep_div < n) ? 0u : 1u) : mode_in;
         h = round == 0 ? (msd ? 7u : 8u) : h_in; // the initial sort ordered the rotations by their first 8 (7) bytes
         if (round > 0 && (gR | gTin)) { // the block had work in the round before
             const bool wasquad = (gTin & QUAD_BIT) != 0;
@@ -2280,6 +2280,12 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         return hipSuccess;
     };
     static const bool trace = getenv("BZH_TRACE_ROUNDS") != nullptr;
+    // A block on the 8 passes with fewer than n / 256 groups after them starts in SWEEP mode (BZH_SWEEP_DIV: A/B timing).
+    // Rounds 2-3 drew the line at n / 8; measured in round 4 (scripts/gpu_sweep_ab.py): the periodic and run-heavy inputs
+    // SWEEP mode exists for have a few hundred to a thousand times fewer groups than suffixes and do not care (they
+    // break at n / 2048), while merely repetitive text is 3-9 % faster in SPLIT mode (real text with every block on the
+    // 8 passes 15.85 -> 14.60 ms, with the buckets 14.73 -> 14.36 ms: two of its blocks keep the 8 passes).
+    static const uint32_t sweep_div = getenv("BZH_SWEEP_DIV") ? (uint32_t)atoi(getenv("BZH_SWEEP_DIV")) : 256u;
     // bounds for the launches of the round being queued (exact lists live on the device)
     uint32_t nS = B, nA = B, nT = B, nQ = B, maxS = nmax, maxA = nmax, maxT = nmax;
     uint32_t err = 0;
@@ -2427,7 +2433,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         {
         KSpan ks(ctx, K_ROUND_BEGIN, 0);
         round_begin<<<1, (B + 63u) / 64u * 64u, 0, st>>>(bt, B, round, actP,
-                                                          const_cast<uint32_t *>(hsum) + (size_t)round * SUMMARY_WORDS, epoch + round + 1u);
+                                                          const_cast<uint32_t *>(hsum) + (size_t)round * SUMMARY_WORDS, epoch + round + 1u,
+                                                          sweep_div);
         }
         if (round > 1) {
             // the summary of the PREVIOUS round: where every block stood when that round began
