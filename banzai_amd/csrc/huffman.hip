@@ -196,11 +196,10 @@ __device__ __forceinline__ void heap_extract(HeapMem &h, uint32_t &len, uint32_t
         const uint32_t g32 = (uint32_t)gm;
         const uint32_t d = (g32 & 0x3u) ? ((g32 & 0x3Cu) ? ((g32 & 0x3FC0u) ? ((g32 & 0x3FFFC000u) ? 4u : 3u) : 2u) : 1u) : 0u;
         if (onpath && lvl <= d) h.key[node >> 1] = k; // the passed slots rise one level
-        {   // the path's lane at level d (lanes 2^d - 2 .. 2^(d+1) - 3); d = 0: the hole stays (lane "0 - (-1)" of a level of one)
-            const uint32_t lo = (1u << d) - 2u + (d ? 0u : 1u);          // first lane of level d (0 for d = 0)
-            const uint32_t lm = ((2u << (lo + (1u << d) - 1u)) - 1u) & ~((1u << lo) - 1u);
-            const uint32_t pl = d ? (uint32_t)__builtin_ctz(((uint32_t)pm & lm) | 0x80000000u) : 0u;
-            hole = (hole << d) + (pl - lo);
+        if (d) {
+            const uint32_t lm = d == 1u ? 0x3u : d == 2u ? 0x3Cu : d == 3u ? 0x3FC0u : 0x3FFFC000u;
+            const uint32_t pl = (uint32_t)__builtin_ctz((uint32_t)pm & lm); // the path's lane at level d
+            hole = (hole << d) + (pl - ((1u << d) - 2u));
         }
         HEAP_ORDER();
         if (d < 4) break;
