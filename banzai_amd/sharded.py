@@ -175,6 +175,10 @@ def encode_sharded(engine, dist=None, rank=0, world=1, side=None):
             raise err
         return engine.assemble([(part, nbits)], own)
     device = part.device if part is not None else getattr(engine, "device", "cpu")
+    # (a process group that moves host memory only -- gloo, e.g. two ranks sharing one GPU in a test -- gets host copies
+    # of the device tensors; over RCCL the tensors go as they are)
+    host_coll = str(getattr(device, "type", device)) == "cuda" and dist.get_backend() == "gloo"
+    cdev = "cpu" if host_coll else device
     # one small all-gather carries every rank's bit count (or -1 = failed), block count and block CRCs
     bounds = offsets(engine.n, world)
     width = 2 + max(bounds[r + 1] - bounds[r] for r in range(world)) // max(1, engine.min_block) + 2
@@ -183,8 +187,8 @@ def encode_sharded(engine, dist=None, rank=0, world=1, side=None):
         err, row = ShardError(f"rank {rank}: {len(own)} blocks do not fit the meta row of {width} words"), [-1, 0]
     meta = torch.zeros(width, dtype=torch.int64)
     meta[:len(row)] = torch.tensor(row, dtype=torch.int64)
-    meta = meta.to(device)
-    allmeta = torch.zeros(world * width, dtype=torch.int64, device=device)
+    meta = meta.to(cdev)
+    allmeta = torch.zeros(world * width, dtype=torch.int64, device=cdev)
     dist.all_gather_into_tensor(allmeta, meta)
     rows = allmeta.view(world, width).tolist()  # one read-back
     nb = [int(r[0]) for r in rows]
@@ -197,10 +201,12 @@ def encode_sharded(engine, dist=None, rank=0, world=1, side=None):
         bigger = torch.zeros(used, dtype=torch.uint8, device=part.device)
         bigger[:part.numel()] = part
         part = bigger
-    send = part[:used]
+    send = part[:used].to(cdev)
     slabs = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
     tg = time.perf_counter()
     dist.gather(send, slabs, dst=0)  # encoded blocks -> rank 0 (RCCL over xGMI on a GPU node)
+    if host_coll and rank == 0:
+        slabs = [x.to(device) for x in slabs]
     if rank != 0:
         t["ms_gather"] = (time.perf_counter() - tg) * 1e3
         return 0

@@ -94,11 +94,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # BZH_BENCH_SHARED_GPU=1 (test aid, tests/test_gpu_parity.py): every rank computes on cuda:0 and the collectives run
+    # over gloo on host tensors -- the whole multi-rank flow of this script and of sharded.encode_sharded on a box with
+    # ONE GPU (RCCL refuses two ranks on one device).  Its numbers are not a measurement of anything.
+    shared_gpu = world > 1 and os.environ.get("BZH_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if shared_gpu else dev  # where the tensors of this script's own collectives live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     seg_bytes = args.bytes
     total = seg_bytes * world
@@ -113,7 +123,7 @@ def main():
     resident = hi_res - lo_res
     d_in = torch.zeros(resident + 16, dtype=torch.uint8, device=dev)
     if world > 1:
-        scratch = torch.empty(seg_bytes, dtype=torch.uint8, device=dev)
+        scratch = torch.empty(seg_bytes, dtype=torch.uint8, device=cdev)
         for k in range(world):
             klen = max(0, min(seg_bytes, total - k * seg_bytes))
             if k == rank and klen:
@@ -121,7 +131,7 @@ def main():
             dist.broadcast(scratch, src=k)
             lo, hi = max(k * seg_bytes, lo_res), min(k * seg_bytes + klen, hi_res)
             if hi > lo:
-                d_in[lo - lo_res:hi - lo_res] = scratch[lo - k * seg_bytes:hi - k * seg_bytes]
+                d_in[lo - lo_res:hi - lo_res] = scratch[lo - k * seg_bytes:hi - k * seg_bytes].to(dev)
         del scratch
     else:
         d_in[:total] = torch.from_numpy(seg).to(dev)
@@ -162,7 +172,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ms_per_step = dt * 1e3 / args.steps
@@ -202,25 +212,27 @@ def main():
     alg = float(path_alg_bytes(counters))
     per_rank = None
     if world > 1:
-        t = torch.tensor([alg], dtype=torch.float64, device=dev)
+        t = torch.tensor([alg], dtype=torch.float64, device=cdev)
         dist.all_reduce(t)
         alg = float(t.item())
         # every rank's share of a step: tables + split, waiting for the chain, encode, gather (+ assembly on rank 0)
         keys = ("ms_plan", "ms_wait", "ms_encode", "ms_gather")
         mine = torch.tensor([rank_ms.get(k, 0.0) / args.steps for k in keys] + [float(resident), float(counters["raw_bytes"])],
-                            dtype=torch.float64, device=dev)
-        allr = torch.zeros(world * mine.numel(), dtype=torch.float64, device=dev)
+                            dtype=torch.float64, device=cdev)
+        allr = torch.zeros(world * mine.numel(), dtype=torch.float64, device=cdev)
         dist.all_gather_into_tensor(allr, mine)
         rows = allr.view(world, -1).tolist()
         per_rank = [dict({k: round(v, 3) for k, v in zip(keys, row)}, resident_bytes=int(row[4]), encoded_input_bytes=int(row[5]))
                     for row in rows]
         # rank 0 also checks the sharded stream against one GPU encoding the whole input (untimed)
-        d_full = torch.zeros(seg_bytes * world + 16, dtype=torch.uint8, device=dev) if rank == 0 else None
+        d_full = torch.zeros(seg_bytes * world + 16, dtype=torch.uint8, device=cdev) if rank == 0 else None
         parts = [d_full[k * seg_bytes:(k + 1) * seg_bytes] for k in range(world)] if rank == 0 else None
-        mine_full = torch.zeros(seg_bytes, dtype=torch.uint8, device=dev)
-        mine_full[:seg_len] = torch.from_numpy(seg).to(dev)
+        mine_full = torch.zeros(seg_bytes, dtype=torch.uint8, device=cdev)
+        mine_full[:seg_len] = torch.from_numpy(seg).to(cdev)
         dist.gather(mine_full, parts, dst=0)
         del mine_full
+        if rank == 0:
+            d_full = d_full.to(dev)
     else:
         d_full = d_in
 

@@ -901,3 +901,27 @@ def test_coverage_guided_corpus(oracle, native):
     finally:
         for c in ctxs.values():
             c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--bytes", "30000000"], ["--total-bytes", "70000000"]])
+def test_bench_multi_rank_flow_on_one_gpu(extra):
+    """`bench.py --gpus 3` end to end on a box with ONE GPU: three real processes, every rank computing on cuda:0, the
+    collectives over gloo on host tensors (BZH_BENCH_SHARED_GPU=1; RCCL refuses several ranks on one device) -- the
+    script's multi-rank flow (self-launch, residency, chain over the side group, all-gather + gather, assembly, timing
+    reductions, per-rank rows) and its checks: the sharded stream equals one GPU's, libbz2 decodes it, the oracle agrees"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BZH_BENCH_SHARED_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1",
+                        "--cpu-sample", "4000000", "--no-extra"] + extra, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 3 and line["ranks_seen"] == 3 and len(line["per_rank"]) == 3
+    assert line["scaling"] == ("strong" if extra[0] == "--total-bytes" else "weak")
+    assert line["checks"]["sharded_equals_single_gpu"] and line["checks"]["libbz2_roundtrip"]
+    assert line["checks"]["bit_exact_vs_oracle_sample"] and all(line["checks"].values())
+    assert sum(r["encoded_input_bytes"] for r in line["per_rank"]) == (70000000 if extra[0] == "--total-bytes" else 90000000)
