@@ -46,8 +46,8 @@ SORT_BYTES_PER_ELEM = 16.0     # one radix pass moves an 8-byte (key, suffix) pa
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--bytes", type=int, default=SEGMENT, help="bytes per GPU")
     ap.add_argument("--total-bytes", type=int, default=0,
                     help="size of the ONE stream all ranks share (overrides --bytes; 1000000000 = BASELINE config 4)")
