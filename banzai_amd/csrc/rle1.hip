@@ -567,6 +567,7 @@ __global__ void __launch_bounds__(128) plan_split(PlanArrays pa)
 constexpr uint32_t CRC_POLY = 0x04C11DB7u;
 constexpr uint32_t CRC_PIECE = 32;                         // bytes per thread
 constexpr uint32_t CRC_TILE = RL_THREADS * CRC_PIECE;      // 8192 bytes per workgroup
+constexpr uint32_t CRC_WG_TILES = 8;                       // adjacent tiles a workgroup folds (at least)
 
 struct CrcTables {
     uint32_t pow2[40];   // x^(2^k) mod P, k = 0..39 (bit exponents)
@@ -594,19 +595,15 @@ __device__ __forceinline__ uint32_t gf_pow_x(const CrcTables &ct, uint64_t e, ui
     return f;
 }
 
-// Workgroup x of block y takes the x-th of gridDim.x equal ranges of the block's tiles; `nbp` (optional) = number of valid blocks
-// on the device (the plan launches this before the host knows how many blocks the split found).
-__global__ void __launch_bounds__(RL_THREADS) crc_tiles(const uint8_t *in, const BlockDesc *blocks, uint32_t *acc,
-                                                         const CrcTables *ctp, const uint32_t *nbp)
+// The CRC of the block's tiles [tA, tB) (adjacent 8 KiB pieces of its input), shifted to the block's end and XORed
+// into *accb.  The tiles fold into one value (acc * x^(8 * tile bytes) + tile), so a workgroup pays one power of x and
+// one atomic, not one per tile.  Slicing by four: tab[k][v] = CRC of byte v followed by k zero bytes, so four bytes
+// cost one dependent step (four independent LDS lookups) instead of four.
+__device__ __forceinline__ void crc_range(const uint8_t *in, const BlockDesc &d, uint32_t *accb, const CrcTables &ct, uint64_t tA,
+                                          uint64_t tB)
 {
-    const uint32_t b = blockIdx.y;
-    if (nbp && b >= *nbp) return;
-    const BlockDesc d = blocks[b];
-    if ((uint64_t)blockIdx.x * ((((d.in_len + CRC_TILE - 1) / CRC_TILE) + gridDim.x - 1) / gridDim.x) * CRC_TILE >= d.in_len) return;
-    const CrcTables &ct = *ctp;
-    // slicing by four: tab[k][v] = CRC of byte v followed by k zero bytes, so four bytes cost one dependent step
-    // (four independent LDS lookups) instead of four
     __shared__ uint32_t tab[4][256];
+    __shared__ uint32_t wred[RL_THREADS / 64];
     {
         uint32_t c = threadIdx.x << 24;
 #pragma unroll
@@ -621,62 +618,111 @@ __global__ void __launch_bounds__(RL_THREADS) crc_tiles(const uint8_t *in, const
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63;
-    __shared__ uint32_t wred[RL_THREADS / 64];
-    // this workgroup's tiles are adjacent: their CRCs fold into one value (acc * x^(8 * tile bytes) + tile), which is
-    // shifted to the block's end once -- one power of x and one atomic per workgroup, not per tile
-    const uint64_t ntile = (d.in_len + CRC_TILE - 1) / CRC_TILE;
-    const uint64_t per = (ntile + gridDim.x - 1) / gridDim.x;
-    const uint64_t tA = (uint64_t)blockIdx.x * per, tB = tA + per < ntile ? tA + per : ntile;
     uint32_t acc_c = 0; // (wavefront 0)
     uint64_t range_end = 0;
     for (uint64_t t = tA; t < tB; t++) {
-    const uint64_t t0 = t * CRC_TILE;
-    const uint32_t tile_len = d.in_len - t0 < CRC_TILE ? (uint32_t)(d.in_len - t0) : CRC_TILE;
-    range_end = t0 + tile_len;
-    // pieces: a ragged first piece of r bytes (if any), then full 32-byte pieces, so that the bytes
-    // after every piece are a multiple of 32
-    const uint32_t r = tile_len % CRC_PIECE, np = tile_len / CRC_PIECE + (r ? 1u : 0u);
-    uint32_t crc = 0;
-    if (threadIdx.x < np) {
-        uint32_t off, len;
-        if (r) {
-            off = threadIdx.x ? r + (threadIdx.x - 1) * CRC_PIECE : 0;
-            len = threadIdx.x ? CRC_PIECE : r;
-        } else {
-            off = threadIdx.x * CRC_PIECE;
-            len = CRC_PIECE;
-        }
-        const uint8_t *p = in + d.in_off + t0 + off;
-        if (len == CRC_PIECE) { // (gfx950 global loads need no alignment: two 16-byte loads of the piece)
-            uint32_t w[8];
-            __builtin_memcpy(w, p, 32);
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const uint32_t x = crc ^ __builtin_bswap32(w[q]); // the stream's first byte is the polynomial's highest term
-                crc = tab[3][x >> 24] ^ tab[2][(x >> 16) & 255u] ^ tab[1][(x >> 8) & 255u] ^ tab[0][x & 255u];
+        const uint64_t t0 = t * CRC_TILE;
+        const uint32_t tile_len = d.in_len - t0 < CRC_TILE ? (uint32_t)(d.in_len - t0) : CRC_TILE;
+        range_end = t0 + tile_len;
+        // pieces: a ragged first piece of r bytes (if any), then full 32-byte pieces, so that the bytes
+        // after every piece are a multiple of 32
+        const uint32_t r = tile_len % CRC_PIECE, np = tile_len / CRC_PIECE + (r ? 1u : 0u);
+        uint32_t crc = 0;
+        if (threadIdx.x < np) {
+            uint32_t off, len;
+            if (r) {
+                off = threadIdx.x ? r + (threadIdx.x - 1) * CRC_PIECE : 0;
+                len = threadIdx.x ? CRC_PIECE : r;
+            } else {
+                off = threadIdx.x * CRC_PIECE;
+                len = CRC_PIECE;
             }
-        } else {
-            for (uint32_t k = 0; k < len; k++) crc = (crc << 8) ^ tab[0][(crc >> 24) ^ p[k]];
-        }
-        crc = gf_mul(crc, ct.shift[np - 1 - threadIdx.x]);
-    }
+            const uint8_t *p = in + d.in_off + t0 + off;
+            if (len == CRC_PIECE) { // (gfx950 global loads need no alignment: two 16-byte loads of the piece)
+                uint32_t w[8];
+                __builtin_memcpy(w, p, 32);
 #pragma unroll
-    for (int s = 32; s > 0; s >>= 1) crc ^= __shfl_xor(crc, s, 64);
-    if (lane == 0) wred[threadIdx.x >> 6] = crc;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        uint32_t c = 0;
-        for (int w = 0; w < RL_THREADS / 64; w++) c ^= wred[w];
-        // x^(8 * tile_len): a constant for full tiles (8 * 8192 = 2^16), a power for the block's last, ragged one
-        const uint32_t xp = tile_len == CRC_TILE ? ct.pow2[16] : gf_pow_x(ct, 8ull * tile_len, lane);
-        acc_c = gf_mul(acc_c, xp) ^ c;
-    }
-    __syncthreads(); // wred is reused by the next tile
+                for (int q = 0; q < 8; q++) {
+                    const uint32_t x = crc ^ __builtin_bswap32(w[q]); // the stream's first byte is the polynomial's highest term
+                    crc = tab[3][x >> 24] ^ tab[2][(x >> 16) & 255u] ^ tab[1][(x >> 8) & 255u] ^ tab[0][x & 255u];
+                }
+            } else {
+                for (uint32_t k = 0; k < len; k++) crc = (crc << 8) ^ tab[0][(crc >> 24) ^ p[k]];
+            }
+            crc = gf_mul(crc, ct.shift[np - 1 - threadIdx.x]);
+        }
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) crc ^= __shfl_xor(crc, s, 64);
+        if (lane == 0) wred[threadIdx.x >> 6] = crc;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            uint32_t c = 0;
+            for (int w = 0; w < RL_THREADS / 64; w++) c ^= wred[w];
+            // x^(8 * tile_len): a constant for full tiles (8 * 8192 = 2^16), a power for the block's last, ragged one
+            const uint32_t xp = tile_len == CRC_TILE ? ct.pow2[16] : gf_pow_x(ct, 8ull * tile_len, lane);
+            acc_c = gf_mul(acc_c, xp) ^ c;
+        }
+        __syncthreads(); // wred is reused by the next tile
     }
     if (threadIdx.x < 64 && tB > tA) {
         const uint32_t pw = gf_pow_x(ct, 8ull * (d.in_len - range_end), lane);
-        if (lane == 0) atomicXor(&acc[b], gf_mul(acc_c, pw));
+        if (lane == 0) atomicXor(accb, gf_mul(acc_c, pw));
     }
+}
+
+// Workgroup x of block y takes the x-th range of the block's tiles: CRC_WG_TILES of them (64 KiB) for an ordinary block,
+// more when the launch has fewer workgroups than that needs (the caller knows the longest block).
+__global__ void __launch_bounds__(RL_THREADS) crc_tiles(const uint8_t *in, const BlockDesc *blocks, uint32_t *acc,
+                                                         const CrcTables *ctp, const uint32_t *nbp)
+{
+    const uint32_t b = blockIdx.y;
+    if (nbp && b >= *nbp) return;
+    const BlockDesc d = blocks[b];
+    const uint64_t ntile = (d.in_len + CRC_TILE - 1) / CRC_TILE;
+    const uint64_t per = max((uint64_t)CRC_WG_TILES, (ntile + gridDim.x - 1) / gridDim.x);
+    const uint64_t tA = (uint64_t)blockIdx.x * per;
+    if (tA >= ntile) return;
+    crc_range(in, d, &acc[b], *ctp, tA, tA + per < ntile ? tA + per : ntile);
+}
+
+// The same over a FLAT grid, for the plan, which queues the CRCs before the host knows the blocks: workgroup g takes
+// the g-th range of CRC_WG_TILES tiles counted over all blocks (a block that is one enormous run of input holds
+// thousands of tiles, an ordinary one 110: a grid of blocks x ranges would be nearly all empty workgroups).  The block
+// of a range: 64 blocks at a time, a lane each, by a wave scan of their range counts.
+__global__ void __launch_bounds__(RL_THREADS) crc_tiles_flat(const uint8_t *in, const BlockDesc *blocks, uint32_t *acc,
+                                                              const CrcTables *ctp, const uint32_t *nbp)
+{
+    const uint32_t nb = *nbp;
+    if (nb == 0xFFFFFFFFu) return; // (the split overflowed: the host reports it)
+    const uint32_t lane = threadIdx.x & 63;
+    __shared__ uint32_t s_b, s_first;
+    if (threadIdx.x < 64) {
+        uint32_t before = 0, found = 0xFFFFFFFFu, first = 0;
+        for (uint32_t b0 = 0; b0 < nb && found == 0xFFFFFFFFu; b0 += 64) {
+            const uint32_t b = b0 + lane;
+            const uint64_t ntile = b < nb ? (blocks[b].in_len + CRC_TILE - 1) / CRC_TILE : 0;
+            const uint32_t cnt = (uint32_t)((ntile + CRC_WG_TILES - 1) / CRC_WG_TILES);
+            const uint32_t inc = wave_incl_add(cnt, (int)lane);
+            const unsigned long long m = __ballot(before + inc > blockIdx.x); // (counts are non-negative: a suffix of the lanes)
+            if (m) {
+                const int l = __ffsll((long long)m) - 1;
+                found = b0 + (uint32_t)l;
+                first = before + (uint32_t)__shfl((int)(inc - cnt), l, 64);
+            }
+            before += (uint32_t)__shfl((int)inc, 63, 64);
+        }
+        if (lane == 0) {
+            s_b = found;
+            s_first = first;
+        }
+    }
+    __syncthreads();
+    const uint32_t b = s_b;
+    if (b == 0xFFFFFFFFu) return; // beyond the last range
+    const BlockDesc d = blocks[b];
+    const uint64_t ntile = (d.in_len + CRC_TILE - 1) / CRC_TILE;
+    const uint64_t tA = (uint64_t)(blockIdx.x - s_first) * CRC_WG_TILES;
+    crc_range(in, d, &acc[b], *ctp, tA, tA + CRC_WG_TILES < ntile ? tA + CRC_WG_TILES : ntile);
 }
 
 __global__ void __launch_bounds__(64) crc_finish(BlockDesc *blocks, const uint32_t *acc, uint32_t nb,
@@ -1014,10 +1060,9 @@ int rle1_plan_split(bzh_ctx *ctx, size_t start, bool with_crc, size_t stop)
         BZH_TRY(crc_tables(ctx, &ct));
         KSpan ks(ctx, K_CRC, n, 2);
         HIP_TRY(ctx, hipMemsetAsync(w.crcacc, 0, (size_t)pa.maxblocks * 4, st));
-        for (uint32_t k0 = 0; k0 < pa.maxblocks; k0 += 32768) { // grid.y limit
-            const uint32_t cnt = pa.maxblocks - k0 < 32768 ? pa.maxblocks - k0 : 32768;
-            crc_tiles<<<dim3(16, cnt), RL_THREADS, 0, st>>>(d_in, pa.blocks + k0, w.crcacc + k0, ct, pa.nblocks);
-        }
+        // (ranges of 64 KiB counted over all blocks: at most n / 64 KiB + one ragged range a block)
+        const uint64_t ranges = n / ((uint64_t)CRC_TILE * CRC_WG_TILES) + pa.maxblocks + 1;
+        crc_tiles_flat<<<dim3((uint32_t)ranges), RL_THREADS, 0, st>>>(d_in, pa.blocks, w.crcacc, ct, pa.nblocks);
         crc_finish<<<dim3(pa.maxblocks), 64, 0, st>>>(pa.blocks, w.crcacc, 0, ct, pa.nblocks);
     }
     // blocks | aux | nblocks are consecutive in the workspace (plan_layout)
@@ -1067,7 +1112,7 @@ int rle1_plan_crc(bzh_ctx *ctx, size_t b0, size_t b1)
     const uint32_t ctiles = (uint32_t)((maxlen + CRC_TILE - 1) / CRC_TILE);
     for (uint32_t k0 = 0; k0 < nb; k0 += 32768) { // grid.y limit
         const uint32_t cnt = nb - k0 < 32768 ? nb - k0 : 32768;
-        crc_tiles<<<dim3((ctiles + 7) / 8, cnt), RL_THREADS, 0, st>>>(ctx->plan_in, pa.blocks + b0 + k0, w.crcacc + b0 + k0, ct, nullptr);
+        crc_tiles<<<dim3(std::min(1024u, (ctiles + CRC_WG_TILES - 1) / CRC_WG_TILES), cnt), RL_THREADS, 0, st>>>(ctx->plan_in, pa.blocks + b0 + k0, w.crcacc + b0 + k0, ct, nullptr);
     }
     crc_finish<<<dim3(nb), 64, 0, st>>>(pa.blocks + b0, w.crcacc + b0, nb, ct, nullptr);
     std::vector<BlockDesc> hb(nb);
@@ -1118,7 +1163,7 @@ int crc_device(bzh_ctx *ctx, const uint8_t *d_in, size_t n, uint32_t *crc_out)
     HIP_TRY(ctx, hipMemcpyAsync(dd, &d, sizeof d, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemsetAsync(acc, 0, 4, st));
     const uint32_t ctiles = (uint32_t)((n + CRC_TILE - 1) / CRC_TILE);
-    if (ctiles) crc_tiles<<<dim3((ctiles + 7) / 8, 1), RL_THREADS, 0, st>>>(d_in, dd, acc, ct, nullptr);
+    if (ctiles) crc_tiles<<<dim3(std::min(4096u, (ctiles + CRC_WG_TILES - 1) / CRC_WG_TILES), 1), RL_THREADS, 0, st>>>(d_in, dd, acc, ct, nullptr);
     crc_finish<<<dim3(1), 64, 0, st>>>(dd, acc, 1, ct, nullptr);
     HIP_TRY(ctx, hipMemcpyAsync(&d, dd, sizeof d, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, bzh_stream_wait(st));
