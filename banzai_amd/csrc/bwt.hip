@@ -2122,7 +2122,14 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         const char *e = getenv("BZH_INIT");
         return e && !strcmp(e, "lsd");
     }();
-    const bool use_msd = ctx->M >= MS_MIN_N && !a.fault && !init_lsd;
+    static const bool init_msd = []() {
+        const char *e = getenv("BZH_INIT");
+        return e && !strcmp(e, "msd");
+    }();
+    // (a batch of fewer than 12 blocks keeps the 8 passes: the bucket tables' fixed work -- histogram, plan, five levels --
+    // does not pay below that: 1 / 2 / 4 / 8 / 16 text blocks 1.56 / 1.62 / 2.08 / 2.55 / 3.07 ms with the buckets, 1.45 / 1.51 /
+    // 1.94 / 2.47 / 3.11 ms with the 8 passes, one random block 1.36 / 1.26 ms; BZH_INIT=msd overrides)
+    const bool use_msd = ctx->M >= MS_MIN_N && !a.fault && !init_lsd && (B >= 12u || init_msd);
     uint32_t nOld = B;
     Lst oldl = all;
     u64 *const binned = reinterpret_cast<u64 *>(bt.sa);

@@ -149,6 +149,27 @@ def main():
                                       lo=lo_res)
         engine.check_lookahead(rank, world)
         side = sharded.side_group(dist)  # the chain's 8-byte hand-offs: gloo, CPU tensors (the collectives stay on RCCL)
+        if shared_gpu:
+            # the ranks take turns on the one GPU (a file lock around every engine call, released once the GPU is idle):
+            # the kernels' decoupled look-backs assume the workgroup -> XCD dealing a process sees when it has the device
+            # to itself; several processes computing at once perturb it, and a look-back can give up (an error status
+            # after a bounded wait, never a hang -- DESIGN.md section 5).  One process per GPU is the deployment.
+            import fcntl
+            import tempfile
+            lock_f = open(os.path.join(tempfile.gettempdir(), f"bzhip_shared_gpu_{os.environ.get('MASTER_PORT', '0')}.lock"), "w")
+
+            def taking_turns(fn):
+                def call(*a, **kw):
+                    fcntl.flock(lock_f, fcntl.LOCK_EX)
+                    try:
+                        out = fn(*a, **kw)
+                        torch.cuda.synchronize()
+                        return out
+                    finally:
+                        fcntl.flock(lock_f, fcntl.LOCK_UN)
+                return call
+            for name in ("tables", "split", "encode_range", "assemble"):
+                setattr(engine, name, taking_turns(getattr(engine, name)))
 
     def step():
         """One pass of the hot path; returns the stream length on rank 0."""
