@@ -346,7 +346,7 @@ extern "C" int bzh_set_profiling(bzh_ctx *ctx, int enabled)
 extern "C" int bzh_debug_fault(bzh_ctx *ctx, int kind)
 {
     return bzh_guard(ctx, [&]() -> int {
-    if (!ctx || kind < 0 || kind > 1) return BZH_E_ARG;
+    if (!ctx || kind < 0 || kind > 2) return BZH_E_ARG;
     ctx->debug_fault = (uint32_t)kind;
     return BZH_OK;
     });

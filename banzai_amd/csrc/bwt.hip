@@ -585,7 +585,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
     }
     uint32_t tile_total;
     const uint32_t ex = block_excl_add(mytot, ls, &tile_total);
-    const bool mute = a.fault == 1u && b == 0u && tile == 1u; // (test hook: this tile's successors must give up, not hang)
+    const bool mute = a.fault != 0u && b == 0u && tile == 1u; // (test hook: this tile's successors must give up, not hang)
     if (threadIdx.x < NB) {
         const uint32_t bin = threadIdx.x;
         binstart[bin] = ex;
@@ -1921,7 +1921,7 @@ static void launch_pass(bzh_ctx *ctx, SortArgs &a, uint32_t NB, uint32_t maxcnt)
 {
     const uint32_t tiles = (maxcnt + SORT_TILE - 1) / SORT_TILE;
     if (tiles == 0 || NB == 0) return;
-    a.T = tiles | (NB < 32 ? WG_SPREAD : 0u);
+    a.T = tiles | ((NB < 32 && !ctx->no_spread) ? WG_SPREAD : 0u); // (look-back: see bwt_run on no_spread)
     a.pass++;
     radix_scatter<BITS, MODE><<<dim3(xcd_grid(a.T, NB)), SORT_THREADS, 0, ctx->stream>>>(a);
     if (ctx->profiling) ctx->stats.bwt_sort_launches++; // every launch issued, also the ones that find their list empty
@@ -1984,7 +1984,7 @@ static void launch_refine(bzh_ctx *ctx, RefineArgs &r, uint32_t NB, uint32_t max
 {
     const uint32_t tiles = (maxcnt + SORT_TILE - 1) / SORT_TILE;
     if (tiles == 0 || NB == 0) return;
-    r.T = tiles | (NB < 32 ? WG_SPREAD : 0u);
+    r.T = tiles | ((NB < 32 && !ctx->no_spread) ? WG_SPREAD : 0u);
     flag_tiles<<<dim3(xcd_grid(r.T, NB)), SORT_THREADS, 0, ctx->stream>>>(r);
     flag_carry<<<dim3(NB), 1024, 0, ctx->stream>>>(r);
     refine<<<dim3(xcd_grid(r.T, NB)), SORT_THREADS, 0, ctx->stream>>>(r);
@@ -2042,7 +2042,7 @@ static void launch_refine_one(bzh_ctx *ctx, RefineArgs &r, uint32_t NB, uint32_t
 {
     const uint32_t tiles = (maxcnt + SORT_TILE - 1) / SORT_TILE;
     if (tiles == 0 || NB == 0) return;
-    r.T = tiles | (NB < 32 ? WG_SPREAD : 0u);
+    r.T = tiles | ((NB < 32 && !ctx->no_spread) ? WG_SPREAD : 0u);
     refine_one<INIT><<<dim3(xcd_grid(r.T, NB)), SORT_THREADS, 0, ctx->stream>>>(r, ctx->bt.c_groups, recs);
 }
 
@@ -2083,6 +2083,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     a.gst = reinterpret_cast<u64 *>(bt.tagg); // (flag_tiles / flag_carry use it after the initial sort only)
     a.chain = bt.chain;
     a.fault = ctx->debug_fault; // (one batch only)
+    const bool had_fault = a.fault == 1u; // (kind 2: the fault of a shared GPU -- the sort is expected to recover by itself)
     ctx->debug_fault = 0;
     a.clist = reinterpret_cast<const uint32_t *>(bt.listD); // (a block in SWEEP mode has no small-group lists)
     a.src = nullptr;
@@ -2552,6 +2553,18 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         return BZH_E_HIP;
     }
     if (err) HIP_TRY(ctx, bzh_stream_wait(st)); // (what was queued behind the faulty kernel ends before the error is reported)
+    // A look-back that gave up although nothing was injected: seen only when several PROCESSES compute on this GPU at once
+    // and the batch is small.  With fewer than 32 blocks a block's tiles are dealt over all XCDs, so a tile may wait for a
+    // predecessor that is still queued on another XCD -- whose slots another process's workgroups hold, waiting in the same
+    // way for tiles queued behind ours.  Blocks pinned to one XCD each (the mapping of larger batches) only ever wait for
+    // workgroups that are resident already.  The sort starts from bt.rle and re-initialises everything it uses, so it is
+    // simply run again with that mapping, which this context then keeps.
+    if ((err & 2u) && !(err & ~2u) && !had_fault && !ctx->no_spread && B < 32u) {
+        ctx->no_spread = true;
+        static const bool say = getenv("BZH_TRACE_ROUNDS") != nullptr;
+        if (say) fprintf(stderr, "[bzhip] a look-back gave up: the suffix sort runs again with every block on one XCD\n");
+        return bwt_run(ctx, B, nmax, ntotal);
+    }
     // (the last summary read is the one of a round that found nothing to do: every kernel before it has run, so
     // its error word and its sum of unresolved suffixes are final)
     ctx->stats.bwt_active_sum += (uint64_t)s[17] | ((uint64_t)s[18] << 32);

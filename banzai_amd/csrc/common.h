@@ -257,6 +257,7 @@ struct bzh_ctx {
     } strm;
     bzh_stats stats{};
     uint32_t debug_fault = 0;         // bzh_debug_fault: fault to inject into the next suffix sort
+    bool no_spread = false;           // look-back kernels keep every block on one XCD (set for good after a look-back gave up: bwt_run)
     uint32_t bwt_epoch = 0;           // calls of bwt_run so far (tags the round summaries in pinned memory)
     std::vector<hipEvent_t> evpool;
     size_t evnext = 0;

@@ -149,7 +149,7 @@ def main():
                                       lo=lo_res)
         engine.check_lookahead(rank, world)
         side = sharded.side_group(dist)  # the chain's 8-byte hand-offs: gloo, CPU tensors (the collectives stay on RCCL)
-        if shared_gpu:
+        if shared_gpu and os.environ.get("BZH_SHARED_GPU_NO_TURNS") != "1":
             # the ranks take turns on the one GPU (a file lock around every engine call, released once the GPU is idle):
             # the kernels' decoupled look-backs assume the workgroup -> XCD dealing a process sees when it has the device
             # to itself; several processes computing at once perturb it, and a look-back can give up (an error status

@@ -88,7 +88,9 @@ BZH_API int bzh_set_lanes(bzh_ctx *ctx, int lanes);
 BZH_API int bzh_get_stats(const bzh_ctx *ctx, bzh_stats *out);
 /* Test hook: inject a fault into the next suffix sort of this context (kind 1: one tile of the first block never
  * publishes its look-back status; 0: none).  The call that runs into it returns an error status -- the waits of
- * the look-backs are bounded -- and the context stays usable.  No counterpart in the reference. */
+ * the look-backs are bounded -- and the context stays usable.  Kind 2: the same fault, treated as the one a GPU
+ * shared with other processes produces (a look-back of a small batch gives up): the sort runs again with every
+ * block pinned to one XCD and the call succeeds.  No counterpart in the reference. */
 BZH_API int bzh_debug_fault(bzh_ctx *ctx, int kind);
 
 /* Per-kernel-class figures of the last whole-path call made with profiling on (bench.py's `roofline.kernels`):

@@ -787,6 +787,17 @@ def test_lookback_give_up_is_an_error_not_a_hang(oracle, native):
         assert ctx.encode(d) == oracle.encode(d, 9)
 
 
+def test_lookback_give_up_of_a_shared_gpu_is_recovered(oracle, native):
+    """what several processes computing on one GPU do to a small batch (a look-back gives up: its predecessor is queued on
+    an XCD whose slots another process holds), injected: the suffix sort runs again with every block on one XCD, the call
+    succeeds with the oracle's bytes, and the context keeps that mapping"""
+    d = cases.gen(400_000, "text", 5) + cases.gen(2_000_000, "text", 6)
+    with native.Context(0, 9, 8) as ctx:
+        ctx.debug_fault(2)
+        assert ctx.encode(d) == oracle.encode(d, 9)
+        assert ctx.encode(d[:700_000]) == oracle.encode(d[:700_000], 9)
+
+
 def test_stream_beyond_four_gib(native):
     """more than 2^32 input bytes through bzh_stream_feed (the reference's encode has no length limit, lib/lib.rs:84-132;
     one plan here has 32-bit positions, so the stream is cut into plans): 16 x 256 MiB of zeros, 64 MiB more, and a
