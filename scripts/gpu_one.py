@@ -1,5 +1,5 @@
 """Encode one named workload a few times on cuda:0 (for rocprofv3 timelines): python scripts/gpu_one.py NAME [reps]
-NAME: enwik | python-sources | shared-libs | c5-zeros | c5-tile1024 | c5-abab | c5-cycling-runs"""
+NAME: enwik | enwik:NBYTES | python-sources | shared-libs | c5-zeros | c5-tile1024 | c5-abab | c5-cycling-runs"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -8,6 +8,8 @@ name = sys.argv[1]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 if name == "enwik":
     data = corpus.workload(100_000_000)[0]
+elif name.startswith("enwik:"): # the first N bytes of the headline text (small batches)
+    data = corpus.workload(100_000_000)[0][:int(name[6:])]
 elif name in corpus.IMAGE_SETS:
     data = corpus.image_corpus(name)
 else:
