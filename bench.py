@@ -98,13 +98,22 @@ def main():
     # over gloo on host tensors -- the whole multi-rank flow of this script and of sharded.encode_sharded on a box with
     # ONE GPU (RCCL refuses two ranks on one device).  Its numbers are not a measurement of anything.
     shared_gpu = world > 1 and os.environ.get("BZH_BENCH_SHARED_GPU") == "1"
+    # BZH_BENCH_DIST_WORLD1=1 (test aid): a single rank takes the MULTI-rank flow -- process group on RCCL (backend "nccl"),
+    # gloo side group, broadcast / all_gather / gather / all_reduce on device tensors, encode_sharded -- which is as much
+    # of the N > 1 transport as a box with one GPU can execute.  Not a measurement of anything.
+    multi = world > 1 or os.environ.get("BZH_BENCH_DIST_WORLD1") == "1"
     if shared_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if shared_gpu else dev  # where the tensors of this script's own collectives live
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:  # (only the one-rank test mode gets here: launchers set it)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if shared_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -119,10 +128,10 @@ def main():
     seg_len = max(0, min(seg_bytes, total - rank * seg_bytes))
     seg, wname = corpus.workload(max(1, seg_len), segment=rank)
     seg = seg[:seg_len]
-    lo_res, hi_res = sharded.resident_range(total, rank, world) if world > 1 else (0, total)
+    lo_res, hi_res = sharded.resident_range(total, rank, world) if multi else (0, total)
     resident = hi_res - lo_res
     d_in = torch.zeros(resident + 16, dtype=torch.uint8, device=dev)
-    if world > 1:
+    if multi:
         scratch = torch.empty(seg_bytes, dtype=torch.uint8, device=cdev)
         for k in range(world):
             klen = max(0, min(seg_bytes, total - k * seg_bytes))
@@ -135,7 +144,7 @@ def main():
         del scratch
     else:
         d_in[:total] = torch.from_numpy(seg).to(dev)
-    out_cap = (total // 3 + total // 8 + (1 << 20)) & ~3 if world == 1 else (total + total // 4 + (1 << 20)) & ~3
+    out_cap = (total // 3 + total // 8 + (1 << 20)) & ~3 if not multi else (total + total // 4 + (1 << 20)) & ~3
     d_out = torch.zeros(out_cap if rank == 0 else 16, dtype=torch.uint8, device=dev)
 
     ctx = nv.Context(local_rank, LEVEL, 128)
@@ -144,7 +153,7 @@ def main():
 
     engine = None
     side = None
-    if world > 1:
+    if multi:
         engine = sharded.DeviceEngine(ctx, d_in, total, d_out, sharded.worst_case_slab(total, world, LEVEL), resident=resident,
                                       lo=lo_res)
         engine.check_lookahead(rank, world)
@@ -173,12 +182,12 @@ def main():
 
     def step():
         """One pass of the hot path; returns the stream length on rank 0."""
-        if world == 1:
+        if not multi:
             return ctx.encode_device(d_in.data_ptr(), total, d_out.data_ptr(), out_cap)
         return sharded.encode_sharded(engine, dist, rank, world, side=side)
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -225,7 +234,7 @@ def main():
         out_len = step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -235,7 +244,7 @@ def main():
     # whole-path accounting needs every rank's counters
     alg = float(path_alg_bytes(counters))
     per_rank = None
-    if world > 1:
+    if multi:
         t = torch.tensor([alg], dtype=torch.float64, device=cdev)
         dist.all_reduce(t)
         alg = float(t.item())
@@ -269,7 +278,7 @@ def main():
             import bz2
             ref_in = d_full[:total].cpu().numpy().tobytes()
             checks["libbz2_roundtrip"] = bool(bz2.decompress(stream_bytes) == ref_in)
-        if world > 1:
+        if multi:
             mcap = (total // 3 + total // 8 + (1 << 20)) & ~3
             d_mono = torch.zeros(mcap, dtype=torch.uint8, device=dev)
             mlen = ctx.encode_device(d_full.data_ptr(), total, d_mono.data_ptr(), mcap)
@@ -301,7 +310,7 @@ def main():
         host_incl = None
         stream_api = None
         extras = None
-        if world == 1 and not args.no_extra:
+        if not multi and not args.no_extra:
             h_in = torch.from_numpy(seg).pin_memory()
             h_out = torch.zeros(out_cap, dtype=torch.uint8).pin_memory()
             hlen = ctx.encode_host_ptr(h_in.data_ptr(), total, h_out.data_ptr(), out_cap)
@@ -460,7 +469,7 @@ def main():
         traffic_source = None
         try:
             pmc = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_pmc_traffic.json"))
-            if pmc and world == 1 and seg_bytes == SEGMENT and dom_key:
+            if pmc and not multi and seg_bytes == SEGMENT and dom_key:
                 with open(os.path.join(ROOT, "profiles", pmc[-1])) as f:
                     pk = json.load(f)["kernels"]
                 hit = [v for k, v in pk.items() if k.startswith(dom_key)]
@@ -478,7 +487,8 @@ def main():
             "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong" if args.total_bytes else "weak",
-            "ranks_seen": dist.get_world_size() if world > 1 else 1, "per_rank": per_rank,
+            "ranks_seen": dist.get_world_size() if multi else 1, "per_rank": per_rank,
+            "collective_backend": dist.get_backend() if multi else None,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic" if wname != "enwik8" else "enwik8",
             "config": {"workload": f"level {LEVEL} {wname}, {seg_bytes} bytes per GPU, {total} bytes in one stream, "
                                    "full RLE1->BWT->MTF->Huffman pipeline",
@@ -510,7 +520,7 @@ def main():
             "value_host_inclusive": host_incl,
             "value_stream_api": stream_api,
             "value_real_text": (extras or {}).get("real-text-100MB", {}).get("MB/s"),
-            "workload_sha256": corpus.corpus_digest(seg) if world == 1 else None,
+            "workload_sha256": corpus.corpus_digest(seg) if not multi else None,
             # north_star's ">= 10x banzai's CPU path, one thread": quoted on the LOWER of the headline and the real-text
             # workload (GPU MB/s over the oracle's MB/s on the same bytes)
             "speedup_vs_cpu_1thread": (lambda rt: {
@@ -525,7 +535,7 @@ def main():
         }
         print(json.dumps(result), flush=True)
     ctx.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     if result is not None and not all(result["checks"].values()):

@@ -915,6 +915,29 @@ def test_coverage_guided_corpus(oracle, native):
 
 
 @pytest.mark.gpu
+def test_bench_multi_rank_flow_over_rccl_with_one_rank():
+    """The N > 1 flow of `bench.py` with its real transport, as far as one GPU can run it: BZH_BENCH_DIST_WORLD1=1 makes
+    the single rank initialise the process group on RCCL (backend "nccl") with the gloo side group beside it and take the
+    sharded path -- broadcast, all_gather, gather, all_reduce and all_gather_into_tensor on device tensors,
+    `encode_sharded` with the chain hand-off over the side group -- and the stream must equal the plain one-GPU encode."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BZH_BENCH_DIST_WORLD1="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "BZH_BENCH_SHARED_GPU"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--cpu-sample", "4000000", "--no-extra", "--bytes", "30000000"], capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["collective_backend"] == "nccl" and line["ranks_seen"] == 1 and len(line["per_rank"]) == 1
+    assert line["checks"]["sharded_equals_single_gpu"] and line["checks"]["libbz2_roundtrip"]
+    assert line["checks"]["bit_exact_vs_oracle_sample"] and all(line["checks"].values())
+    assert line["per_rank"][0]["encoded_input_bytes"] == 30000000
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("extra", [["--bytes", "30000000"], ["--total-bytes", "70000000"]])
 def test_bench_multi_rank_flow_on_one_gpu(extra):
     """`bench.py --gpus 3` end to end on a box with ONE GPU: three real processes, every rank computing on cuda:0, the
