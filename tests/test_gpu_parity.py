@@ -881,6 +881,32 @@ def test_full_size_headline_bit_exact_vs_oracle(oracle, native):
         assert d_out[:ln].cpu().numpy().tobytes() == want
 
 
+def test_full_size_other_workloads_bit_exact_vs_oracle(oracle, native):
+    """every other workload of the bench line at the size bench.py runs it -- BASELINE config 5 as its four 25 MB quarters
+    (zeros, a 1,024-byte tile, "ab", runs around 255), the corpora taken from the image (Python sources, shared libraries,
+    100 MB of real text) -- whole streams against the oracle (which runs on a thread per workload: the C library releases
+    the GIL).  Corpora the box does not hold are skipped one by one."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from banzai_amd import corpus
+    sets = [(name, data) for name, data in corpus.c5_parts(100_000_000)]
+    sets += [(name, corpus.image_corpus(name)) for name in corpus.IMAGE_SETS]
+    sets = [(name, np.ascontiguousarray(data)) for name, data in sets if data.size >= 1_000_000]
+    assert len(sets) >= 4
+    with ThreadPoolExecutor(max_workers=len(sets)) as pool:
+        wants = [pool.submit(oracle.encode, data.tobytes(), 9) for _, data in sets]
+        with native.Context(0, 9, 128) as ctx:
+            for (name, data), want in zip(sets, wants):
+                n = int(data.size)
+                d_in = torch.zeros(n + 16, dtype=torch.uint8, device="cuda")
+                d_in[:n] = torch.from_numpy(data).cuda()
+                cap = (n + n // 4 + (1 << 20)) & ~3
+                d_out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+                ln = ctx.encode_device(d_in.data_ptr(), n, d_out.data_ptr(), cap)
+                assert d_out[:ln].cpu().numpy().tobytes() == want.result(), name
+                del d_in, d_out
+
+
 @pytest.mark.parametrize("init", ["msd", "lsd"])
 def test_both_initial_sorts(native, init):
     """the bucket-first initial sort of bwt_msd.h (the default for text-like blocks) and the 8-pass sort forced on every
