@@ -123,9 +123,8 @@ constexpr u64 LIST_INVALID = ~0ull; // list slot without an unresolved suffix
 // XCD-aware workgroup -> (bzip2 block, tile) map.  Workgroups are dealt round-robin over the 8
 // XCDs (observed dispatch behaviour, used for speed only): ids congruent mod 8 share an XCD and
 // its private 4 MiB L2.  All tiles of the k-th listed block get ids = k (mod 8).  Grid = 8*ceil(NB/8)*T.
-// With few blocks that would leave XCDs idle or unevenly loaded (a single block would run on 32 of the
-// 256 CUs; 28 blocks give four XCDs a third more work than the others): launches that expect fewer than 32
-// blocks set WG_SPREAD in T and get the plain
+// With very few blocks that would leave XCDs idle (a single block would run on 32 of the 256 CUs): launches over
+// fewer than 6 blocks (few_blocks below) set WG_SPREAD in T and get the plain
 // mapping, consecutive workgroup ids = consecutive tiles of one block, i.e. every block on all XCDs.
 // Either way tile t-1 of a block has a lower workgroup id than tile t (the look-backs rely on it).
 constexpr uint32_t WG_SPREAD = 0x80000000u;
@@ -147,6 +146,17 @@ __device__ __forceinline__ bool wg_map(uint32_t T, const Lst &l, uint32_t &b, ui
     if (k >= nb) return false;
     b = l.ids ? l.ids[k] : k;
     return true;
+}
+
+// Which launches spread: those over fewer than 6 blocks.  Pinned, a block's rank array, lists and output stay in ONE
+// XCD's L2 (the random 4-byte gathers and stores of the rounds, the one-byte scatter of bwt_emit: 177 -> 78 us for 16
+// blocks), which outweighs idle XCDs from 6 blocks on -- whole encodes of 6 / 8 / 16 / 24 / 31 text blocks 2.21 / 2.42 /
+// 3.09 / 3.73 / 4.38 ms spread against 2.14 / 2.27 / 2.87 / 3.38 / 3.94 ms pinned, 5 blocks the same, 4 blocks 1.73
+// against 1.82 ms.  (BZH_SPREAD_MAX moves the limit: A/B timing.)
+static inline bool few_blocks(uint32_t NB)
+{
+    static const uint32_t lim = getenv("BZH_SPREAD_MAX") ? (uint32_t)atoi(getenv("BZH_SPREAD_MAX")) : 6u;
+    return NB < lim;
 }
 
 static inline uint32_t xcd_grid(uint32_t tiles, uint32_t NB)
@@ -1921,7 +1931,7 @@ static void launch_pass(bzh_ctx *ctx, SortArgs &a, uint32_t NB, uint32_t maxcnt)
 {
     const uint32_t tiles = (maxcnt + SORT_TILE - 1) / SORT_TILE;
     if (tiles == 0 || NB == 0) return;
-    a.T = tiles | ((NB < 32 && !ctx->no_spread) ? WG_SPREAD : 0u); // (look-back: see bwt_run on no_spread)
+    a.T = tiles | ((few_blocks(NB) && !ctx->no_spread) ? WG_SPREAD : 0u); // (look-back: see bwt_run on no_spread)
     a.pass++;
     radix_scatter<BITS, MODE><<<dim3(xcd_grid(a.T, NB)), SORT_THREADS, 0, ctx->stream>>>(a);
     if (ctx->profiling) ctx->stats.bwt_sort_launches++; // every launch issued, also the ones that find their list empty
@@ -1984,7 +1994,7 @@ static void launch_refine(bzh_ctx *ctx, RefineArgs &r, uint32_t NB, uint32_t max
 {
     const uint32_t tiles = (maxcnt + SORT_TILE - 1) / SORT_TILE;
     if (tiles == 0 || NB == 0) return;
-    r.T = tiles | ((NB < 32 && !ctx->no_spread) ? WG_SPREAD : 0u);
+    r.T = tiles | ((few_blocks(NB) && !ctx->no_spread) ? WG_SPREAD : 0u);
     flag_tiles<<<dim3(xcd_grid(r.T, NB)), SORT_THREADS, 0, ctx->stream>>>(r);
     flag_carry<<<dim3(NB), 1024, 0, ctx->stream>>>(r);
     refine<<<dim3(xcd_grid(r.T, NB)), SORT_THREADS, 0, ctx->stream>>>(r);
@@ -2042,7 +2052,7 @@ static void launch_refine_one(bzh_ctx *ctx, RefineArgs &r, uint32_t NB, uint32_t
 {
     const uint32_t tiles = (maxcnt + SORT_TILE - 1) / SORT_TILE;
     if (tiles == 0 || NB == 0) return;
-    r.T = tiles | ((NB < 32 && !ctx->no_spread) ? WG_SPREAD : 0u);
+    r.T = tiles | ((few_blocks(NB) && !ctx->no_spread) ? WG_SPREAD : 0u);
     refine_one<INIT><<<dim3(xcd_grid(r.T, NB)), SORT_THREADS, 0, ctx->stream>>>(r, ctx->bt.c_groups, recs);
 }
 
@@ -2379,7 +2389,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         a.cnt = bt.gateA;
         a.src = cur;
         a.dst = oth;
-        a.T = gt | (nA < 32 ? WG_SPREAD : 0u);
+        a.T = gt | (few_blocks(nA) ? WG_SPREAD : 0u);
         {
             KSpan ks(ctx, K_ACTIVE_GEN, 0, 2);
             active_gen<<<dim3(xcd_grid(a.T, nA)), SORT_THREADS, 0, sa>>>(a, bt.dtot);
@@ -2410,7 +2420,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         const uint32_t tt = (maxT + TR_T - 1) / TR_T;
         if (!nT || !tt) return;
         KSpan ks(ctx, K_TAIL_ROUND, 0, nQ ? 2 : 1);
-        ta.T = tt | (nT < 32 ? WG_SPREAD : 0u);
+        ta.T = tt | (few_blocks(nT) ? WG_SPREAD : 0u);
         ta.tag = a.tag;
         ta.lst = Lst{actP, bt.nlist + L_P, B};
         tail_round<false><<<dim3(xcd_grid(ta.T, nT)), TR_THREADS, 0, st>>>(ta);
@@ -2554,12 +2564,12 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     }
     if (err) HIP_TRY(ctx, bzh_stream_wait(st)); // (what was queued behind the faulty kernel ends before the error is reported)
     // A look-back that gave up although nothing was injected: seen only when several PROCESSES compute on this GPU at once
-    // and the batch is small.  With fewer than 32 blocks a block's tiles are dealt over all XCDs, so a tile may wait for a
+    // and the batch is small.  With fewer than 6 blocks (few_blocks; fewer than 32 when this was seen) a block's tiles are dealt over all XCDs, so a tile may wait for a
     // predecessor that is still queued on another XCD -- whose slots another process's workgroups hold, waiting in the same
     // way for tiles queued behind ours.  Blocks pinned to one XCD each (the mapping of larger batches) only ever wait for
     // workgroups that are resident already.  The sort starts from bt.rle and re-initialises everything it uses, so it is
     // simply run again with that mapping, which this context then keeps.
-    if ((err & 2u) && !(err & ~2u) && !had_fault && !ctx->no_spread && B < 32u) {
+    if ((err & 2u) && !(err & ~2u) && !had_fault && !ctx->no_spread && few_blocks(B)) {
         ctx->no_spread = true;
         static const bool say = getenv("BZH_TRACE_ROUNDS") != nullptr;
         if (say) fprintf(stderr, "[bzhip] a look-back gave up: the suffix sort runs again with every block on one XCD\n");
@@ -2580,7 +2590,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     uint32_t gx = (nmax + 1023) / 1024;
     if (gx > 256) gx = 256;
     if (gx == 0) gx = 1;
-    if (B < 32) gx |= WG_SPREAD;
+    if (few_blocks(B)) gx |= WG_SPREAD;
     KSpan ks(ctx, K_BWT_EMIT, 6 * ntotal);
     bwt_emit<<<dim3(xcd_grid(gx, B)), 256, 0, st>>>(bt, gx, B);
     HIP_TRY(ctx, hipGetLastError());

@@ -1099,7 +1099,7 @@ static int msd_initial_sort(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t nt
     if (!force_old) {
         const Lst nl{bt.ms_new, bt.ms_cnt + MC_NEW, B};
         const uint32_t tiles = (nmax + MS_TILE - 1) / MS_TILE;
-        const uint32_t T = tiles | (B < 32 ? WG_SPREAD : 0u);
+        const uint32_t T = tiles | (few_blocks(B) ? WG_SPREAD : 0u);
         {
             KSpan ks(ctx, K_MSD_SCATTER, 9 * ntotal);
             bigram_scatter<<<dim3(xcd_grid(T, B)), MS_THREADS, 0, st>>>(m, T, nl);

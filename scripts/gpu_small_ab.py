@@ -7,8 +7,8 @@ import numpy as np, torch
 from banzai_amd import _native as nv, corpus
 dev = torch.device("cuda", 0)
 ctx = nv.Context(0, 9, 128)
-text = corpus.workload(16_000_000)[0]
-sets = [(f"text x{k}", text[:k * 890_000]) for k in (1, 2, 4, 8, 16)] + [("random x1", corpus.xorshift_bytes(899_999))]
+text = corpus.workload(32_000_000)[0]
+sets = [(f"text x{k}", text[:k * 890_000]) for k in [int(x) for x in os.environ.get("BZH_AB_BLOCKS", "1,2,4,8,16").split(",")]] + [("random x1", corpus.xorshift_bytes(899_999))]
 for name, data in sets:
     n = int(data.size)
     d_in = torch.zeros(n + 16, dtype=torch.uint8, device=dev); d_in[:n] = torch.from_numpy(np.array(data, dtype=np.uint8, copy=True)).to(dev)
