@@ -2564,12 +2564,12 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     }
     if (err) HIP_TRY(ctx, bzh_stream_wait(st)); // (what was queued behind the faulty kernel ends before the error is reported)
     // A look-back that gave up although nothing was injected: seen only when several PROCESSES compute on this GPU at once
-    // and the batch is small.  With fewer than 6 blocks (few_blocks; fewer than 32 when this was seen) a block's tiles are dealt over all XCDs, so a tile may wait for a
-    // predecessor that is still queued on another XCD -- whose slots another process's workgroups hold, waiting in the same
+    // and a launch covers few blocks (few_blocks: fewer than 6; fewer than 32 when this was seen).  Their tiles are dealt over
+    // all XCDs, so a tile may wait for a predecessor that is still queued on another XCD -- whose slots another process's workgroups hold, waiting in the same
     // way for tiles queued behind ours.  Blocks pinned to one XCD each (the mapping of larger batches) only ever wait for
     // workgroups that are resident already.  The sort starts from bt.rle and re-initialises everything it uses, so it is
     // simply run again with that mapping, which this context then keeps.
-    if ((err & 2u) && !(err & ~2u) && !had_fault && !ctx->no_spread && few_blocks(B)) {
+    if ((err & 2u) && !(err & ~2u) && !had_fault && !ctx->no_spread) { // (late rounds of a large batch also launch over few blocks)
         ctx->no_spread = true;
         static const bool say = getenv("BZH_TRACE_ROUNDS") != nullptr;
         if (say) fprintf(stderr, "[bzhip] a look-back gave up: the suffix sort runs again with every block on one XCD\n");
