@@ -1453,7 +1453,7 @@ __global__ void __launch_bounds__(TR_THREADS) tail_round(TailArgs a)
 #pragma unroll
         for (int k = 0; k < TR_PER; k++) {
             const uint32_t w = k * TR_THREADS + threadIdx.x;
-            x[k] = w < nwin ? src[s_lo + w] : LIST_INVALID;
+            x[k] = w < nwin ? __builtin_nontemporal_load(src + s_lo + w) : LIST_INVALID; // (read once: the L2 is for the rank array)
             xp[k] = 0; // the record before my wavefront's 64 slots (lane 0 compares with it)
             if (lane == 0 && w > 0 && w <= nwin) xp[k] = src[s_lo + w - 1];
         }
@@ -1583,7 +1583,7 @@ __global__ void __launch_bounds__(TR_THREADS) tail_round(TailArgs a)
 #pragma unroll
     for (int k = 0; k < TR_PER; k++) {
         const uint32_t off = (uint32_t)__shfl((int)ex, k * NWV + (int)wave, 64);
-        if (x[k] != LIST_INVALID) dst[pre + off + lo[k]] = x[k];
+        if (x[k] != LIST_INVALID) __builtin_nontemporal_store(x[k], dst + pre + off + lo[k]);
     }
 }
 
@@ -1611,7 +1611,8 @@ __global__ void __launch_bounds__(256) bwt_emit(Batch bt, uint32_t T, uint32_t B
         uint8_t c[4];
         const uint32_t m = min(4u, n - i0);
         if (m == 4) { // (4 | i0, and rslot keeps the low five bits: the four slots are adjacent)
-            const uint4 rv = *reinterpret_cast<const uint4 *>(rank + rslot(i0));
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 rv = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rank + rslot(i0))); // (read once: the L2 is for the output)
             r[0] = rv.x;
             r[1] = rv.y;
             r[2] = rv.z;
