@@ -29,6 +29,13 @@ def _ctx(level, device=0):
     return _ctx_cache[key]
 
 
+def _copying_sink(writer):
+    """True for the writers that are known to copy what write() is handed before it returns (in-memory and real files):
+    only they may be given a VIEW of the context's output buffer, which the next feed overwrites.  Any other writer -- a
+    list's append, a queue, a transport -- may keep the object, so it gets its own bytes."""
+    return isinstance(writer, (io.BytesIO, io.BufferedWriter, io.BufferedRandom, io.FileIO))
+
+
 def encode(reader, writer, level, device=0):
     """bzip2-encode everything `reader` yields and write the stream to `writer`.
 
@@ -38,6 +45,7 @@ def encode(reader, writer, level, device=0):
     if isinstance(level, bool) or not isinstance(level, int) or not 1 <= level <= 9:
         raise ValueError("level must be in 1..=9")
     ctx = _ctx(level, device)
+    put = writer.write if _copying_sink(writer) else (lambda view: writer.write(bytes(view)))
     # incremental ingestion (the reference pulls from fill_buf as it goes, lib/rle.rs:30-92): input is
     # handed to the GPU in chunks, finished stream bytes are written as soon as they are final
     ctx.stream_begin()
@@ -53,7 +61,7 @@ def encode(reader, writer, level, device=0):
             out = ctx.stream_feed_view(view[pos:pos + k], k == 0)
             pos += k
             if len(out):
-                writer.write(out)
+                put(out)
             if k == 0:
                 break
         reader.seek(pos)
@@ -61,7 +69,7 @@ def encode(reader, writer, level, device=0):
             writer.flush()
         return ctx.stream_consumed()
     # one reusable buffer: a reader with readinto() fills it in place (no bytes object per chunk); finished stream
-    # bytes go to the writer as a view of the context's output buffer (no copy on this side either)
+    # bytes go to a copying sink (BytesIO, a real file) as a view of the context's output buffer, to any other writer as bytes
     buf = bytearray(READ_CHUNK) if hasattr(reader, "readinto") else None
     while True:
         chunk = None
@@ -81,7 +89,7 @@ def encode(reader, writer, level, device=0):
         eof = len(chunk) == 0
         out = ctx.stream_feed_view(chunk, eof)
         if len(out):
-            writer.write(out)
+            put(out)
         if eof:
             break
     if hasattr(writer, "flush"):

@@ -1480,14 +1480,20 @@ extern "C" int bzh_stream_feed(bzh_ctx *ctx, const uint8_t *in, size_t n, int eo
     } done[2];
     int ndone = 0;
     // the finished passes' words: device -> the caller's buffer (called with the next pass already running)
+    // (A failure here loses words whose bits are already counted in bitpos / carry_word / stream_crc: the stream cannot go
+    // on -- later feeds get BZH_E_STATE, not a stream with a hole.)
     auto drain = [&]() -> int {
-        for (int k = 0; k < ndone; k++) {
-            HIP_TRY(ctx, hipMemcpyAsync(out + opos, s.d_out[done[k].obuf], done[k].bytes, hipMemcpyDeviceToHost, s.copy_stream));
-            opos += done[k].bytes;
-        }
-        if (ndone) HIP_TRY(ctx, bzh_stream_wait(s.copy_stream));
+        const int rc = [&]() -> int {
+            for (int k = 0; k < ndone; k++) {
+                HIP_TRY(ctx, hipMemcpyAsync(out + opos, s.d_out[done[k].obuf], done[k].bytes, hipMemcpyDeviceToHost, s.copy_stream));
+                opos += done[k].bytes;
+            }
+            if (ndone) HIP_TRY(ctx, bzh_stream_wait(s.copy_stream));
+            return BZH_OK;
+        }();
         ndone = 0;
-        return BZH_OK;
+        if (rc != BZH_OK) s.active = false;
+        return rc;
     };
     auto collect = [&]() -> int {
         stream_join(ctx);

@@ -386,6 +386,26 @@ __global__ void __launch_bounds__(256) active_bases(uint32_t *dtot, uint32_t *db
     }
 }
 
+// A look-back waits for a predecessor that is resident or about to be: no legitimate wait is longer than one kernel
+// (about a millisecond).  The wait is bounded by TIME, not by a spin count (2^26 sleeps were 16 seconds): the constant
+// 100 MHz clock (s_memrealtime) is read every 64th idle spin; LOOK_TICKS = 20 ms, then the caller raises bit 1 of the
+// error word and bwt_run starts over with every block pinned to one XCD.
+constexpr unsigned long long LOOK_TICKS = 2000000ull, LOOK_TICKS_FAULT = 100000ull; // (injected faults: 1 ms)
+struct LookWait {
+    unsigned long long t0 = 0;
+    uint32_t spins = 0;
+    __device__ __forceinline__ bool expired(unsigned long long budget = LOOK_TICKS)
+    {
+        if ((++spins & 63u) != 0u) return false;
+        const unsigned long long now = wall_clock64();
+        if (t0 == 0) {
+            t0 = now | 1ull;
+            return false;
+        }
+        return now - t0 > budget;
+    }
+};
+
 constexpr uint32_t LOOK_LOCAL = 1u, LOOK_GLOBAL = 2u;
 __device__ __forceinline__ u64 look_word(uint32_t pass, uint32_t state, uint32_t count)
 {
@@ -409,7 +429,7 @@ __device__ __forceinline__ uint32_t lookback_wave(u64 *st, uint32_t tile, uint32
     if (tile > 0) {
         if (lane == 0 && !published) __hip_atomic_store(st + tile, look_word(pass, LOOK_LOCAL, own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int t = (int)tile - 1; // nearest predecessor not yet summed
-        uint32_t spins = 0;
+        LookWait lw;
         for (;;) {
             const int idx = t - lane;
             u64 w = look_word(pass, LOOK_GLOBAL, 0u); // before tile 0: a known prefix of nothing
@@ -425,7 +445,7 @@ __device__ __forceinline__ uint32_t lookback_wave(u64 *st, uint32_t tile, uint32
             if (gl) break;
             t -= first_nr;
             if (first_nr == 0) {
-                if (++spins > (1u << 24)) { // seconds: only a logic error gets here
+                if (lw.expired()) { // 20 ms: only a logic error or a shared GPU gets here
                     if (lane == 0) atomicOr(err, 2u);
                     break;
                 }
@@ -626,13 +646,14 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
     if (threadIdx.x < NB) { // look back for the counts of digit `bin` in tiles 0 .. tile-1
         const uint32_t bin = threadIdx.x;
         u64 *col = a.look + (size_t)b * a.TPB * NBMAX + bin;
-        uint32_t acc = 0, spins = 0;
+        uint32_t acc = 0;
+        LookWait lw;
         int t = (int)tile - 1;
         while (t >= 0) {
             const u64 w = __hip_atomic_load(col + (size_t)t * NBMAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t state = (uint32_t)(w >> 30) & 3u;
             if ((uint32_t)(w >> 32) != a.pass || state == 0) { // predecessor has not published yet
-                if (++spins > (a.fault ? 1u << 14 : 1u << 26)) { // seconds: only a logic error gets here
+                if (lw.expired(a.fault ? LOOK_TICKS_FAULT : LOOK_TICKS)) { // only a logic error or a shared GPU gets here
                     atomicOr(a.err, 2u);
                     break;
                 }
@@ -919,14 +940,15 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     stage_tile(a.list + base, tile0, cnt, lds);
     if (threadIdx.x == 0) {
-        uint32_t accS = 0, accB = 0, spins = 0;
+        uint32_t accS = 0, accB = 0;
+        LookWait lw;
         if (tile > 0) {
             int t = (int)tile - 1;
             while (t >= 0) {
                 const u64 w = __hip_atomic_load(cst + (size_t)t * NBMAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t state = (uint32_t)(w >> 42) & 3u;
                 if ((uint32_t)(w >> 44) != (a.cpass & 0xFFFFFu) || state == 0) {
-                    if (++spins > (1u << 26)) {
+                    if (lw.expired()) {
                         atomicOr(a.err, 2u);
                         break;
                     }
@@ -1082,7 +1104,7 @@ __device__ __forceinline__ void carry_lookback(u64 *st, uint32_t tile, uint32_t 
         if (lane == 0) __hip_atomic_store(st + (size_t)tile * 2, look2_word(pass, LOOK_LOCAL, egs, ebd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bool hg = !need_gs, hb = false;
         int t = (int)tile - 1;
-        uint32_t spins = 0;
+        LookWait lw;
         for (;;) {
             const int idx = t - lane;
             u64 w = look2_word(pass, LOOK_GLOBAL, 0u, 0u); // before tile 0: nothing
@@ -1111,7 +1133,7 @@ __device__ __forceinline__ void carry_lookback(u64 *st, uint32_t tile, uint32_t 
             if (hb && hg) break;
             t -= first_nr;
             if (first_nr == 0) {
-                if (++spins > (1u << 24)) { // seconds: only a logic error gets here
+                if (lw.expired()) {
                     if (lane == 0) atomicOr(err, 2u);
                     break;
                 }
@@ -1347,13 +1369,14 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
     if (threadIdx.x < 256) {
         const uint32_t bin = threadIdx.x;
         u64 *col = a.cstat + (size_t)b * a.TPB * NBMAX + bin;
-        uint32_t acc = 0, spins = 0;
+        uint32_t acc = 0;
+        LookWait lw;
         int t = (int)tile - 1;
         while (t >= 0) {
             const u64 w = __hip_atomic_load(col + (size_t)t * NBMAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t state = (uint32_t)(w >> 30) & 3u;
             if ((uint32_t)(w >> 32) != a.bpass || state == 0) { // predecessor has not published yet
-                if (++spins > (1u << 26)) { // seconds: only a logic error gets here
+                if (lw.expired()) {
                     atomicOr(a.err, 2u);
                     break;
                 }
@@ -2065,6 +2088,12 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     if (B == 0) return BZH_OK;
     hipStream_t st = ctx->stream;
     const uint32_t mb = ctx->max_batch;
+    // (what a retry must not count twice: see the look-back retry at the end)
+    const bzh_stats stats_in = ctx->stats;
+    const size_t spans_in = ctx->sort_spans.size(), kspans_in = ctx->kspans.size();
+    uint64_t kb_in[K_COUNT], kl_in[K_COUNT];
+    memcpy(kb_in, ctx->k_bytes, sizeof kb_in);
+    memcpy(kl_in, ctx->k_launch, sizeof kl_in);
     u64 *bufA = reinterpret_cast<u64 *>(bt.listA), *bufB = reinterpret_cast<u64 *>(bt.listB);
     u64 *bufC = reinterpret_cast<u64 *>(bt.listC), *bufD = reinterpret_cast<u64 *>(bt.listD);
     const Lst all{nullptr, nullptr, B};
@@ -2570,8 +2599,15 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     // way for tiles queued behind ours.  Blocks pinned to one XCD each (the mapping of larger batches) only ever wait for
     // workgroups that are resident already.  The sort starts from bt.rle and re-initialises everything it uses, so it is
     // simply run again with that mapping, which this context then keeps.
-    if ((err & 2u) && !(err & ~2u) && !had_fault && !ctx->no_spread) { // (late rounds of a large batch also launch over few blocks)
+    // (Whatever else the kernels behind the give-up reported -- they ran on garbage lists -- does not matter: the sort
+    // restarts from bt.rle and clears the error word.)
+    if ((err & 2u) && !had_fault && !ctx->no_spread) { // (late rounds of a large batch also launch over few blocks)
         ctx->no_spread = true;
+        ctx->stats = stats_in; // the abandoned attempt is not counted
+        ctx->sort_spans.resize(spans_in);
+        ctx->kspans.resize(kspans_in);
+        memcpy(ctx->k_bytes, kb_in, sizeof kb_in);
+        memcpy(ctx->k_launch, kl_in, sizeof kl_in);
         static const bool say = getenv("BZH_TRACE_ROUNDS") != nullptr;
         if (say) fprintf(stderr, "[bzhip] a look-back gave up: the suffix sort runs again with every block on one XCD\n");
         return bwt_run(ctx, B, nmax, ntotal);

@@ -90,3 +90,21 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 assert "pyoracle" not in src and "banzai_oracle" not in src and "from oracle" not in src, f
+
+
+def test_encode_hands_views_only_to_copying_sinks(tmp_path):
+    """banzai_amd.encode passes a view of its reusable output buffer to BytesIO / real files only; any other writer may
+    retain the object and gets bytes (tests/test_gpu_parity.py::test_public_api_retaining_writer runs it on the GPU)"""
+    import io
+    import banzai_amd
+    assert banzai_amd._copying_sink(io.BytesIO())
+    with open(tmp_path / "f", "wb") as f:
+        assert banzai_amd._copying_sink(f)
+    with open(tmp_path / "g", "wb", buffering=0) as f:
+        assert banzai_amd._copying_sink(f)
+
+    class Keeper:
+        def write(self, b):
+            return len(b)
+    assert not banzai_amd._copying_sink(Keeper())
+    assert not banzai_amd._copying_sink([].append)

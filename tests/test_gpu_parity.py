@@ -736,6 +736,26 @@ def test_streaming_public_api_chunked_reader(oracle):
     assert w.getvalue() == oracle.encode(d, 9)
 
 
+def test_public_api_retaining_writer(oracle):
+    """A writer that KEEPS what write() is handed (a list sink, a queue, a transport) must not see its pieces change
+    under it: encode() hands the context's reusable output buffer only to sinks known to copy (BytesIO, real files)."""
+    import banzai_amd
+
+    class Keeper:  # several feeds with output each: level 1, 16 MiB reads over 40 MB
+        def __init__(self):
+            self.parts = []
+
+        def write(self, b):
+            self.parts.append(b)
+            return len(b)
+
+    d = cases.gen(40_000_000, "text", 23)
+    k = Keeper()
+    assert banzai_amd.encode(io.BytesIO(d), k, 1) == len(d)
+    assert len(k.parts) >= 2 and all(isinstance(p, bytes) for p in k.parts)
+    assert b"".join(k.parts) == oracle.encode(d, 1)
+
+
 def test_near_periodic_blocks_vs_oracle(oracle, ctx9):
     """BASELINE config 5, the near-periodic part: a word repeated and cut off inside a repetition (periods 2, 3, 1024,
     4099; lengths 899,999 / 899,998 / 450,000), plus words whose own structure mixes phases in the early groups, words
