@@ -129,17 +129,17 @@ static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
     carve(p, bt.dtot, NB * DB_STRIDE);
     carve(p, bt.flg, NB * S);
     carve(p, bt.tagg, NB * bt.TPB);
-    { // round state of the suffix sort: 21 words per block, contiguous (one memset clears it)
+    { // round state of the suffix sort: RS_ROWS words per block, contiguous (one memset clears it)
         uint32_t *rs = nullptr;
-        const size_t oA = (21 * NB + 8 + SUMMARY_WORDS + 1) & ~(size_t)1; // 64-bit counter: even word index
+        const size_t oA = (RS_ROWS * NB + 8 + SUMMARY_WORDS + 1) & ~(size_t)1; // 64-bit counter: even word index
         carve(p, rs, oA + 4);
-        uint32_t **f[21] = {&bt.st_mode, &bt.st_h, &bt.st_nbig, &bt.st_ntail, &bt.c_big, &bt.c_small, &bt.c_tail,
-                            &bt.c_prog, &bt.gateS, &bt.gateA, &bt.gateR, &bt.gateT, &bt.actS, &bt.actA, &bt.actR,
-                            &bt.actT, &bt.actQ, nullptr, &bt.c_nolist, &bt.c_groups, &bt.scratch}; // row 17: sixth list (bwt.hip)
-        for (int k = 0; k < 21; k++)
+        uint32_t **f[RS_ROWS] = {&bt.st_mode, &bt.st_h, &bt.st_nbig, &bt.st_ntail, &bt.c_big, &bt.c_small, &bt.c_tail,
+                                 &bt.c_prog, &bt.gateS, &bt.gateA, &bt.gateR, &bt.gateT, &bt.actS, &bt.actA, &bt.actR,
+                                 &bt.actT, &bt.actQ, nullptr, &bt.c_nolist, &bt.c_groups, &bt.scratch, &bt.st_tdst}; // row 17: sixth list (bwt.hip)
+        for (int k = 0; k < RS_ROWS; k++)
             if (f[k]) *f[k] = rs ? rs + (size_t)k * NB : nullptr;
-        bt.nlist = rs ? rs + 21 * NB : nullptr;
-        bt.summary = rs ? rs + 21 * NB + 8 : nullptr;
+        bt.nlist = rs ? rs + RS_ROWS * NB : nullptr;
+        bt.summary = rs ? rs + RS_ROWS * NB + 8 : nullptr;
         bt.stat_A = rs ? reinterpret_cast<unsigned long long *>(rs + oA) : nullptr;
     }
     carve(p, bt.chain, NB * 4);

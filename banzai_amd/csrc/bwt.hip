@@ -689,7 +689,8 @@ struct RefineArgs {
     const uint32_t *cnt; // [B] length of the sorted list (n for the init pass)
     const u64 *list;     // [B][S] sorted elements
     u64 *big;            // [B][S] the block's OTHER list buffer: receives the suffixes of large groups, compacted, in order
-    u64 *tail;           // [B][S] the block's small-group list: receives the suffixes of small groups behind `tbase`
+    u64 *tail0, *tail1;  // [B][S] the two small-group list buffers; the block's records of this round go to the one
+    const uint32_t *tdst; // [B]   st_tdst names (behind `tbase`)
     const uint32_t *tbase; // [B] records already in the small-group list (SPLIT-mode blocks; survivors of this round)
     uint32_t *mode;        // [B] st_mode (flag_carry of the init pass decides the first mode)
     u64 *cstat;          // tile status words of the compaction's look-back (word 192 of the tile's hist row)
@@ -977,7 +978,7 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
     uint32_t *sa = a.sa + base;
     uint32_t *headp = a.headp + base;
     u64 *big = a.big + base;
-    u64 *tail = a.tail + base;
+    u64 *tail = (a.tdst[b] ? a.tail1 : a.tail0) + base;
     __shared__ uint32_t dh[384];
     if (sweep) {
         for (int k = threadIdx.x; k < 384; k += SORT_THREADS) dh[k] = 0;
@@ -1347,7 +1348,7 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
     __syncthreads();
     {
         const uint32_t tbase = INIT ? 0u : a.tbase[b];
-        u64 *ts = a.tail + base + tbase + s_offS;
+        u64 *ts = (a.tdst[b] ? a.tail1 : a.tail0) + base + tbase + s_offS;
         u64 *bs = a.big + base + s_offB;
         const uint32_t nSm = totS + nH;
         for (uint32_t e = threadIdx.x; e < nSm; e += SORT_THREADS) ts[e] = lds[e];
@@ -1427,8 +1428,8 @@ static_assert(TAIL_G <= 64, "the rank word keeps a 6-bit displacement");
 struct TailArgs {
     const uint32_t *n;   // [B]
     const uint32_t *len; // [B] slot count of the block's list this round
-    u64 *src;            // [B][S] the lists as the round finds them (read only)
-    u64 *dst;            // [B][S] the survivors, compacted
+    u64 *buf0, *buf1;    // [B][S] the two list buffers: a block's survivors go, compacted, to the one st_tdst names;
+    const uint32_t *tdst; // [B]   the round finds the block's list in the other one (read only)
     uint32_t *rank;      // [B][S]
     uint32_t *c_tail;    // [B] survivors of the round
     uint32_t *c_prog;    // [B] "a group was refined"
@@ -1455,8 +1456,9 @@ __global__ void __launch_bounds__(TR_THREADS) tail_round(TailArgs a)
     const uint32_t nwin = s_hi - s_lo; // <= TR_W
     const uint32_t n = a.n[b], h = a.hb[b], tag = a.tag;
     const size_t base = (size_t)b * a.S;
-    const u64 *src = a.src + base;
-    u64 *dst = a.dst + base;
+    const uint32_t td = a.tdst[b];
+    const u64 *src = (td ? a.buf0 : a.buf1) + base;
+    u64 *dst = (td ? a.buf1 : a.buf0) + base;
     uint32_t *rank = a.rank + base;
     constexpr int NWV = TR_THREADS / 64, ROWS = TR_W / 64;
     typedef typename std::conditional<QUAD, u64, uint32_t>::type key_t; // the 4h form packs three 20-bit ranks
@@ -1814,7 +1816,7 @@ __global__ void __launch_bounds__(1024) period_probe(ProbeArgs a)
 // c_tail, c_prog; after the initial refine: `first`), decides every block's mode and depth, builds this
 // round's work lists and gates, clears the counters and the digit totals of the blocks on the big-list
 // path, and writes the summary the host reads one round late.
-// summary words: 0 round, 1 nS, 2 nA, 3 nT, 4 nQ, 5 maxS, 6 maxA, 7 maxT, 8/9 total unresolved (lo/hi),
+// summary words: 0 round, 1 nS, 2 nA, 3 nT, 4 nQ, 5 maxS, 6 maxA, 7 maxT, 8 total unresolved, 9 of them sitting the round out,
 //                10/11 sum of the S lists, 12/13 sum of the A lists, 14 error flag, 15 largest depth in use,
 //                16 S blocks whose refine writes lists this round (the only ones that can leave SWEEP mode next round),
 //                17/18 sum over the rounds so far of the unresolved suffixes entering them, 19 sequence word (last)
@@ -1824,14 +1826,16 @@ __global__ void __launch_bounds__(1024) period_probe(ProbeArgs a)
 constexpr uint32_t QUAD_BIT = 0x80000000u; // in st_ntail-derived gates: this round runs at depth x4
 enum ListId : int { L_S = 0, L_A = 1, L_R = 2, L_T = 3, L_Q = 4, L_P = 5 };
 
-__global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32_t round, uint32_t *actP, uint32_t *hsum, uint32_t seq, uint32_t sweep_div)
+__global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32_t round, uint32_t *actP, uint32_t *hsum, uint32_t seq, uint32_t sweep_div,
+                                                    uint32_t r0_fused)
 {
     const uint32_t b = threadIdx.x;
     const bool valid = b < B;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     // per-wavefront partial results: sums (all, S, A, n, sconv), maxima (S, A, T, depth), list counts
-    __shared__ uint32_t psum[5][16], pmax[4][16], pcnt[6][16];
+    __shared__ uint32_t psum[6][16], pmax[4][16], pcnt[6][16];
     uint32_t gS = 0, gA = 0, gT = 0, h = 0, n = 0, conv = 0;
+    bool sit = false; // the block's small groups sit this round out (below)
     if (valid) {
         // everything this thread needs, loaded at once
         n = bt.n[b];
@@ -1845,6 +1849,17 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
         const bool msd = round == 0 && bt.ms_np[b] != 0u;
         uint32_t mode = round == 0 ? ((!msd && (uint64_t)groups * sweep_div < n) ? 0u : 1u) : mode_in;
         h = round == 0 ? (msd ? 7u : 8u) : h_in; // the initial sort ordered the rotations by their first 8 (7) bytes
+        // A bucket-first block whose small groups chunk_finish has already ordered by bytes 7..14 of their rotations
+        // (bwt_msd.h: the first doubling step, from the text, inside the kernel that found the groups): those groups
+        // stand at depth 15, only the large groups need round 0 (depth 7 -> 14); the small-group list stays where it is
+        // and joins in round 1, whose depth is 14 whatever round 0 did or did not refine (mixed depths are sound: every
+        // rank is a refinement of the order by 7 bytes that agrees with the final order, and a group is only ever
+        // keyed at a depth its members are known to share).
+        const bool fusedblk = r0_fused != 0u && bt.ms_np[b] != 0u;
+        sit = round == 0 && fusedblk;
+        if (round == 1 && fusedblk) {
+            h = h_in << 1;
+        } else
         if (round > 0 && (gR | gTin)) { // the block had work in the round before
             const bool wasquad = (gTin & QUAD_BIT) != 0;
             if (!prog && h < n)
@@ -1871,15 +1886,22 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
         bt.gateR[b] = gS | gA; // one of them is 0
         bt.c_big[b] = 0;
         bt.c_small[b] = 0;
-        bt.c_tail[b] = 0;
+        // where the block's small-group records of this round go: tail_round reads the list from the buffer the round
+        // before left it in and writes the survivors to the other one, refine appends behind them; a block without a
+        // tail_round this round keeps its list (and its length: refine appends behind c_tail) where it is
+        const uint32_t loc = round == 0 ? 0u : bt.st_tdst[b];
+        const bool runs = gT != 0u && !sit;
+        bt.st_tdst[b] = runs ? loc ^ 1u : loc;
+        bt.c_tail[b] = sit ? gT : 0u;
         bt.c_prog[b] = 0;
         bt.c_nolist[b] = 0;
     }
+    const uint32_t gTl = sit ? 0u : gT; // what this round's small-group kernels see
     { // (every sum stays below 2^30: at most 1024 blocks of fewer than 2^20 suffixes)
-        const uint32_t v[5] = {gS + gA + gT, gS, gA, n, conv};
+        const uint32_t v[6] = {gS + gA + gT, gS, gA, n, conv, sit ? gT : 0u};
         const uint32_t m[4] = {gS, gA, gT, (gS | gA | gT) ? h : 0u};
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
+        for (int k = 0; k < 6; k++) {
             const uint32_t r = wave_reduce_add(v[k]);
             if (lane == 0) psum[k][wave] = r;
         }
@@ -1892,20 +1914,21 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
         }
     }
     __syncthreads();
-    uint32_t sum[5] = {0, 0, 0, 0, 0}, mx[4] = {0, 0, 0, 0};
+    uint32_t sum[6] = {0, 0, 0, 0, 0, 0}, mx[4] = {0, 0, 0, 0};
     for (uint32_t w = 0; w < nw; w++) {
 #pragma unroll
-        for (int k = 0; k < 5; k++) sum[k] += psum[k][w];
+        for (int k = 0; k < 6; k++) sum[k] += psum[k][w];
 #pragma unroll
         for (int k = 0; k < 4; k++) mx[k] = max(mx[k], pmax[k][w]);
     }
     // a block with small groups only may look three h-blocks ahead (depth 4h, three gathers per suffix):
     // worth it once few suffixes are left -- in the block, or in the whole batch -- when rounds are latency-bound
     const bool few = (uint64_t)gT * QUAD_DIV < n || (uint64_t)sum[0] * QUAD_DIV < sum[3];
-    const uint32_t quad = (valid && gA == 0u && gT != 0u && few && h < (1u << 28)) ? 1u : 0u;
-    if (valid) bt.gateT[b] = gT | (quad ? QUAD_BIT : 0u);
+    const uint32_t quad = (valid && gA == 0u && gTl != 0u && few && h < (1u << 28)) ? 1u : 0u;
+    if (valid) bt.gateT[b] = gTl | (quad ? QUAD_BIT : 0u);
     // order-preserving lists: position = listed blocks in lower lanes + in earlier wavefronts
-    const bool fl[6] = {gS != 0u, gA != 0u, (gS | gA) != 0u, gT != 0u, gT != 0u && quad, gT != 0u && !quad};
+    // (list 3 only counts: blocks that HOLD small groups, sitting out or not -- the host bounds the next round with it)
+    const bool fl[6] = {gS != 0u, gA != 0u, (gS | gA) != 0u, gT != 0u, gTl != 0u && quad, gTl != 0u && !quad};
     uint32_t *dst[6] = {bt.actS, bt.actA, bt.actR, bt.actT, bt.actQ, actP};
     uint32_t pre[6];
 #pragma unroll
@@ -1929,7 +1952,7 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
     }
     if (wave == 0) { // the summary, one word per lane, straight into pinned host memory
         const unsigned long long asum = *bt.stat_A + sum[0]; // unresolved suffixes entering the rounds so far
-        const uint32_t words[SUMMARY_WORDS] = {round,  tot[L_S], tot[L_A], tot[L_T], tot[L_Q], mx[0],  mx[1], mx[2], sum[0], 0u,
+        const uint32_t words[SUMMARY_WORDS] = {round,  tot[L_S], tot[L_A], tot[L_T], tot[L_Q], mx[0],  mx[1], mx[2], sum[0], sum[5],
                                                sum[1], 0u,       sum[2],   0u,       *bt.errflag, mx[3], sum[4], (uint32_t)asum,
                                                (uint32_t)(asum >> 32), 0u};
         uint32_t mine = 0;
@@ -2171,6 +2194,9 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     // does not pay below that: 1 / 2 / 4 / 8 / 16 text blocks 1.56 / 1.62 / 2.08 / 2.55 / 3.07 ms with the buckets, 1.45 / 1.51 /
     // 1.94 / 2.47 / 3.11 ms with the 8 passes, one random block 1.36 / 1.26 ms; BZH_INIT=msd overrides)
     const bool use_msd = ctx->M >= MS_MIN_N && !a.fault && !init_lsd && (B >= 12u || init_msd);
+    // chunk_finish takes the first doubling step of the small groups itself, keyed on the text (BZH_R0=0: A/B timing)
+    static const bool r0_off = getenv("BZH_R0") && !strcmp(getenv("BZH_R0"), "0");
+    const uint32_t r0_fused = (use_msd && !r0_off) ? 1u : 0u;
     uint32_t nOld = B;
     Lst oldl = all;
     u64 *const binned = reinterpret_cast<u64 *>(bt.sa);
@@ -2178,7 +2204,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     volatile uint32_t *const hrec0 = ctx->h_pinned + (size_t)mb * 8 + 64; // [MAX_ROUNDS + 1][SUMMARY_WORDS]
     const uint32_t epoch = (++ctx->bwt_epoch & 0xFFFFFFu) << 6;
     if (use_msd) {
-        BZH_TRY(msd_initial_sort(ctx, B, nmax, ntotal, bufB, bufD, bufA, bufC, binned, false,
+        BZH_TRY(msd_initial_sort(ctx, B, nmax, ntotal, bufB, bufD, bufA, bufC, binned, false, r0_fused,
                                  hrec0 + (size_t)MAX_ROUNDS * SUMMARY_WORDS, epoch + 63u, &nOld, side ? ctx->side_ev[0] : nullptr));
         oldl = Lst{bt.ms_old, bt.ms_cnt + MC_OLD, B};
         a.lst = oldl;
@@ -2242,7 +2268,9 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     r.cnt = bt.n;
     r.list = cur;
     r.big = oth;
-    r.tail = bufC;
+    r.tail0 = bufC;
+    r.tail1 = bufD;
+    r.tdst = bt.st_tdst;
     r.tbase = bt.c_tail;
     r.mode = bt.st_mode;
     r.blk = bt.rle;
@@ -2296,8 +2324,9 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     TailArgs ta{};
     ta.n = bt.n;
     ta.len = bt.st_ntail; // (gateT carries the QUAD bit; the plain length lives here)
-    ta.src = bufC; // the small-group lists move between bufC and bufD, one hop per round that has any
-    ta.dst = bufD;
+    ta.buf0 = bufC; // a block's small-group list moves between bufC and bufD, one hop per round in which it is worked on
+    ta.buf1 = bufD; // (round_begin keeps track per block: st_tdst)
+    ta.tdst = bt.st_tdst;
     ta.rank = bt.rank;
     ta.c_tail = bt.c_tail;
     ta.c_prog = bt.c_prog;
@@ -2458,12 +2487,10 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             ta.lst = Lst{bt.actQ, bt.nlist + L_Q, B};
             tail_round<true><<<dim3(xcd_grid(ta.T, nQ)), TR_THREADS, 0, st>>>(ta);
         }
-        r.tail = ta.dst; // refine appends this round's new small groups behind the survivors
-        std::swap(ta.src, ta.dst);
     };
     auto account = [&](const uint32_t *sm) { // statistics of the round a summary describes
         if (!ctx->profiling) return;
-        const uint64_t tot = (uint64_t)sm[8] | ((uint64_t)sm[9] << 32), eS = (uint64_t)sm[10] | ((uint64_t)sm[11] << 32),
+        const uint64_t tot = (uint64_t)sm[8], eS = (uint64_t)sm[10] | ((uint64_t)sm[11] << 32),
                        eA = (uint64_t)sm[12] | ((uint64_t)sm[13] << 32);
         if (sm[1]) ctx->stats.bwt_sort_elems += 3 * eS;
         if (sm[2]) ctx->stats.bwt_sort_elems += 5 * eA;
@@ -2472,7 +2499,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         ctx->k_bytes[K_ACTIVE_GEN] += eA * 20;                      // record in, re-keyed record out, one rank gather
         ctx->k_bytes[K_RADIX_ROUNDS] += eA * 5 * 16;
         ctx->k_bytes[K_REFINE_ROUNDS] += eA * 20;                   // record in, rank word, list record out
-        ctx->k_bytes[K_TAIL_ROUND] += (tot - eS - eA) * 24;         // record in, key gather, rank word, survivor out
+        ctx->k_bytes[K_TAIL_ROUND] += (tot - eS - eA - sm[9]) * 24; // record in, key gather, rank word, survivor out (not the groups that sit the round out)
         if (sm[0] == 0) ctx->k_bytes[nOld == B ? K_REFINE_INIT : K_MSD_FINISH] += tot * 8; // the list records the initial refinement wrote
     };
 
@@ -2482,12 +2509,12 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         KSpan ks(ctx, K_ROUND_BEGIN, 0);
         round_begin<<<1, (B + 63u) / 64u * 64u, 0, st>>>(bt, B, round, actP,
                                                           const_cast<uint32_t *>(hsum) + (size_t)round * SUMMARY_WORDS, epoch + round + 1u,
-                                                          sweep_div);
+                                                          sweep_div, r0_fused);
         }
         if (round > 1) {
             // the summary of the PREVIOUS round: where every block stood when that round began
             if (const hipError_t we = wait_summary(round - 1, s); we != hipSuccess) return fail_wait(we);
-            const uint64_t total = (uint64_t)s[8] | ((uint64_t)s[9] << 32);
+            const uint64_t total = (uint64_t)s[8];
             err |= s[14];
             if (trace)
                 fprintf(stderr, "[bzhip] round %u h<=%u unresolved=%llu  S blocks=%u (max %u)  A blocks=%u (max %u)  T blocks=%u (quad %u, max %u)\n",
@@ -2518,7 +2545,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             run_A();
             run_T();
             if (const hipError_t we = wait_summary(0, s); we != hipSuccess) return fail_wait(we);
-            const uint64_t total = (uint64_t)s[8] | ((uint64_t)s[9] << 32);
+            const uint64_t total = (uint64_t)s[8];
             err |= s[14];
             if (trace)
                 fprintf(stderr, "[bzhip] round %u h<=%u unresolved=%llu  S blocks=%u (max %u)  A blocks=%u (max %u)  T blocks=%u (quad %u, max %u)\n",

@@ -43,6 +43,7 @@ struct Msd {
     uint32_t *err;
     uint32_t force_old;  // every block keeps the 8-pass path (BZH_INIT=lsd)
     uint32_t force_new;  // no block is kept off the buckets for its share of oversized ones (BZH_INIT=msd)
+    uint32_t fuse;       // chunk_finish also takes the first doubling step of the small groups (round_begin: r0_fused)
     uint32_t dbg;        // timing experiments only (BZH_MSD_DBG): 16 = cycles per phase of chunk_finish
 };
 
@@ -69,18 +70,19 @@ __device__ __forceinline__ uint4 ms_unit(uint32_t b, uint32_t buf, uint32_t unif
 // Counters: 16 bits are enough (a tile holds 8192 elements), two sets: a pass clears the set of the NEXT pass while it
 // ranks, so a pass costs three barriers (the first pass of a tile needs `cur` cleared by the caller).
 typedef uint16_t MsCnt[MS_NW][256];
-__device__ __forceinline__ void ms_clear(MsCnt &c)
+__device__ __forceinline__ void ms_clear(MsCnt &c, uint32_t tid)
 {
-    reinterpret_cast<uint2 *>(&c[0][0])[threadIdx.x] = make_uint2(0u, 0u); // 512 threads x 8 bytes = 4 KB
+    reinterpret_cast<uint2 *>(&c[0][0])[tid] = make_uint2(0u, 0u); // 512 threads x 8 bytes = 4 KB
 }
+__device__ __forceinline__ void ms_clear(MsCnt &c) { ms_clear(c, threadIdx.x); }
 
 template <int NBITS, typename T>
 __device__ __forceinline__ void tile_rank(const T (&v)[MS_ITEMS], int sh, uint32_t actmask, int R, MsCnt &cur, MsCnt &nxt, uint32_t *ls,
-                                          uint32_t (&pos)[MS_ITEMS / 2])
+                                          uint32_t (&pos)[MS_ITEMS / 2], uint32_t tid)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = (int)(tid >> 6), lane = (int)(tid & 63u);
     constexpr uint32_t dmask = (1u << NBITS) - 1u;
-    ms_clear(nxt);
+    ms_clear(nxt, tid);
     uint32_t wr[MS_ITEMS / 2];
 #pragma unroll
     for (int k = 0; k < MS_ITEMS / 2; k++) wr[k] = 0;
@@ -114,20 +116,20 @@ __device__ __forceinline__ void tile_rank(const T (&v)[MS_ITEMS], int sh, uint32
     __syncthreads();
     // digit totals -> exclusive starts (threads 0..255 = digits: four wavefronts scan, their sums meet in LDS)
     uint32_t mytot = 0, inc = 0;
-    if (threadIdx.x < 256) {
+    if (tid < 256) {
 #pragma unroll
-        for (int w = 0; w < MS_NW; w++) mytot += cur[w][threadIdx.x];
+        for (int w = 0; w < MS_NW; w++) mytot += cur[w][tid];
         inc = wave_incl_add(mytot, lane);
         if (lane == 63) ls[wave] = inc;
     }
     __syncthreads();
-    if (threadIdx.x < 256) {
+    if (tid < 256) {
         uint32_t g = inc - mytot;
         for (int w = 0; w < wave; w++) g += ls[w];
 #pragma unroll
         for (int w = 0; w < MS_NW; w++) {
-            const uint32_t t = cur[w][threadIdx.x];
-            cur[w][threadIdx.x] = (uint16_t)g;
+            const uint32_t t = cur[w][tid];
+            cur[w][tid] = (uint16_t)g;
             g += t;
         }
     }
@@ -503,7 +505,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) bigram_scatter(Msd m, uint32_t 
         if (pass == 0) // (by byte 1: no order to keep yet)
             tile_rank_unordered(v, sh, actmask, MS_ITEMS, ucnt, ls, pos);
         else
-            tile_rank<8>(v, sh, actmask, MS_ITEMS, cur[1], cur[0], ls, pos);
+            tile_rank<8>(v, sh, actmask, MS_ITEMS, cur[1], cur[0], ls, pos, threadIdx.x);
 #pragma unroll
         for (int k = 0; k < MS_ITEMS; k++)
             if ((actmask >> k) & 1u) stage[(pos[k >> 1] >> (16 * (k & 1))) & 0xFFFFu] = v[k];
@@ -679,7 +681,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) seg_scatter(Msd m, uint32_t L)
             v[k] = src[p < cntv ? p : 0u]; // (branch-free; slots past the end are never ranked)
         }
         uint32_t pos[MS_ITEMS / 2];
-        tile_rank<8>(v, (int)shift, actmask, MS_ITEMS, cur[par], cur[par ^ 1], ls, pos);
+        tile_rank<8>(v, (int)shift, actmask, MS_ITEMS, cur[par], cur[par ^ 1], ls, pos, threadIdx.x);
         par ^= 1;
 #pragma unroll
         for (int k = 0; k < MS_ITEMS; k++)
@@ -709,42 +711,77 @@ __global__ void __launch_bounds__(MS_THREADS, 4) seg_scatter(Msd m, uint32_t L)
 // ---- one unit = whole buckets, at most a tile: sorted, ranked and routed inside one workgroup ----------------------------
 // Sort: elements in registers, wave w holding rows of 64 consecutive slots ("striped": what the ballot ranking wants);
 // LDS element = [bucket index in the unit : 8 @53][bytes 2..6 : 40 @13][slot the element was loaded at : 13] -- the suffix
-// stays in the registers of that slot and is fetched through LDS once, after the last pass.
-// After the sort: every thread owns 16 CONSECUTIVE sorted elements ("blocked", as refine_one): group boundaries by
-// comparing neighbours in registers, extents by two workgroup scans, lists and binned rank pairs through LDS.
+// is NOT carried through the passes: the low halves of the unit's elements are read once more after the last pass
+// (coalesced, the lines are in the L2) into a table by load slot, from which every sorted element fetches its suffix.
+// After the sort everything stays striped (slot w = k * 512 + thread; row k * 8 + wave = 64 consecutive slots of the
+// sorted order): group heads by ballots (one 64-bit mask per row), a group's extent from the masks of its row and the
+// rows next to it, and then
+//   * THE FIRST DOUBLING STEP OF THE SMALL GROUPS (m.fuse): a group of 2..64 rotations that share their first 7 bytes
+//     is ordered by bytes 7..14 -- one 8-byte load from the text per member (what rank[i + 7] at depth 7 would say, and
+//     one byte more), all pairs inside the group from keys in LDS, exactly as tail_round ranks a group from gathered
+//     ranks.  The members leave with their rank at depth 15: the rank words of this step are the ones the initial
+//     binning writes anyway, the small-group list holds what is STILL unresolved (about a third of what depth 7 left),
+//     and the block's small groups sit round 0 out (round_begin) -- there is no tail_round over 43 M suffixes;
+//   * (rank word, suffix) pairs binned by 4096-suffix window of the rank array (rank_apply turns them into whole lines),
+//     small groups to the small-group list (a group's members adjacent), large groups to the big list (in order).
+// Units are whole buckets, so no group crosses a unit: no carries, no look-back.
 constexpr int MS_SLOTS = MS_TILE + MS_TILE / 16;
-__device__ __forceinline__ uint32_t ms_slot(uint32_t e) { return e + (e >> 4); } // (+1 per 16: blocked 8-byte reads stay conflict free)
+__device__ __forceinline__ uint32_t ms_slot(uint32_t e) { return e + (e >> 4); } // (+1 per 16: blocked 8-byte accesses stay conflict free)
+constexpr u64 MS_REC_BIG = 1ull << 63; // in the staged list records: member of a large group
+
+// bytes 7..14 of rotation i (big-endian: the smaller key is the smaller rotation among rotations that share 7 bytes)
+__device__ __forceinline__ u64 ms_key8(const uint8_t *txt, uint32_t i, uint32_t n)
+{
+    if (n <= 7u) return (u64)(n - 1u - i); // equal for 7 >= n bytes: identical rotations, larger index first
+    uint32_t p = i + 7u;
+    if (p >= n) p -= n;
+    if (p + 8u <= n) {
+        u64 v;
+        __builtin_memcpy(&v, txt + p, 8); // (gfx950 global loads need no alignment)
+        return __builtin_bswap64(v);
+    }
+    u64 v = 0;
+    for (int q = 0; q < 8; q++) { // cyclic wrap (also more than once: n may be as small as 8)
+        v = (v << 8) | txt[p];
+        if (++p == n) p = 0;
+    }
+    return v;
+}
 
 __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
 {
     __shared__ u64 stage[MS_SLOTS];
-    __shared__ MsCnt cur[2];         // counters of the passes; afterwards: the bins of the rank binning and a scan row
-    __shared__ u64 HM[128];          // bucket heads by position (bit per slot)
-    __shared__ uint32_t rowpre[128];
-    __shared__ uint32_t ls[MS_NW + 2];
-    __shared__ int lmm[MS_NW], lmn[MS_NW];
-    __shared__ u64 s_or, s_and;
+    __shared__ MsCnt cur[2];         // counters of the passes; afterwards: the bins of the rank binning
+    __shared__ u64 HM[128];          // bucket heads by load position, later group heads by sorted position (bit per slot)
+    __shared__ uint32_t rowpre[128]; // bucket heads before a row; later 1 + position of the last group head before a row
+    __shared__ uint32_t wc[128];     // per row of the sorted order: surviving small-group records | large-group records << 16
+    __shared__ uint32_t ls[MS_NW + 2], lsv[MS_NW];
+    __shared__ u64 s_wo[MS_NW], s_wa[MS_NW]; // per wavefront: OR / AND of its elements
     __shared__ uint32_t s_unit, s_offS, s_offB;
     uint32_t *const bh = reinterpret_cast<uint32_t *>(&cur[0][0][0]); // 4 x 256 words: counts, local starts, cursors, offsets
     uint32_t *const bl = bh + 256, *const bcur = bh + 512, *const bgo = bh + 768;
     const uint32_t nunits = min(m.cnt[MC_UNITS], m.B * MS_UNIT_CAP);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t tid = threadIdx.x;
-    // (timing experiments, BZH_MSD_DBG & 16: cycles per phase, summed over the units of the workgroup, to cnt[24 ..])
-    long long t_last = 0;
-    uint32_t t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define MS_T(k)                                                 \
-    if ((m.dbg & 16u) && tid == 0) {                            \
-        const long long t_now = clock64();                      \
-        t_acc[k] += (uint32_t)((t_now - t_last) >> 4);          \
-        t_last = t_now;                                         \
+    // (timing experiments, BZH_MSD_DBG & 16: cycles per phase, summed over all units, to cnt[24 ..]; the last reading lives in
+    // LDS and the sums go straight to memory: no register of the product path is held for it)
+    __shared__ long long s_tlast;
+#define MS_T(k)                                                                    \
+    if ((m.dbg & 16u) && tid == 0) {                                               \
+        const long long t_now = clock64();                                         \
+        atomicAdd(&m.cnt[24 + (k)], (uint32_t)((t_now - s_tlast) >> 4));           \
+        s_tlast = t_now;                                                           \
     }
     // Global atomics return after one to two microseconds: the ticket of the NEXT unit, the room claimed in the two lists
     // and in the rank windows are requested as soon as their arguments exist and consumed as late as possible.
     uint32_t pend_ticket = 0;
-    if (tid == 0) pend_ticket = atomicAdd(&m.cnt[MC_TICKET], 1u);
+    if (threadIdx.x == 0) pend_ticket = atomicAdd(&m.cnt[MC_TICKET], 1u);
     for (;;) {
-        if ((m.dbg & 16u) && tid == 0) t_last = clock64();
+        // The thread's index is made opaque once per unit: otherwise every address and mask that depends on it only (a few
+        // dozen values: slots, rows, lane masks of all 16 steps) is hoisted out of this loop and kept alive across it -- in
+        // scratch memory (the compiler's resource report showed 80 spilled registers, all of this kind).
+        uint32_t tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = (int)(tid & 63u), wave = (int)(tid >> 6);
+        if ((m.dbg & 16u) && tid == 0) s_tlast = clock64();
         if (tid == 0) s_unit = pend_ticket;
         __syncthreads();
         const uint32_t u = s_unit;
@@ -764,14 +801,9 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
         const uint32_t Lw = (uint32_t)R * 64u;    // slots per wave
         // ---- load; bucket index of every slot from the bucket starts
         u64 x[MS_ITEMS];
-        uint32_t suf[MS_ITEMS];
         uint32_t actmask = 0;
         if (tid < 128) HM[tid] = 0ull;
-        if (tid == 0) {
-            s_or = 0ull;
-            s_and = ~0ull;
-        }
-        ms_clear(cur[0]);
+        ms_clear(cur[0], tid);
         __syncthreads();
         const bool multi = !uniform && nb > 1u;
         if (multi) {
@@ -793,7 +825,6 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
             const bool act = k < R && p < len;
             actmask |= (act ? 1u : 0u) << k;
             const u64 w = src[act ? p : 0u]; // (branch-free: slots past the end are never ranked, stored or counted)
-            suf[k] = (uint32_t)(w & SUF_MASK);
             x[k] = ((w >> 20) << 13) | p;
         }
         __syncthreads();
@@ -834,191 +865,211 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
                 a &= ((u64)(uint32_t)__shfl_xor((int)(a >> 32), d, 64) << 32) | (uint32_t)__shfl_xor((int)a, d, 64);
             }
             if (lane == 0) {
-                atomicOr((unsigned long long *)&s_or, (unsigned long long)o);
-                atomicAnd((unsigned long long *)&s_and, (unsigned long long)a);
+                s_wo[wave] = o;
+                s_wa[wave] = a;
             }
         }
         __syncthreads();
         MS_T(0);
-        const u64 vary = uniform ? 0ull : (s_or & ~s_and);
-        uint32_t pos[MS_ITEMS / 2];
-        int par = 0;
-        bool staged = false;
-#pragma unroll 1
-        for (int pass = 0; pass < 6; pass++) {
-            const int sh = pass < 5 ? 13 + 8 * pass : 53;
-            if (((vary >> sh) & 255ull) == 0ull) continue; // (the same for every thread)
-            tile_rank<8>(x, sh, actmask, R, cur[par], cur[par ^ 1], ls, pos);
-            par ^= 1;
-            MS_T(1);
+        u64 vary = 0ull;
+        if (!uniform) {
+            u64 o = 0ull, a = ~0ull;
 #pragma unroll
-            for (int k = 0; k < MS_ITEMS; k++)
-                if ((actmask >> k) & 1u) stage[ms_slot((pos[k >> 1] >> (16 * (k & 1))) & 0xFFFFu)] = x[k];
-            __syncthreads();
-            MS_T(2);
-            staged = true;
-            bool again = false; // is there another pass?  (then the striped registers are refilled)
-            for (int q = pass + 1; q < 6; q++) again |= ((vary >> (q < 5 ? 13 + 8 * q : 53)) & 255ull) != 0ull;
-            if (again) {
-#pragma unroll
-                for (int k = 0; k < MS_ITEMS; k++) x[k] = stage[ms_slot((wave * Lw + k * 64 + lane) & 8191u)];
+            for (int w = 0; w < MS_NW; w++) {
+                o |= s_wo[w];
+                a &= s_wa[w];
             }
+            vary = o & ~a;
         }
-        if (!staged) { // nothing to sort (one key): the blocked phase still reads the elements from the stage
+        {
+            uint32_t pos[MS_ITEMS / 2];
+            int par = 0;
+            bool staged = false;
+#pragma unroll 1
+            for (int pass = 0; pass < 6; pass++) {
+                const int sh = pass < 5 ? 13 + 8 * pass : 53;
+                if (((vary >> sh) & 255ull) == 0ull) continue; // (the same for every thread)
+                tile_rank<8>(x, sh, actmask, R, cur[par], cur[par ^ 1], ls, pos, tid);
+                par ^= 1;
+                MS_T(1);
 #pragma unroll
-            for (int k = 0; k < MS_ITEMS; k++)
-                if ((actmask >> k) & 1u) stage[ms_slot(wave * Lw + k * 64 + lane)] = x[k];
-            __syncthreads();
+                for (int k = 0; k < MS_ITEMS; k++)
+                    if ((actmask >> k) & 1u) stage[ms_slot((pos[k >> 1] >> (16 * (k & 1))) & 0xFFFFu)] = x[k];
+                __syncthreads();
+                MS_T(2);
+                staged = true;
+                bool again = false; // is there another pass?  (then the striped registers are refilled)
+                for (int q = pass + 1; q < 6; q++) again |= ((vary >> (q < 5 ? 13 + 8 * q : 53)) & 255ull) != 0ull;
+                if (again) {
+#pragma unroll
+                    for (int k = 0; k < MS_ITEMS; k++) x[k] = stage[ms_slot((wave * Lw + k * 64 + lane) & 8191u)];
+                }
+            }
+            if (!staged) { // nothing to sort (one key): the next phase still reads the elements from the stage
+#pragma unroll
+                for (int k = 0; k < MS_ITEMS; k++)
+                    if ((actmask >> k) & 1u) stage[ms_slot(wave * Lw + k * 64 + lane)] = x[k];
+                __syncthreads();
+            }
         }
         MS_T(3);
-        // ---- blocked: my 16 consecutive sorted elements, group boundaries, extents
-        const uint32_t e0 = tid * MS_ITEMS;
-        uint32_t lidx[MS_ITEMS / 2]; // the slots my elements were loaded at, 16 bits each
-        uint32_t bdm = 0;            // bit k: element e0 + k starts a group
-        {
-            u64 prevk = e0 ? (stage[ms_slot(e0 - 1)] >> 13) : 0ull;
+        // ---- sorted order, striped: slot w = k * 512 + tid; group heads of every row of 64 slots by ballot
+        uint32_t sl[MS_ITEMS / 2]; // the slots my elements were loaded at, 16 bits each; later: where their list records go
 #pragma unroll
-            for (int k = 0; k < MS_ITEMS / 2; k++) lidx[k] = 0;
-#pragma unroll
-            for (int k = 0; k < MS_ITEMS; k++) {
-                const uint32_t q = e0 + k;
-                const u64 yk = stage[ms_slot(q & 8191u)];
-                const u64 key = yk >> 13;
-                lidx[k >> 1] |= ((uint32_t)yk & 8191u) << (16 * (k & 1));
-                if (q < len && (q == 0 || (!uniform && key != prevk))) bdm |= 1u << k;
-                prevk = key;
-            }
-        }
-        const int lastbd = bdm ? (int)e0 + 31 - __clz((int)bdm) : -1;
-        const int firstbd = bdm ? (int)e0 + __ffs((int)bdm) - 1 : INT32_MAX;
-        // last boundary before my range / first boundary behind it: one pair of wave scans, one barrier
-        int cd, nxt;
-        {
-            int imax = lastbd, imin = firstbd; // inclusive prefix max / inclusive suffix min inside the wavefront
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int tu = __shfl_up(imax, d, 64), td = __shfl_down(imin, d, 64);
-                if (lane >= d) imax = max(imax, tu);
-                if (lane + d < 64) imin = min(imin, td);
-            }
-            if (lane == 63) lmm[wave] = imax;
-            if (lane == 0) lmn[wave] = imin;
-            int emax = __shfl_up(imax, 1, 64), emin = __shfl_down(imin, 1, 64);
-            if (lane == 0) emax = -1;
-            if (lane == 63) emin = INT32_MAX;
-            __syncthreads(); // (every thread has read its elements from the stage by now, too)
-            for (int w = 0; w < wave; w++) emax = max(emax, lmm[w]);
-            for (int w = wave + 1; w < MS_NW; w++) emin = min(emin, lmn[w]);
-            cd = emax;
-            nxt = emin == INT32_MAX ? (int)len : emin;
-        }
-        // the suffixes follow their elements: table of the slots' suffixes over the (now free) stage
-        {
-            uint32_t *st32 = reinterpret_cast<uint32_t *>(stage);
-#pragma unroll
-            for (int k = 0; k < MS_ITEMS; k++)
-                if ((actmask >> k) & 1u) st32[wave * Lw + k * 64 + lane] = suf[k];
-        }
-        if (tid < 256) bh[tid] = 0; // (the pass counters are free: the last pass ended behind barriers)
-        {
-            const uint32_t nheads = wave_reduce_add((uint32_t)__popc(bdm));
-            if (lane == 0 && nheads) atomicAdd(&m.c_groups[b], nheads);
-        }
-        // class and rank of element k from the boundary bits: [class : 2 @30][first position of its group in the block's order : 20]
-        auto class_head = [&](int k) -> uint32_t {
-            const uint32_t below = bdm & ((2u << k) - 1u), above = k < 15 ? bdm >> (k + 1) : 0u;
-            const int head = below ? (int)e0 + 31 - __clz((int)below) : cd;
-            const int end = above ? (int)e0 + k + __ffs((int)above) : nxt;
-            const uint32_t size = (uint32_t)(end - head);
-            uint32_t c = size == 1u ? CLS_SINGLE : (size <= (uint32_t)TAIL_G ? CLS_SMALL : CLS_BIG);
-            uint32_t hp = s + (uint32_t)head;
-            if (uniform) { // one tile of a group that spans several units
-                c = CLS_BIG;
-                hp = tbl;
-            }
-            return (c << 30) | hp;
-        };
-        uint32_t hg[MS_ITEMS]; // (computed once per element)
-        uint32_t nS = 0, nB = 0;
+        for (int k = 0; k < MS_ITEMS / 2; k++) sl[k] = 0;
 #pragma unroll
         for (int k = 0; k < MS_ITEMS; k++) {
-            hg[k] = e0 + k < len ? class_head(k) : 0u;
-            const uint32_t c = hg[k] >> 30;
-            nS += (e0 + k < len && c == CLS_SMALL) ? 1u : 0u;
-            nB += (e0 + k < len && c == CLS_BIG) ? 1u : 0u;
+            const uint32_t w = k * MS_THREADS + tid;
+            const bool act = w < len;
+            u64 key = ~0ull;
+            if (act) {
+                const u64 y = stage[ms_slot(w)];
+                key = y >> 13;
+                sl[k >> 1] |= ((uint32_t)y & 8191u) << (16 * (k & 1));
+            }
+            u64 pk = ((u64)(uint32_t)__shfl_up((int)(uint32_t)(key >> 32), 1, 64) << 32) | (uint32_t)__shfl_up((int)(uint32_t)key, 1, 64);
+            if (lane == 0) pk = (act && w > 0u) ? stage[ms_slot(w - 1u)] >> 13 : ~0ull;
+            const bool head = act && (w == 0u || (!uniform && key != pk));
+            const u64 hm = __ballot(head);
+            if (lane == 0) HM[k * MS_NW + wave] = hm;
         }
-        uint32_t totS, totB, offS, offB;
-        { // both compaction offsets in one scan: 16 bits each (a unit holds at most 8192 records)
-            uint32_t tot2;
-            const uint32_t off2 = block_excl_add(nS | (nB << 16), ls, &tot2); // (barriers inside: the suffix table is complete behind them)
-            offS = off2 & 0xFFFFu;
-            offB = off2 >> 16;
-            totS = tot2 & 0xFFFFu;
-            totB = tot2 >> 16;
+        __syncthreads(); // every thread holds its elements: the stage is free; the head masks are complete
+        // the suffixes follow their elements: table of the load slots' suffixes over the stage (second read of the unit's
+        // low halves); wave 0 on the way: last group head before every row, groups of the unit
+        {
+            uint32_t *st32 = reinterpret_cast<uint32_t *>(stage);
+            const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+#pragma unroll
+            for (int k = 0; k < MS_ITEMS; k++) {
+                const uint32_t p = wave * Lw + k * 64 + lane;
+                if ((actmask >> k) & 1u) st32[p] = s32[2u * p] & (uint32_t)SUF_MASK;
+            }
         }
-        uint32_t pendS = 0, pendB = 0;
-        if (tid == 0) {
-            pendS = totS ? atomicAdd(&m.c_small[b], totS) : 0u;
-            pendB = totB ? atomicAdd(&m.c_big[b], totB) : 0u;
+        if (wave == 0) {
+            const u64 h0 = HM[2 * lane], h1 = HM[2 * lane + 1];
+            const int v0 = h0 ? (2 * lane) * 64 + 64 - __clzll((long long)h0) : 0;
+            const int v1 = h1 ? (2 * lane + 1) * 64 + 64 - __clzll((long long)h1) : 0;
+            const int inc = wave_incl_max(max(v0, v1), lane);
+            int ex = __shfl_up(inc, 1, 64);
+            if (lane == 0) ex = 0;
+            rowpre[2 * lane] = (uint32_t)ex;
+            rowpre[2 * lane + 1] = (uint32_t)max(ex, v0);
+            const uint32_t nheads = wave_reduce_add((uint32_t)(__popcll(h0) + __popcll(h1)));
+            if (lane == 0 && nheads) atomicAdd(&m.c_groups[b], nheads);
         }
+        if (tid < 256) bh[tid] = 0; // (the pass counters are free: the last pass ended behind barriers)
+        __syncthreads();
         MS_T(4);
+        // ---- suffix, group extent and class of every element; rank windows counted
+        const bool fuse = m.fuse != 0u && !uniform;
+        const uint8_t *txt = m.blk + (size_t)b * m.S;
         uint32_t sf[MS_ITEMS];
+        uint32_t gi[MS_ITEMS]; // [class : 2 @30][members - 1 : 6 @24 (small groups)][first slot of the group : 13]
         {
             const uint32_t *st32 = reinterpret_cast<const uint32_t *>(stage);
 #pragma unroll
             for (int k = 0; k < MS_ITEMS; k++) {
-                sf[k] = st32[(lidx[k >> 1] >> (16 * (k & 1))) & 0xFFFFu];
-                if (e0 + k < len) atomicAdd(&bh[sf[k] >> 12], 1u);
-            }
-        }
-        __syncthreads(); // the table has been read; the bin counts are complete
-        MS_T(5);
-        // list records through LDS: small groups at [0, totS), large groups behind them
-        {
-            uint32_t wS = offS, wB = totS + offB;
-#pragma unroll
-            for (int k = 0; k < MS_ITEMS; k++) {
-                if (e0 + k < len) {
-                    const uint32_t ch = hg[k], c = ch >> 30;
-                    const u64 rec = ((u64)(ch & 0xFFFFFu) << 40) | sf[k];
-                    if (c == CLS_SMALL) stage[wS++] = rec;
-                    if (c == CLS_BIG) stage[wB++] = rec;
+                const uint32_t w = k * MS_THREADS + tid;
+                sf[k] = 0;
+                gi[k] = 0;
+                if (w < len) {
+                    sf[k] = st32[(sl[k >> 1] >> (16 * (k & 1))) & 0xFFFFu];
+                    const uint32_t row = k * MS_NW + wave;
+                    const u64 own = HM[row];
+                    const u64 upto = (2ull << lane) - 1ull; // bits 0..lane (lane 63: all)
+                    const u64 below = own & upto, above = own & ~upto;
+                    const uint32_t g = below ? row * 64u + 63u - (uint32_t)__clzll((long long)below) : rowpre[row] - 1u;
+                    uint32_t ge;
+                    if (above) {
+                        ge = row * 64u + (uint32_t)__ffsll((long long)above) - 1u;
+                    } else { // (exact if it is a head or the unit's end; otherwise the group has more than 64 members anyway)
+                        const u64 nm = row + 1u < 128u ? HM[row + 1u] : 0ull;
+                        ge = nm ? (row + 1u) * 64u + (uint32_t)__ffsll((long long)nm) - 1u : min(len, (row + 2u) * 64u);
+                    }
+                    const uint32_t size = ge - g;
+                    uint32_t c = size == 1u ? CLS_SINGLE : (size <= (uint32_t)TAIL_G ? CLS_SMALL : CLS_BIG);
+                    if (uniform) c = CLS_BIG; // one tile of a group that spans several units
+                    gi[k] = (c << 30) | (((size - 1u) & 63u) << 24) | g;
+                    atomicAdd(&bh[sf[k] >> 12], 1u);
                 }
             }
         }
-        // rank binning: local starts of the bins, their room in the block's windows
-        uint32_t pendG = 0;
-        const uint32_t binc = tid < 256 ? bh[tid] : 0u;
-        if (tid == 0) {
-            s_offS = pendS;
-            s_offB = pendB;
+        __syncthreads(); // the table has been read; the bin counts are complete
+        // keys of the small groups' members: bytes 7..14 of their rotations, one 8-byte load each, straight into LDS
+        if (fuse) {
+#pragma unroll
+            for (int k = 0; k < MS_ITEMS; k++) {
+                const uint32_t w = k * MS_THREADS + tid;
+                if (w < len && (gi[k] >> 30) == CLS_SMALL) stage[w] = ms_key8(txt, sf[k], n);
+            }
         }
+        // rank binning: local starts of the bins, their room in the block's windows
+        const uint32_t binc = tid < 256 ? bh[tid] : 0u;
         {
             uint32_t tot;
-            const uint32_t ex = block_excl_add(binc, ls, &tot); // (barriers inside: the list records and offsets are in place after it)
+            const uint32_t ex = block_excl_add_at(binc, ls, &tot, tid); // (barriers inside: the keys are in place after it)
             if (tid < 256) {
                 bl[tid] = ex;
                 bcur[tid] = ex;
-                if (binc) pendG = atomicAdd(&m.bincur[(size_t)b * 256 + tid], binc);
+                const uint32_t w0 = tid * 4096u, wcap = w0 < n ? min(4096u, n - w0) : 0u;
+                const uint32_t at = binc ? atomicAdd(&m.bincur[(size_t)b * 256 + tid], binc) : 0u;
+                if (binc && at + binc > wcap) atomicOr(m.err, ERR_MSD);
+                bgo[tid] = min(n, w0) + at;
             }
         }
+        // ---- the first doubling step of the small groups: every member counts the members that sort before it
+        uint32_t hg[MS_ITEMS]; // [class : 2 @30][first position of the element's group in the block's order : 20]
         {
-            u64 *ts = m.tail + (size_t)b * m.S + s_offS;
-            u64 *bs = m.big + (size_t)b * m.S + s_offB;
-            for (uint32_t q = tid; q < totS; q += MS_THREADS) ts[q] = stage[q];
-            for (uint32_t q = tid; q < totB; q += MS_THREADS) bs[q] = stage[totS + q];
+            uint32_t nsv = 0; // my records for the two lists: small groups | large groups << 16
+#pragma unroll
+            for (int k = 0; k < MS_ITEMS; k++) {
+                const uint32_t w = k * MS_THREADS + tid;
+                hg[k] = 0;
+                if (w < len) {
+                    uint32_t c = gi[k] >> 30;
+                    const uint32_t g = gi[k] & 8191u;
+                    uint32_t hp = s + g, dest = w;
+                    if (fuse && c == CLS_SMALL) {
+                        const uint32_t ge = g + ((gi[k] >> 24) & 63u) + 1u;
+                        const u64 my = stage[w];
+                        uint32_t less = 0, eq = 0, eqb = 0;
+#pragma unroll 4
+                        for (uint32_t f = g; f < ge; f++) { // bounds known up front: the LDS reads pipeline
+                            const u64 kf = stage[f];
+                            less += kf < my;
+                            eq += kf == my;
+                            eqb += kf == my && f < w;
+                        }
+                        hp += less; // a group of <= 64 members: the members with equal keys share the new head
+                        dest = g + less + eqb; // the u-th smallest member takes the slot of the u-th member
+                        if (eq == 1u) c = CLS_SINGLE;
+                    }
+                    if (uniform) hp = tbl;
+                    hg[k] = (c << 30) | hp;
+                    nsv += (c == CLS_SMALL ? 1u : 0u) + (c == CLS_BIG ? 0x10000u : 0u);
+                    sl[k >> 1] = (sl[k >> 1] & ~(0xFFFFu << (16 * (k & 1)))) | (dest << (16 * (k & 1)));
+                }
+            }
+            nsv = wave_reduce_add(nsv);
+            if (lane == 0) lsv[wave] = nsv;
         }
-        if (tid < 256) {
-            const uint32_t w0 = tid * 4096u, wcap = w0 < n ? min(4096u, n - w0) : 0u;
-            if (binc && pendG + binc > wcap) atomicOr(m.err, ERR_MSD);
-            bgo[tid] = min(n, tid * 4096u) + pendG;
+        __syncthreads(); // the keys have been read: the stage is free
+        MS_T(5);
+        uint32_t pendS = 0, pendB = 0;
+        if (tid == 0) { // (a unit holds at most 8192 records: 16 bits each)
+            uint32_t t2 = 0;
+#pragma unroll
+            for (int w = 0; w < MS_NW; w++) t2 += lsv[w];
+            const uint32_t totS = t2 & 0xFFFFu, totB = t2 >> 16;
+            pendS = totS ? atomicAdd(&m.c_small[b], totS) : 0u;
+            pendB = totB ? atomicAdd(&m.c_big[b], totB) : 0u;
         }
-        __syncthreads();
-        MS_T(6);
+        // ---- (rank word, suffix) pairs in bin order in LDS, then out as runs
 #pragma unroll
         for (int k = 0; k < MS_ITEMS; k++) {
-            if (e0 + k < len) {
-                const uint32_t ch = hg[k], c = ch >> 30, head = ch & 0xFFFFFu;
+            const uint32_t w = k * MS_THREADS + tid;
+            if (w < len) {
+                const uint32_t c = hg[k] >> 30, head = hg[k] & 0xFFFFFu;
                 const uint32_t word = c == CLS_SINGLE ? (head | RANK_RESOLVED) : head;
                 stage[atomicAdd(&bcur[sf[k] >> 12], 1u)] = ((u64)word << 32) | sf[k];
             }
@@ -1032,11 +1083,53 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
                 dst[bgo[d] + (q - bl[d])] = w;
             }
         }
+        __syncthreads();
+        MS_T(6);
+        // ---- list records through LDS, each at its place in the new order: a small group's members adjacent, equal keys together
+#pragma unroll
+        for (int k = 0; k < MS_ITEMS; k++) {
+            const uint32_t w = k * MS_THREADS + tid;
+            if (w < len) {
+                const uint32_t c = hg[k] >> 30;
+                const u64 rec = ((u64)(hg[k] & 0xFFFFFu) << 40) | sf[k];
+                stage[(sl[k >> 1] >> (16 * (k & 1))) & 0xFFFFu] = c == CLS_SMALL ? rec : (c == CLS_BIG ? (rec | MS_REC_BIG) : LIST_INVALID);
+            }
+        }
+        if (tid == 0) {
+            s_offS = pendS;
+            s_offB = pendB;
+        }
+        __syncthreads();
+        {
+            u64 o[MS_ITEMS];
+#pragma unroll
+            for (int k = 0; k < MS_ITEMS; k++) {
+                const uint32_t w = k * MS_THREADS + tid;
+                o[k] = w < len ? stage[w] : LIST_INVALID;
+                const u64 mS = __ballot(o[k] != LIST_INVALID && !(o[k] & MS_REC_BIG)), mB = __ballot(o[k] != LIST_INVALID && (o[k] & MS_REC_BIG));
+                if (lane == 0) wc[k * MS_NW + wave] = (uint32_t)__popcll(mS) | ((uint32_t)__popcll(mB) << 16);
+            }
+            __syncthreads(); // the row counts are there (and the records in registers)
+            // exclusive scan of the row counts in slot order (every wavefront for itself: 128 values, two a lane)
+            const uint32_t c0 = wc[2 * lane], c1 = wc[2 * lane + 1];
+            const uint32_t inc = wave_incl_add(c0 + c1, lane);
+            const uint32_t ex0 = inc - c0 - c1, ex1 = inc - c1;
+            u64 *ts = m.tail + (size_t)b * m.S + s_offS;
+            u64 *bs = m.big + (size_t)b * m.S + s_offB;
+#pragma unroll
+            for (int k = 0; k < MS_ITEMS; k++) {
+                const int row = k * MS_NW + wave;
+                const uint32_t a0 = (uint32_t)__shfl((int)ex0, row >> 1, 64), a1 = (uint32_t)__shfl((int)ex1, row >> 1, 64);
+                const uint32_t off = (row & 1) ? a1 : a0;
+                const bool isS = o[k] != LIST_INVALID && !(o[k] & MS_REC_BIG), isB = o[k] != LIST_INVALID && (o[k] & MS_REC_BIG);
+                const u64 mS = __ballot(isS), mB = __ballot(isB);
+                if (isS) ts[(off & 0xFFFFu) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mS >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mS, 0u))] = o[k];
+                if (isB) bs[(off >> 16) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mB, 0u))] = o[k] & ~MS_REC_BIG;
+            }
+        }
         MS_T(7);
         __syncthreads(); // the stage, the bins and s_unit are reused by the next unit
     }
-    if ((m.dbg & 16u) && tid == 0)
-        for (int k = 0; k < 8; k++) atomicAdd(&m.cnt[24 + k], t_acc[k]);
 #undef MS_T
 }
 
@@ -1047,7 +1140,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
 // small-group lists in `tail`, big lists in `big`, c_small / c_big / c_groups -- what refine_one<init> leaves.
 // X / Y: the two list buffers the partition levels alternate between (X also receives the 2-byte partition).
 static int msd_initial_sort(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal, u64 *X, u64 *Y, u64 *big, u64 *tail, u64 *binned,
-                            bool force_old, volatile uint32_t *hrec, uint32_t seq, uint32_t *n_old, hipEvent_t ev_plan)
+                            bool force_old, uint32_t fuse, volatile uint32_t *hrec, uint32_t seq, uint32_t *n_old, hipEvent_t ev_plan)
 {
     Batch &bt = ctx->bt;
     hipStream_t st = ctx->stream;
@@ -1077,6 +1170,7 @@ static int msd_initial_sort(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t nt
     m.c_groups = bt.c_groups;
     m.err = bt.errflag;
     m.force_old = force_old ? 1u : 0u;
+    m.fuse = fuse;
     {
         static const bool init_msd = []() {
             const char *e = getenv("BZH_INIT");

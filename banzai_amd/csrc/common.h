@@ -54,6 +54,7 @@ constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS; // 8192 elements per workgr
                                                      // scan overhead per element against 256 x 16, -7 % on the bench)
 constexpr uint32_t RANK_RESOLVED = 0x80000000u;      // suffix is alone in its group
 constexpr int SUMMARY_WORDS = 20; // round summary: see round_begin (bwt.hip)
+constexpr int RS_ROWS = 22;       // per-block rows of the suffix sort's round state (layout_batch, api.hip)
 constexpr uint32_t MS_BG_ROW = 65552, MS_LEVELS = 5, MS_SEG_SLOTS = 112, MS_SEG_ROW = 264, MS_UNIT_CAP = 4096, MS_ITEM_CAP = 224,
                    MS_CNT_WORDS = 32, MS_MIN_N = 131072; // (levels whose blocks stay below MS_MIN_N bytes keep the 8-pass path: no tables for them)
 constexpr int MAX_ROUNDS = 30; // depth 8 doubles every round and ends at 2^20; < 31 keeps the rank words' round tags unique
@@ -96,6 +97,9 @@ struct Batch {
     uint32_t *st_h;     // depth of the block's next round
     uint32_t *st_nbig;  // records in the big-group list (SPLIT) / unresolved suffixes (SWEEP)
     uint32_t *st_ntail; // records in the small-group list
+    uint32_t *st_tdst;  // which of listC (0) / listD (1) receives the block's small-group records this round: the survivors of
+                        // tail_round (which reads the other one) and what refine appends; a block whose small groups sit a
+                        // round out keeps its list where it is (round_begin)
     uint32_t *c_big, *c_small, *c_tail, *c_prog; // produced by a round: list lengths, "some group was refined"
     uint32_t *c_nolist; // produced by a round: refine did not write the block's lists (SWEEP mode, mostly large groups)
     uint32_t *c_groups; // groups of the block after the initial sort (refine_one<init>; round_begin picks the first mode)
@@ -322,9 +326,11 @@ __device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v)
 
 // Workgroup exclusive add-scan of one value per thread.  `lds` needs (threads/64)+1 words.
 // Returns the exclusive prefix; *total receives the workgroup sum.
-__device__ __forceinline__ uint32_t block_excl_add(uint32_t v, uint32_t *lds, uint32_t *total)
+// (`tid`: the thread's index as the caller holds it -- a kernel that loops over work items and has made its index opaque
+// per item passes that one, so that nothing here is hoisted out of its loop and kept alive across it)
+__device__ __forceinline__ uint32_t block_excl_add_at(uint32_t v, uint32_t *lds, uint32_t *total, uint32_t tid)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    const int lane = tid & 63, wave = tid >> 6, nw = (blockDim.x + 63) >> 6;
     uint32_t inc = wave_incl_add(v, lane);
     if (lane == 63) lds[wave] = inc;
     __syncthreads();
@@ -339,6 +345,10 @@ __device__ __forceinline__ uint32_t block_excl_add(uint32_t v, uint32_t *lds, ui
     *total = lds[nw];
     __syncthreads();
     return res;
+}
+__device__ __forceinline__ uint32_t block_excl_add(uint32_t v, uint32_t *lds, uint32_t *total)
+{
+    return block_excl_add_at(v, lds, total, threadIdx.x);
 }
 
 // Workgroup inclusive max-scan of one int per thread. `lds` needs (threads/64) ints.
