@@ -2214,9 +2214,9 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
                 fprintf(stderr, "[bzhip] initial sort: %u blocks bucket-first, %u blocks 8-pass; %u units; %.1f %% of the suffixes in oversized 2-byte buckets; oversized buckets per level %u %u %u %u %u (tiles %u %u %u %u %u)\n",
                         c[MC_NEW], c[MC_OLD], c[MC_UNITS], 100.0 * 1024.0 * c[23] / (double)std::max<uint64_t>(1, ntotal), c[MC_SEGS + 1], c[MC_SEGS + 2], c[MC_SEGS + 3], c[MC_SEGS + 4], c[MC_SEGS + 5],
                         c[MC_ITEMS + 1], c[MC_ITEMS + 2], c[MC_ITEMS + 3], c[MC_ITEMS + 4], c[MC_ITEMS + 5]);
-            if (c[24] | c[27])
-                fprintf(stderr, "[bzhip] chunk_finish, 16-cycle ticks over all workgroups: ticket+load+bucket index %u, ranking %u, stage scatter+barrier %u, reload %u, boundaries+classes %u, suffixes+bins %u, lists out %u, ranks out %u\n",
-                        c[24], c[25], c[26], c[27], c[28], c[29], c[30], c[31]);
+            if (c[32] | c[35])
+                fprintf(stderr, "[bzhip] chunk_finish, 16-cycle ticks over all workgroups: ticket+load+bucket index %u, ranking %u, stage scatter+barrier %u, reload %u, heads+suffix table %u, suffixes+extents+bins %u, keys+bin scan %u, all pairs %u, rank pairs out %u, lists out %u\n",
+                        c[32], c[33], c[34], c[35], c[36], c[37], c[38], c[39], c[40], c[41]);
         }
     } else {
         HIP_TRY(ctx, hipMemsetAsync(bt.ms_np, 0, (size_t)B * sizeof(uint32_t), st));

@@ -761,13 +761,13 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
     uint32_t *const bh = reinterpret_cast<uint32_t *>(&cur[0][0][0]); // 4 x 256 words: counts, local starts, cursors, offsets
     uint32_t *const bl = bh + 256, *const bcur = bh + 512, *const bgo = bh + 768;
     const uint32_t nunits = min(m.cnt[MC_UNITS], m.B * MS_UNIT_CAP);
-    // (timing experiments, BZH_MSD_DBG & 16: cycles per phase, summed over all units, to cnt[24 ..]; the last reading lives in
+    // (timing experiments, BZH_MSD_DBG & 16: cycles per phase, summed over all units, to cnt[32 ..]; the last reading lives in
     // LDS and the sums go straight to memory: no register of the product path is held for it)
     __shared__ long long s_tlast;
 #define MS_T(k)                                                                    \
     if ((m.dbg & 16u) && tid == 0) {                                               \
         const long long t_now = clock64();                                         \
-        atomicAdd(&m.cnt[24 + (k)], (uint32_t)((t_now - s_tlast) >> 4));           \
+        atomicAdd(&m.cnt[32 + (k)], (uint32_t)((t_now - s_tlast) >> 4));           \
         s_tlast = t_now;                                                           \
     }
     // Global atomics return after one to two microseconds: the ticket of the NEXT unit, the room claimed in the two lists
@@ -780,7 +780,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
         // scratch memory (the compiler's resource report showed 80 spilled registers, all of this kind).
         uint32_t tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        const int lane = (int)(tid & 63u), wave = (int)(tid >> 6);
+        const int lane = (int)(tid & 63u), wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6)); // (the wavefront's number is uniform: scalar row arithmetic)
         if ((m.dbg & 16u) && tid == 0) s_tlast = clock64();
         if (tid == 0) s_unit = pend_ticket;
         __syncthreads();
@@ -914,6 +914,17 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
         }
         MS_T(3);
         // ---- sorted order, striped: slot w = k * 512 + tid; group heads of every row of 64 slots by ballot
+        // (the suffixes follow their elements through a table by load slot: the second read of the unit's low halves is
+        // issued first and lands while the heads are found)
+        uint32_t sfl[MS_ITEMS];
+        {
+            const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+#pragma unroll
+            for (int k = 0; k < MS_ITEMS; k++) {
+                const uint32_t p = wave * Lw + k * 64 + lane;
+                sfl[k] = s32[((actmask >> k) & 1u) ? 2u * p : 0u];
+            }
+        }
         uint32_t sl[MS_ITEMS / 2]; // the slots my elements were loaded at, 16 bits each; later: where their list records go
 #pragma unroll
         for (int k = 0; k < MS_ITEMS / 2; k++) sl[k] = 0;
@@ -934,15 +945,13 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
             if (lane == 0) HM[k * MS_NW + wave] = hm;
         }
         __syncthreads(); // every thread holds its elements: the stage is free; the head masks are complete
-        // the suffixes follow their elements: table of the load slots' suffixes over the stage (second read of the unit's
-        // low halves); wave 0 on the way: last group head before every row, groups of the unit
+        // table of the load slots' suffixes over the stage; wave 0 on the way: last group head before every row, groups of the unit
         {
             uint32_t *st32 = reinterpret_cast<uint32_t *>(stage);
-            const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
 #pragma unroll
             for (int k = 0; k < MS_ITEMS; k++) {
                 const uint32_t p = wave * Lw + k * 64 + lane;
-                if ((actmask >> k) & 1u) st32[p] = s32[2u * p] & (uint32_t)SUF_MASK;
+                if ((actmask >> k) & 1u) st32[p] = sfl[k] & (uint32_t)SUF_MASK;
             }
         }
         if (wave == 0) {
@@ -995,28 +1004,43 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
             }
         }
         __syncthreads(); // the table has been read; the bin counts are complete
-        // keys of the small groups' members: bytes 7..14 of their rotations, one 8-byte load each, straight into LDS
-        if (fuse) {
+        MS_T(5);
+        // keys of the small groups' members: bytes 7..14 of their rotations, one 8-byte load each -- issued now, in LDS
+        // behind the scan of the rank windows (whose barriers they do not need)
+        constexpr int KH = 12; // keys in flight across the scan (the rest follows behind it: registers)
+        u64 kk[KH];
 #pragma unroll
-            for (int k = 0; k < MS_ITEMS; k++) {
-                const uint32_t w = k * MS_THREADS + tid;
-                if (w < len && (gi[k] >> 30) == CLS_SMALL) stage[w] = ms_key8(txt, sf[k], n);
-            }
+        for (int k = 0; k < KH; k++) {
+            const uint32_t w = k * MS_THREADS + tid;
+            kk[k] = 0ull;
+            if (fuse && w < len && (gi[k] >> 30) == CLS_SMALL) kk[k] = ms_key8(txt, sf[k], n);
         }
-        // rank binning: local starts of the bins, their room in the block's windows
+        // rank binning: local starts of the bins, their room in the block's windows (claimed now, consumed at the end)
+        uint32_t pendG = 0;
         const uint32_t binc = tid < 256 ? bh[tid] : 0u;
         {
             uint32_t tot;
-            const uint32_t ex = block_excl_add_at(binc, ls, &tot, tid); // (barriers inside: the keys are in place after it)
+            const uint32_t ex = block_excl_add_at(binc, ls, &tot, tid);
             if (tid < 256) {
                 bl[tid] = ex;
                 bcur[tid] = ex;
-                const uint32_t w0 = tid * 4096u, wcap = w0 < n ? min(4096u, n - w0) : 0u;
-                const uint32_t at = binc ? atomicAdd(&m.bincur[(size_t)b * 256 + tid], binc) : 0u;
-                if (binc && at + binc > wcap) atomicOr(m.err, ERR_MSD);
-                bgo[tid] = min(n, w0) + at;
+                if (binc) pendG = atomicAdd(&m.bincur[(size_t)b * 256 + tid], binc);
             }
         }
+        if (fuse) {
+#pragma unroll
+            for (int k = KH; k < MS_ITEMS; k++) {
+                const uint32_t w = k * MS_THREADS + tid;
+                if (w < len && (gi[k] >> 30) == CLS_SMALL) stage[w] = ms_key8(txt, sf[k], n);
+            }
+#pragma unroll
+            for (int k = 0; k < KH; k++) {
+                const uint32_t w = k * MS_THREADS + tid;
+                if (w < len && (gi[k] >> 30) == CLS_SMALL) stage[w] = kk[k];
+            }
+            __syncthreads();
+        }
+        MS_T(6);
         // ---- the first doubling step of the small groups: every member counts the members that sort before it
         uint32_t hg[MS_ITEMS]; // [class : 2 @30][first position of the element's group in the block's order : 20]
         {
@@ -1054,7 +1078,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
             if (lane == 0) lsv[wave] = nsv;
         }
         __syncthreads(); // the keys have been read: the stage is free
-        MS_T(5);
+        MS_T(7);
         uint32_t pendS = 0, pendB = 0;
         if (tid == 0) { // (a unit holds at most 8192 records: 16 bits each)
             uint32_t t2 = 0;
@@ -1065,6 +1089,11 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
             pendB = totB ? atomicAdd(&m.c_big[b], totB) : 0u;
         }
         // ---- (rank word, suffix) pairs in bin order in LDS, then out as runs
+        if (tid < 256) {
+            const uint32_t w0 = tid * 4096u, wcap = w0 < n ? min(4096u, n - w0) : 0u;
+            if (binc && pendG + binc > wcap) atomicOr(m.err, ERR_MSD);
+            bgo[tid] = min(n, w0) + pendG;
+        }
 #pragma unroll
         for (int k = 0; k < MS_ITEMS; k++) {
             const uint32_t w = k * MS_THREADS + tid;
@@ -1084,7 +1113,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
             }
         }
         __syncthreads();
-        MS_T(6);
+        MS_T(8);
         // ---- list records through LDS, each at its place in the new order: a small group's members adjacent, equal keys together
 #pragma unroll
         for (int k = 0; k < MS_ITEMS; k++) {
@@ -1127,7 +1156,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
                 if (isB) bs[(off >> 16) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mB, 0u))] = o[k] & ~MS_REC_BIG;
             }
         }
-        MS_T(7);
+        MS_T(9);
         __syncthreads(); // the stage, the bins and s_unit are reused by the next unit
     }
 #undef MS_T

@@ -56,7 +56,7 @@ constexpr uint32_t RANK_RESOLVED = 0x80000000u;      // suffix is alone in its g
 constexpr int SUMMARY_WORDS = 20; // round summary: see round_begin (bwt.hip)
 constexpr int RS_ROWS = 22;       // per-block rows of the suffix sort's round state (layout_batch, api.hip)
 constexpr uint32_t MS_BG_ROW = 65552, MS_LEVELS = 5, MS_SEG_SLOTS = 112, MS_SEG_ROW = 264, MS_UNIT_CAP = 4096, MS_ITEM_CAP = 224,
-                   MS_CNT_WORDS = 32, MS_MIN_N = 131072; // (levels whose blocks stay below MS_MIN_N bytes keep the 8-pass path: no tables for them)
+                   MS_CNT_WORDS = 48, MS_MIN_N = 131072; // (levels whose blocks stay below MS_MIN_N bytes keep the 8-pass path: no tables for them)
 constexpr int MAX_ROUNDS = 30; // depth 8 doubles every round and ends at 2^20; < 31 keeps the rank words' round tags unique
 
 struct BlockDesc { // device-side description of one planned block (mirrors bzh_block + restart info)
