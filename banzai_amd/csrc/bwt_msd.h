@@ -269,14 +269,20 @@ __device__ __forceinline__ void ms_push_seg(const Msd &m, uint32_t L, uint32_t b
     for (uint32_t t = 0; t < tiles; t++) m.items[(size_t)L * m.B * MS_ITEM_CAP + i0 + t] = g | (t << 20);
 }
 
+// The units of a block form a list of their own (row 0 of the per-block counters: its length, row MS_LEVELS + 1: the
+// tickets chunk_finish hands out over it): the finishing kernel works through a block's units on ONE XCD.
+__device__ __forceinline__ uint32_t *ms_unit_count(const Msd &m, uint32_t b) { return m.cnt + MS_CNT_WORDS + b; }
+__device__ __forceinline__ uint32_t *ms_unit_ticket(const Msd &m, uint32_t b) { return m.cnt + MS_CNT_WORDS + (size_t)(MS_LEVELS + 1) * m.B + b; }
 __device__ __forceinline__ void ms_push_unit(const Msd &m, uint4 u)
 {
-    const uint32_t i = atomicAdd(&m.cnt[MC_UNITS], 1u);
-    if (i >= m.B * MS_UNIT_CAP) {
+    const uint32_t b = u.x & 1023u;
+    const uint32_t i = atomicAdd(ms_unit_count(m, b), 1u);
+    if (i >= MS_UNIT_CAP) {
         atomicOr(m.err, ERR_MSD);
         return;
     }
-    m.units[i] = u;
+    atomicAdd(&m.cnt[MC_UNITS], 1u); // (trace only)
+    m.units[(size_t)b * MS_UNIT_CAP + i] = u;
 }
 
 __global__ void __launch_bounds__(1024) bigram_plan(Msd m, uint32_t *hsum, uint32_t seq)
@@ -748,6 +754,14 @@ __device__ __forceinline__ u64 ms_key8(const uint8_t *txt, uint32_t i, uint32_t 
     return v;
 }
 
+// (a fresh copy of a lane-dependent value the optimizer cannot relate to the others: what is derived from it -- shuffle
+// addresses, lane compares of a scan -- is computed where it is used instead of once per unit and held in registers)
+__device__ __forceinline__ int ms_opaque(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
 {
     __shared__ u64 stage[MS_SLOTS];
@@ -760,7 +774,6 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
     __shared__ uint32_t s_unit, s_offS, s_offB;
     uint32_t *const bh = reinterpret_cast<uint32_t *>(&cur[0][0][0]); // 4 x 256 words: counts, local starts, cursors, offsets
     uint32_t *const bl = bh + 256, *const bcur = bh + 512, *const bgo = bh + 768;
-    const uint32_t nunits = min(m.cnt[MC_UNITS], m.B * MS_UNIT_CAP);
     // (timing experiments, BZH_MSD_DBG & 16: cycles per phase, summed over all units, to cnt[32 ..]; the last reading lives in
     // LDS and the sums go straight to memory: no register of the product path is held for it)
     __shared__ long long s_tlast;
@@ -770,29 +783,89 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
         atomicAdd(&m.cnt[32 + (k)], (uint32_t)((t_now - s_tlast) >> 4));           \
         s_tlast = t_now;                                                           \
     }
-    // Global atomics return after one to two microseconds: the ticket of the NEXT unit, the room claimed in the two lists
-    // and in the rank windows are requested as soon as their arguments exist and consumed as late as possible.
-    uint32_t pend_ticket = 0;
-    if (threadIdx.x == 0) pend_ticket = atomicAdd(&m.cnt[MC_TICKET], 1u);
+    // ---- which unit next.  Workgroups are dealt round-robin over the 8 XCDs (as wg_map assumes; used for speed only), and a
+    // workgroup works through the blocks b = xcd, xcd + 8, ... in turn, a ticket per unit of the block: the block's text
+    // (the key gathers of the first doubling step: 0.9 MB), its rank windows (partial lines from many units) and its list
+    // tails then live in ONE L2 instead of in all eight.  When its XCD's blocks are used up a workgroup takes units of
+    // whichever block has the most left (one look at all counters by wave 0, then a ticket).  The ticket of the NEXT unit,
+    // the room claimed in the two lists and in the rank windows are requested as soon as their arguments exist and consumed
+    // as late as possible: a global atomic returns after one to two microseconds.
+    __shared__ uint32_t s_blk, s_next;
+    const uint32_t NOBLK = 0xFFFFFFFFu;
+    uint32_t cur_blk = blockIdx.x & 7u; // (uniform; >= m.B: nothing of my own)
+    bool own = true;                    // still inside my XCD's sequence of blocks
+    uint32_t cur_cnt = 0; // (cur_cnt: units of cur_blk -- final, the plans ran in earlier launches)
+    if (cur_blk >= m.B) {
+        own = false;
+        cur_blk = NOBLK;
+    } else {
+        cur_cnt = min(*ms_unit_count(m, cur_blk), MS_UNIT_CAP);
+    }
+    if (threadIdx.x == 0 && cur_blk != NOBLK) s_next = atomicAdd(ms_unit_ticket(m, cur_blk), 1u);
+    uint32_t tid = threadIdx.x;
     for (;;) {
         // The thread's index is made opaque once per unit: otherwise every address and mask that depends on it only (a few
         // dozen values: slots, rows, lane masks of all 16 steps) is hoisted out of this loop and kept alive across it -- in
         // scratch memory (the compiler's resource report showed 80 spilled registers, all of this kind).
-        uint32_t tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
+        asm volatile("" : "+v"(tid)); // (one register carried round the loop: threadIdx.x itself does not live on beside it)
         const int lane = (int)(tid & 63u), wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6)); // (the wavefront's number is uniform: scalar row arithmetic)
         if ((m.dbg & 16u) && tid == 0) s_tlast = clock64();
-        if (tid == 0) s_unit = pend_ticket;
+        if (wave == 0) {
+            uint32_t bq = cur_blk, t = s_next; // (the ticket requested a unit ago, parked in LDS once it had arrived)
+            for (uint32_t tries = 0;; tries++) {
+                if (bq != NOBLK && t < cur_cnt) break;
+                if (own && bq != NOBLK && bq + 8u < m.B) {
+                    bq += 8u;
+                } else { // my XCD's blocks are used up: the block with the most units left, anywhere
+                    own = false;
+                    uint32_t best = 0, bb = NOBLK;
+                    for (uint32_t b0 = 0; b0 < m.B; b0 += 64) {
+                        const uint32_t bx = b0 + (uint32_t)lane;
+                        uint32_t left = 0;
+                        if (bx < m.B) {
+                            const uint32_t c = min(*ms_unit_count(m, bx), MS_UNIT_CAP);
+                            const uint32_t k = __hip_atomic_load(ms_unit_ticket(m, bx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            left = c > k ? c - k : 0u;
+                        }
+                        const uint32_t mx = wave_all_max(left);
+                        if (mx > best) {
+                            best = mx;
+                            const u64 who = __ballot(left == mx);
+                            bb = b0 + (uint32_t)__ffsll((long long)who) - 1u;
+                        }
+                    }
+                    bq = bb;
+                    if (bq == NOBLK || tries > 4096u) { // nothing left anywhere (or a logic error: never spin for ever)
+                        bq = NOBLK;
+                        break;
+                    }
+                }
+                uint32_t tt = 0;
+                if (lane == 0) tt = atomicAdd(ms_unit_ticket(m, bq), 1u);
+                cur_cnt = min(*ms_unit_count(m, bq), MS_UNIT_CAP); // (beside the ticket's round trip)
+                t = (uint32_t)__builtin_amdgcn_readfirstlane((int)tt);
+            }
+            cur_blk = bq; // (wave 0's copy; the others take it from LDS)
+            if (lane == 0) {
+                s_blk = bq;
+                s_unit = t;
+            }
+        }
         __syncthreads();
-        const uint32_t u = s_unit;
-        if (u >= nunits) break;
-        if (tid == 0) pend_ticket = atomicAdd(&m.cnt[MC_TICKET], 1u);
-        const uint4 ud = m.units[u];
+        const uint32_t ub = s_blk, u = s_unit;
+        if (ub == NOBLK) break;
+        cur_blk = ub;
+        uint32_t pend_ticket = 0;
+        if (tid == 0) pend_ticket = atomicAdd(ms_unit_ticket(m, ub), 1u);
+        const uint4 ud = m.units[(size_t)ub * MS_UNIT_CAP + u];
         const uint32_t b = ud.x & 1023u, buf = (ud.x >> 10) & 1u, uniform = (ud.x >> 11) & 1u, nb = ud.x >> 12;
         const uint32_t s = ud.y, e = ud.z, tbl = ud.w, len = e - s;
         const uint32_t n = m.n[b];
         if (len == 0 || len > (uint32_t)MS_TILE) {
-            if (tid == 0) atomicOr(m.err, ERR_MSD);
+            if (tid == 0) {
+                atomicOr(m.err, ERR_MSD);
+                s_next = pend_ticket;
+            }
             __syncthreads();
             continue;
         }
@@ -832,7 +905,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
         if (multi) {
             if (wave == 0) { // bucket heads before every row of 64 slots: one wavefront, two rows a lane
                 const uint32_t p0 = (uint32_t)__popcll(HM[2 * lane]), p1 = (uint32_t)__popcll(HM[2 * lane + 1]);
-                const uint32_t inc = wave_incl_add(p0 + p1, lane);
+                const uint32_t inc = wave_incl_add(p0 + p1, ms_opaque(lane));
                 rowpre[2 * lane] = inc - p0 - p1;
                 rowpre[2 * lane + 1] = inc - p1;
                 if (lane == 63) ls[0] = inc;
@@ -859,17 +932,15 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
                     a &= x[k];
                 }
             }
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) {
-                o |= ((u64)(uint32_t)__shfl_xor((int)(o >> 32), d, 64) << 32) | (uint32_t)__shfl_xor((int)o, d, 64);
-                a &= ((u64)(uint32_t)__shfl_xor((int)(a >> 32), d, 64) << 32) | (uint32_t)__shfl_xor((int)a, d, 64);
-            }
+            o = ((u64)wave_all_or((uint32_t)(o >> 32)) << 32) | wave_all_or((uint32_t)o);
+            a = ((u64)wave_all_and((uint32_t)(a >> 32)) << 32) | wave_all_and((uint32_t)a);
             if (lane == 0) {
                 s_wo[wave] = o;
                 s_wa[wave] = a;
             }
         }
         __syncthreads();
+        if (tid == 0) s_next = pend_ticket; // (requested before the unit's elements were: it is there, and its register is free for the sort)
         MS_T(0);
         u64 vary = 0ull;
         if (!uniform) {
@@ -917,11 +988,12 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
         // (the suffixes follow their elements through a table by load slot: the second read of the unit's low halves is
         // issued first and lands while the heads are found)
         uint32_t sfl[MS_ITEMS];
+        const uint32_t pb2 = (uint32_t)ms_opaque((int)(wave * Lw + lane)); // (a fresh base: the 16 load slots are not kept from the load on)
         {
             const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
 #pragma unroll
             for (int k = 0; k < MS_ITEMS; k++) {
-                const uint32_t p = wave * Lw + k * 64 + lane;
+                const uint32_t p = pb2 + k * 64;
                 sfl[k] = s32[((actmask >> k) & 1u) ? 2u * p : 0u];
             }
         }
@@ -950,7 +1022,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
             uint32_t *st32 = reinterpret_cast<uint32_t *>(stage);
 #pragma unroll
             for (int k = 0; k < MS_ITEMS; k++) {
-                const uint32_t p = wave * Lw + k * 64 + lane;
+                const uint32_t p = pb2 + k * 64;
                 if ((actmask >> k) & 1u) st32[p] = sfl[k] & (uint32_t)SUF_MASK;
             }
         }
@@ -958,12 +1030,12 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
             const u64 h0 = HM[2 * lane], h1 = HM[2 * lane + 1];
             const int v0 = h0 ? (2 * lane) * 64 + 64 - __clzll((long long)h0) : 0;
             const int v1 = h1 ? (2 * lane + 1) * 64 + 64 - __clzll((long long)h1) : 0;
-            const int inc = wave_incl_max(max(v0, v1), lane);
+            const int inc = wave_incl_max(max(v0, v1), ms_opaque(lane));
             int ex = __shfl_up(inc, 1, 64);
             if (lane == 0) ex = 0;
             rowpre[2 * lane] = (uint32_t)ex;
             rowpre[2 * lane + 1] = (uint32_t)max(ex, v0);
-            const uint32_t nheads = wave_reduce_add((uint32_t)(__popcll(h0) + __popcll(h1)));
+            const uint32_t nheads = wave_all_add((uint32_t)(__popcll(h0) + __popcll(h1)));
             if (lane == 0 && nheads) atomicAdd(&m.c_groups[b], nheads);
         }
         if (tid < 256) bh[tid] = 0; // (the pass counters are free: the last pass ended behind barriers)
@@ -1013,25 +1085,26 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
         for (int k = 0; k < KH; k++) {
             const uint32_t w = k * MS_THREADS + tid;
             kk[k] = 0ull;
-            if (fuse && w < len && (gi[k] >> 30) == CLS_SMALL) kk[k] = ms_key8(txt, sf[k], n);
+            if (fuse && w < len && (gi[k] >> 30) == CLS_SMALL) kk[k] = (m.dbg & 32u) ? (u64)sf[k] * 0x9E3779B97F4A7C15ull : ms_key8(txt, sf[k], n);
         }
-        // rank binning: local starts of the bins, their room in the block's windows (claimed now, consumed at the end)
+        // rank binning: local starts of the bins -- one wavefront, four bins a lane, while the keys are on their way (no
+        // workgroup scan: three barriers less per unit); their room in the block's windows is claimed behind the next
+        // barrier and consumed at the end
+        if (wave == 0) {
+            const uint4 c4 = *reinterpret_cast<const uint4 *>(&bh[4 * lane]);
+            const uint32_t t4 = c4.x + c4.y + c4.z + c4.w;
+            const uint32_t ex = wave_incl_add(t4, ms_opaque(lane)) - t4;
+            const uint4 e4 = make_uint4(ex, ex + c4.x, ex + c4.x + c4.y, ex + c4.x + c4.y + c4.z);
+            *reinterpret_cast<uint4 *>(&bl[4 * lane]) = e4;
+            *reinterpret_cast<uint4 *>(&bcur[4 * lane]) = e4;
+        }
         uint32_t pendG = 0;
         const uint32_t binc = tid < 256 ? bh[tid] : 0u;
-        {
-            uint32_t tot;
-            const uint32_t ex = block_excl_add_at(binc, ls, &tot, tid);
-            if (tid < 256) {
-                bl[tid] = ex;
-                bcur[tid] = ex;
-                if (binc) pendG = atomicAdd(&m.bincur[(size_t)b * 256 + tid], binc);
-            }
-        }
         if (fuse) {
 #pragma unroll
             for (int k = KH; k < MS_ITEMS; k++) {
                 const uint32_t w = k * MS_THREADS + tid;
-                if (w < len && (gi[k] >> 30) == CLS_SMALL) stage[w] = ms_key8(txt, sf[k], n);
+                if (w < len && (gi[k] >> 30) == CLS_SMALL) stage[w] = (m.dbg & 32u) ? (u64)sf[k] * 0x9E3779B97F4A7C15ull : ms_key8(txt, sf[k], n);
             }
 #pragma unroll
             for (int k = 0; k < KH; k++) {
@@ -1039,21 +1112,21 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
                 if (w < len && (gi[k] >> 30) == CLS_SMALL) stage[w] = kk[k];
             }
             __syncthreads();
+            if (binc) pendG = atomicAdd(&m.bincur[(size_t)b * 256 + tid], binc);
         }
         MS_T(6);
         // ---- the first doubling step of the small groups: every member counts the members that sort before it
-        uint32_t hg[MS_ITEMS]; // [class : 2 @30][first position of the element's group in the block's order : 20]
+        // (gi[k] becomes [class : 2 @30][first position of the element's group in the block's order : 20])
         {
             uint32_t nsv = 0; // my records for the two lists: small groups | large groups << 16
 #pragma unroll
             for (int k = 0; k < MS_ITEMS; k++) {
                 const uint32_t w = k * MS_THREADS + tid;
-                hg[k] = 0;
                 if (w < len) {
                     uint32_t c = gi[k] >> 30;
                     const uint32_t g = gi[k] & 8191u;
                     uint32_t hp = s + g, dest = w;
-                    if (fuse && c == CLS_SMALL) {
+                    if (fuse && c == CLS_SMALL && !(m.dbg & 64u)) {
                         const uint32_t ge = g + ((gi[k] >> 24) & 63u) + 1u;
                         const u64 my = stage[w];
                         uint32_t less = 0, eq = 0, eqb = 0;
@@ -1069,15 +1142,16 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
                         if (eq == 1u) c = CLS_SINGLE;
                     }
                     if (uniform) hp = tbl;
-                    hg[k] = (c << 30) | hp;
+                    gi[k] = (c << 30) | hp;
                     nsv += (c == CLS_SMALL ? 1u : 0u) + (c == CLS_BIG ? 0x10000u : 0u);
                     sl[k >> 1] = (sl[k >> 1] & ~(0xFFFFu << (16 * (k & 1)))) | (dest << (16 * (k & 1)));
                 }
             }
-            nsv = wave_reduce_add(nsv);
+            nsv = wave_all_add(nsv);
             if (lane == 0) lsv[wave] = nsv;
         }
         __syncthreads(); // the keys have been read: the stage is free
+        if (!fuse && binc) pendG = atomicAdd(&m.bincur[(size_t)b * 256 + tid], binc);
         MS_T(7);
         uint32_t pendS = 0, pendB = 0;
         if (tid == 0) { // (a unit holds at most 8192 records: 16 bits each)
@@ -1098,7 +1172,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
         for (int k = 0; k < MS_ITEMS; k++) {
             const uint32_t w = k * MS_THREADS + tid;
             if (w < len) {
-                const uint32_t c = hg[k] >> 30, head = hg[k] & 0xFFFFFu;
+                const uint32_t c = gi[k] >> 30, head = gi[k] & 0xFFFFFu;
                 const uint32_t word = c == CLS_SINGLE ? (head | RANK_RESOLVED) : head;
                 stage[atomicAdd(&bcur[sf[k] >> 12], 1u)] = ((u64)word << 32) | sf[k];
             }
@@ -1119,8 +1193,8 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
         for (int k = 0; k < MS_ITEMS; k++) {
             const uint32_t w = k * MS_THREADS + tid;
             if (w < len) {
-                const uint32_t c = hg[k] >> 30;
-                const u64 rec = ((u64)(hg[k] & 0xFFFFFu) << 40) | sf[k];
+                const uint32_t c = gi[k] >> 30;
+                const u64 rec = ((u64)(gi[k] & 0xFFFFFu) << 40) | sf[k];
                 stage[(sl[k >> 1] >> (16 * (k & 1))) & 0xFFFFu] = c == CLS_SMALL ? rec : (c == CLS_BIG ? (rec | MS_REC_BIG) : LIST_INVALID);
             }
         }
@@ -1141,7 +1215,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
             __syncthreads(); // the row counts are there (and the records in registers)
             // exclusive scan of the row counts in slot order (every wavefront for itself: 128 values, two a lane)
             const uint32_t c0 = wc[2 * lane], c1 = wc[2 * lane + 1];
-            const uint32_t inc = wave_incl_add(c0 + c1, lane);
+            const uint32_t inc = wave_incl_add(c0 + c1, ms_opaque(lane));
             const uint32_t ex0 = inc - c0 - c1, ex1 = inc - c1;
             u64 *ts = m.tail + (size_t)b * m.S + s_offS;
             u64 *bs = m.big + (size_t)b * m.S + s_offB;
@@ -1208,7 +1282,7 @@ static int msd_initial_sort(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t nt
         m.force_new = init_msd ? 1u : 0u;
     }
     m.dbg = getenv("BZH_MSD_DBG") ? (uint32_t)atoi(getenv("BZH_MSD_DBG")) : 0u;
-    HIP_TRY(ctx, hipMemsetAsync(bt.ms_cnt, 0, (MS_CNT_WORDS + (size_t)(MS_LEVELS + 1) * B) * sizeof(uint32_t), st));
+    HIP_TRY(ctx, hipMemsetAsync(bt.ms_cnt, 0, (MS_CNT_WORDS + (size_t)(MS_LEVELS + 2) * B) * sizeof(uint32_t), st));
     HIP_TRY(ctx, hipMemsetAsync(bt.ms_bincur, 0, (size_t)B * 256 * sizeof(uint32_t), st));
     {
         KSpan ks(ctx, K_MSD_PLAN, force_old ? 0 : ntotal, 2);

@@ -119,7 +119,7 @@ struct Batch {
     uint4 *ms_units;     // [B * MS_UNIT_CAP] work list of the finishing kernel
     uint4 *ms_segs;      // [MS_LEVELS + 1][B * MS_SEG_SLOTS] oversized buckets per level
     uint32_t *ms_items;  // [MS_LEVELS + 1][B * MS_ITEM_CAP] (oversized bucket, tile) pairs per level
-    uint32_t *ms_cnt;    // [MS_CNT_WORDS + (MS_LEVELS + 1) * B] counters; per-block slot counters of the levels behind them
+    uint32_t *ms_cnt;    // [MS_CNT_WORDS + (MS_LEVELS + 2) * B] counters; behind them per block: units, slot counters of the levels, unit tickets
     uint32_t *ms_np;     // [B] 1: the block takes the bucket-first path (its first doubling round has depth 7)
     uint32_t *ms_old, *ms_new; // [B] ids of the blocks on the 8-pass path / on the bucket-first path
     uint32_t *ms_bincur; // [B][256] rank binning: pairs already claimed in each 4096-suffix window
@@ -322,6 +322,47 @@ __device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v)
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
     return v;
+}
+
+// Wavefront reductions without address registers: five ds_swizzle steps (the xor pattern is an immediate) and two lane
+// reads.  The __shfl_xor forms above cost six lane-dependent addresses, which a kernel that loops over work items keeps alive
+// across the whole loop -- in a kernel at its register limit that is six registers in scratch memory.  Result in every lane.
+#define BZH_SWZ(v, x) __builtin_amdgcn_ds_swizzle((int)(v), ((x) << 10) | 0x1F)
+__device__ __forceinline__ uint32_t wave_all_add(uint32_t v)
+{
+    v += (uint32_t)BZH_SWZ(v, 1);
+    v += (uint32_t)BZH_SWZ(v, 2);
+    v += (uint32_t)BZH_SWZ(v, 4);
+    v += (uint32_t)BZH_SWZ(v, 8);
+    v += (uint32_t)BZH_SWZ(v, 16);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
+}
+__device__ __forceinline__ uint32_t wave_all_max(uint32_t v)
+{
+    v = max(v, (uint32_t)BZH_SWZ(v, 1));
+    v = max(v, (uint32_t)BZH_SWZ(v, 2));
+    v = max(v, (uint32_t)BZH_SWZ(v, 4));
+    v = max(v, (uint32_t)BZH_SWZ(v, 8));
+    v = max(v, (uint32_t)BZH_SWZ(v, 16));
+    return max((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 32));
+}
+__device__ __forceinline__ uint32_t wave_all_or(uint32_t v)
+{
+    v |= (uint32_t)BZH_SWZ(v, 1);
+    v |= (uint32_t)BZH_SWZ(v, 2);
+    v |= (uint32_t)BZH_SWZ(v, 4);
+    v |= (uint32_t)BZH_SWZ(v, 8);
+    v |= (uint32_t)BZH_SWZ(v, 16);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
+}
+__device__ __forceinline__ uint32_t wave_all_and(uint32_t v)
+{
+    v &= (uint32_t)BZH_SWZ(v, 1);
+    v &= (uint32_t)BZH_SWZ(v, 2);
+    v &= (uint32_t)BZH_SWZ(v, 4);
+    v &= (uint32_t)BZH_SWZ(v, 8);
+    v &= (uint32_t)BZH_SWZ(v, 16);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) & (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
 }
 
 // Workgroup exclusive add-scan of one value per thread.  `lds` needs (threads/64)+1 words.
