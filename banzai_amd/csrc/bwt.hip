@@ -1969,6 +1969,40 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
     }
 }
 
+// ---- one launch clears everything a sort starts from ---------------------------------------------------------------
+// (a hipMemsetAsync is a kernel of its own, about 5 us each back to back: eight of them were 45 us of every step)
+struct ClearArgs {
+    uint4 *p[10];         // 16-byte aligned regions (carved at 256-byte boundaries)
+    unsigned long long q[10]; // their lengths in 16-byte words, as a running total (region k = [q[k-1], q[k]))
+    int n;
+};
+__global__ void __launch_bounds__(256) bwt_clear(ClearArgs c)
+{
+    const unsigned long long total = c.q[c.n - 1];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (unsigned long long)gridDim.x * 256) {
+        int k = 0;
+        while (i >= c.q[k]) k++;
+        c.p[k][i - (k ? c.q[k - 1] : 0ull)] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+struct ClearList {
+    ClearArgs a{};
+    void add(void *p, size_t bytes)
+    {
+        if (!bytes || a.n >= 10) return;
+        a.p[a.n] = reinterpret_cast<uint4 *>(p);
+        a.q[a.n] = (a.n ? a.q[a.n - 1] : 0ull) + (bytes + 15) / 16; // (regions end at 256-byte boundaries of the arena: rounding up stays inside)
+        a.n++;
+    }
+    void launch(hipStream_t st)
+    {
+        if (!a.n) return;
+        const unsigned long long total = a.q[a.n - 1];
+        const unsigned grid = (unsigned)std::min<unsigned long long>(4096ull, (total + 255) / 256);
+        bwt_clear<<<dim3(grid), 256, 0, st>>>(a);
+    }
+};
+
 #include "bwt_msd.h"
 
 // ---- host driver -----------------------------------------------------------------------------------
@@ -2156,13 +2190,14 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     a.doff = 0;
     a.err = bt.errflag;
     a.pass = 0;
-    HIP_TRY(ctx, hipMemsetAsync(bt.errflag, 0, sizeof(uint32_t), st));
-    HIP_TRY(ctx, hipMemsetAsync(a.look, 0, (size_t)B * bt.TPB * NBMAX * sizeof(u64), st));
-    HIP_TRY(ctx, hipMemsetAsync(bt.tagg, 0, (size_t)B * bt.TPB * sizeof(int4), st));
-    HIP_TRY(ctx, hipMemsetAsync(bt.dtot, 0, (size_t)B * DB_STRIDE * sizeof(uint32_t), st));
+    ClearList clr; // launched below, once it is known whether the bucket tables are used
+    clr.add(bt.errflag, sizeof(uint32_t));
+    clr.add(a.look, (size_t)B * bt.TPB * NBMAX * sizeof(u64));
+    clr.add(bt.tagg, (size_t)B * bt.TPB * sizeof(int4));
+    clr.add(bt.dtot, (size_t)B * DB_STRIDE * sizeof(uint32_t));
     // round state: everything from st_mode to the 64-bit counter (one contiguous carve, see layout_batch)
-    HIP_TRY(ctx, hipMemsetAsync(bt.st_mode, 0,
-                                (size_t)((uint8_t *)(bt.stat_A + 1) - (uint8_t *)bt.st_mode), st));
+    clr.add(bt.st_mode, (size_t)((uint8_t *)(bt.stat_A + 1) - (uint8_t *)bt.st_mode));
+    clr.add(bt.hasbyte, (size_t)B * 256); // (bwt_emit ORs into it at the very end)
     // The second stream of the suffix sort (created once): the big-list path of a round runs on it beside the small-group
     // kernel, and so do the 8 passes of the blocks that keep them when the rest of the batch takes the bucket-first
     // initial sort.  (With profiling on everything stays on one stream, or the per-kernel spans would overlap.)
@@ -2203,6 +2238,14 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     static_assert(sizeof(u64) == 2 * sizeof(uint32_t), "sa and headp together hold one 64-bit word per suffix");
     volatile uint32_t *const hrec0 = ctx->h_pinned + (size_t)mb * 8 + 64; // [MAX_ROUNDS + 1][SUMMARY_WORDS]
     const uint32_t epoch = (++ctx->bwt_epoch & 0xFFFFFFu) << 6;
+    if (use_msd) { // (its counters, rank-window cursors and bigram counts join the one clearing launch)
+        clr.add(bt.ms_cnt, (MS_CNT_WORDS + (size_t)(MS_LEVELS + 2) * B) * sizeof(uint32_t));
+        clr.add(bt.ms_bincur, (size_t)B * 256 * sizeof(uint32_t));
+        clr.add(bt.ms_bgcur, (size_t)B * MS_BG * sizeof(uint32_t));
+    } else {
+        clr.add(bt.ms_np, (size_t)B * sizeof(uint32_t));
+    }
+    clr.launch(st);
     if (use_msd) {
         BZH_TRY(msd_initial_sort(ctx, B, nmax, ntotal, bufB, bufD, bufA, bufC, binned, false, r0_fused,
                                  hrec0 + (size_t)MAX_ROUNDS * SUMMARY_WORDS, epoch + 63u, &nOld, side ? ctx->side_ev[0] : nullptr));
@@ -2218,8 +2261,6 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
                 fprintf(stderr, "[bzhip] chunk_finish, 16-cycle ticks over all workgroups: ticket+load+bucket index %u, ranking %u, stage scatter+barrier %u, reload %u, heads+suffix table %u, suffixes+extents+bins %u, keys+bin scan %u, all pairs %u, rank pairs out %u, lists out %u\n",
                         c[32], c[33], c[34], c[35], c[36], c[37], c[38], c[39], c[40], c[41]);
         }
-    } else {
-        HIP_TRY(ctx, hipMemsetAsync(bt.ms_np, 0, (size_t)B * sizeof(uint32_t), st));
     }
     const uint64_t ntotal_old = nOld == B ? ntotal : ntotal * nOld / B; // (statistics only)
     u64 *cur = bufA, *oth = bufB;
@@ -2650,7 +2691,6 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         return BZH_E_HIP;
     }
 
-    HIP_TRY(ctx, hipMemsetAsync(bt.hasbyte, 0, (size_t)B * 256, st));
     uint32_t gx = (nmax + 1023) / 1024;
     if (gx > 256) gx = 256;
     if (gx == 0) gx = 1;

@@ -1282,12 +1282,10 @@ static int msd_initial_sort(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t nt
         m.force_new = init_msd ? 1u : 0u;
     }
     m.dbg = getenv("BZH_MSD_DBG") ? (uint32_t)atoi(getenv("BZH_MSD_DBG")) : 0u;
-    HIP_TRY(ctx, hipMemsetAsync(bt.ms_cnt, 0, (MS_CNT_WORDS + (size_t)(MS_LEVELS + 2) * B) * sizeof(uint32_t), st));
-    HIP_TRY(ctx, hipMemsetAsync(bt.ms_bincur, 0, (size_t)B * 256 * sizeof(uint32_t), st));
+    // (bt.ms_cnt, bt.ms_bincur and bt.ms_bgcur arrive cleared: bwt_run's one clearing launch)
     {
         KSpan ks(ctx, K_MSD_PLAN, force_old ? 0 : ntotal, 2);
         if (!force_old) {
-            HIP_TRY(ctx, hipMemsetAsync(bt.ms_bgcur, 0, (size_t)B * MS_BG * sizeof(uint32_t), st));
             bigram_hist<<<dim3(BGH_SEGS, B), 1024, 0, st>>>(m);
         }
         bigram_plan<<<dim3(B), 1024, 0, st>>>(m, const_cast<uint32_t *>(hrec), seq);

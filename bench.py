@@ -18,8 +18,10 @@ Timed region: K steps with profiling OFF (the product's default path).  Stage ti
 roofline (HIP events on the context's stream) and the counters of `roofline.path_frac` come from a
 second, untimed pass of the same K steps with profiling on.
 
-Output: ONE JSON line on rank 0 (see the driver contract) with `roofline` (dominant kernel class
-radix_scatter + the whole path by SURVEY 8(d)'s fixed accounting), `cpu_baseline` (the oracle =
+Output: ONE JSON line on rank 0 (see the driver contract) with `roofline` (the kernel class that took the most time
+in the profiled pass -- chunk_finish since the bucket-first initial sort -- its launches timed by HIP events on the
+stream it runs on, the ten most expensive classes beside it, and the whole path by SURVEY 8(d)'s fixed accounting),
+`cpu_baseline` (the oracle =
 single-thread C restatement of banzai's path, timed on the same workload; also the bit-exactness
 check), `value_host_inclusive` (pinned host buffers through bzh_encode, PCIe inside the clock), `value_stream_api` (the
 reference's API surface: the streaming entry points fed from pageable memory, C ABI and banzai_amd.encode),
@@ -514,12 +516,17 @@ def main():
                          # the whole path by SURVEY 8(d)'s fixed accounting, over the TIMED region (all ranks)
                          "path_alg_bytes_per_step": round(alg), "path_achieved": round(path_gbs, 1),
                          "path_frac": round(path_gbs / (HBM_PEAK_GBS * world), 4),
-                         "path_A_convention": "A = unresolved suffixes entering each doubling round actually run "
-                                              "(depth 8 onwards: the 8-byte initial sort stands in for the h=4 round)"},
+                         "path_A_convention": "A = unresolved suffixes entering each doubling round actually run (a block on "
+                                              "the bucket-first initial sort enters round 0 at depth 7 with the small groups "
+                                              "already at depth 15 -- they are counted in round 0's A all the same; a block on "
+                                              "the 8 passes enters at depth 8)"},
             "cpu_baseline": cpu,
             "value_host_inclusive": host_incl,
             "value_stream_api": stream_api,
             "value_real_text": (extras or {}).get("real-text-100MB", {}).get("MB/s"),
+            # the generator rounds 1-3 quoted their headline on (driver lines on it: r1 6,344, r2 7,146, r3 8,858; r4 measured 8,977 on it in `extra_workloads`):
+            # the same-input series across rounds
+            "value_v1": (extras or {}).get("enwik8-synthetic-v1", {}).get("MB/s"),
             "workload_sha256": corpus.corpus_digest(seg) if not multi else None,
             # north_star's ">= 10x banzai's CPU path, one thread": quoted on the LOWER of the headline and the real-text
             # workload (GPU MB/s over the oracle's MB/s on the same bytes)

@@ -16,7 +16,7 @@ def _line(name):
 
 import pytest
 
-ROUNDS = [r for r in ("r01", "r02", "r03", "r04") if os.path.exists(os.path.join(PROF, f"{r}_bench_n1.json"))]
+ROUNDS = [r for r in ("r01", "r02", "r03", "r04", "r05") if os.path.exists(os.path.join(PROF, f"{r}_bench_n1.json"))]
 
 
 @pytest.mark.parametrize("rnd", ROUNDS)
@@ -38,8 +38,8 @@ def test_bench_line_contract(rnd):
         assert all(w.get("bit_exact", True) for w in d["extra_workloads"].values())
     if rnd not in ("r01", "r02"):  # round 3 on: per-kernel-class table, where the traffic figure comes from, real text
         assert len(r["kernels"]) >= 6 and all(0 < k["frac"] < 1 for k in r["kernels"] if k["frac"] is not None)
-        if rnd == "r03":
-            assert f"profiles/{rnd}_pmc_traffic.json" in r["traffic_source"]
+        # (the line names the newest committed PMC file when it is written: the round's own, collected by the same script)
+        assert f"profiles/{rnd}_pmc_traffic.json" in r["traffic_source"] and r["traffic"] > 0
         rt = d["extra_workloads"]["real-text-100MB"]
         assert rt["bytes"] == 100_000_000 and rt["bit_exact"] and rt["rounds"] > 0 and rt["A/n"] > 0
         assert all(d["extra_workloads"][k]["MB/s"] >= 3000 for k in d["extra_workloads"] if k.startswith("c5-"))
@@ -50,6 +50,8 @@ def test_bench_line_contract(rnd):
         assert "enwik8-synthetic-v2" in d["config"]["workload"] and "enwik8-synthetic-v1" in d["extra_workloads"]
         assert "sha256" in d["extra_workloads"]["real-text-100MB"]
         assert r["kernel"] == r["kernels"][0]["kernel"]  # the dominant class is the one that took the most time
+    if rnd not in ("r01", "r02", "r03", "r04"):  # round 5 on: the same-input series (rounds 1-3's generator) in the line itself
+        assert d["value_v1"] == d["extra_workloads"]["enwik8-synthetic-v1"]["MB/s"] and d["value_v1"] > 8000
     # value is whole-job throughput of the named workload: bytes per step / time per step
     assert abs(d["value"] - 100_000_000 / d["ms_per_step"] / 1e3) / d["value"] < 0.01
 
