@@ -1434,6 +1434,7 @@ struct TailArgs {
     uint32_t *c_tail;    // [B] survivors of the round
     uint32_t *c_prog;    // [B] "a group was refined"
     uint32_t tag;        // this round's id in the rank words
+    uint32_t dbg;        // timing experiments only (BZH_TAIL_DBG: 1 = no ranking loop, 2 = no rank stores, 4 = no key gather; wrong results)
     uint32_t *err;       // [1] precondition violations
     const uint32_t *hb;  // [B] depth h of each block
     uint32_t S, T;
@@ -1493,7 +1494,7 @@ __global__ void __launch_bounds__(TR_THREADS) tail_round(TailArgs a)
                 if (h < n) {
                     uint32_t i2 = i + h;
                     if (i2 >= n) i2 -= n;
-                    const uint32_t k2 = rank_at(rank[rslot(i2)], tag);
+                    const uint32_t k2 = (a.dbg & 4u) ? i2 * 2654435761u >> 12 : rank_at(rank[rslot(i2)], tag);
                     key = (key_t)k2;
                     if (QUAD) { // two more h-blocks of the (cyclic) rotation
                         uint32_t i3 = i2 + h;
@@ -1552,6 +1553,7 @@ __global__ void __launch_bounds__(TR_THREADS) tail_round(TailArgs a)
             }
             const key_t my = K[w];
             uint32_t less = 0, eq = 0, eqb = 0;
+            if (a.dbg & 1u) ge = g;
 #pragma unroll 4
             for (uint32_t f = g; f < ge; f++) { // bounds known up front: the LDS reads pipeline
                 const key_t kf = K[f];
@@ -1566,7 +1568,7 @@ __global__ void __launch_bounds__(TR_THREADS) tail_round(TailArgs a)
                 // only if the rank moved: nobody reads the "resolved" bit of a block in SPLIT mode (the SA-order
                 // enumeration of SWEEP mode is its one reader), and a random 4-byte store is the most expensive
                 // thing this kernel does (it leaves the XCD as a partial 64-byte write).
-                if (less) rank[rslot(ci[k])] = rank_word(cr[k], less, tag, single);
+                if (less && !(a.dbg & 2u)) rank[rslot(ci[k])] = rank_word(cr[k], less, tag, single);
                 nsurv += single ? 0u : 1u;
             }
             res[k] = (owned ? 0x80000000u : 0u) | (single ? 0x40000000u : 0u) | (less << 24) | (g + less + eqb);
@@ -2374,6 +2376,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     ta.err = bt.errflag;
     ta.hb = bt.st_h;
     ta.S = bt.S;
+    ta.dbg = getenv("BZH_TAIL_DBG") ? (uint32_t)atoi(getenv("BZH_TAIL_DBG")) : 0u;
 
     // ---- doubling rounds, queued one ahead of the summaries ---------------------------------------------
     // round_begin writes its summary straight into pinned host memory and sets the record's last word to

@@ -51,6 +51,30 @@ def block_range(nblocks, rank, world):
     return rank * nblocks // world, (rank + 1) * nblocks // world
 
 
+def set_plan_cost(split_ms_per_block, encode_ms_per_block):
+    """Chooses PLAN_COST from a measurement (bench.py times one split and one encode of the first rank's bytes and
+    broadcasts the two figures, so that every rank computes the same offsets): half the ratio, as above, kept inside
+    [0, 0.05].  Must be called on every rank, with the same values, before anything asks for `offsets`."""
+    global PLAN_COST
+    if encode_ms_per_block > 0:
+        PLAN_COST = min(0.05, max(0.0, 0.5 * split_ms_per_block / encode_ms_per_block))
+    return PLAN_COST
+
+
+def model_finish_ms(n, world, split_ms_per_block, encode_ms_per_block, block_bytes):
+    """The chain's arithmetic, per rank: rank r starts cutting when the r ranks before it have cut (their split times add
+    up), then cuts and encodes its own range -> [(wait, split, encode, finish)] in ms.  (Not in it: the 8-byte hops,
+    the gather and the assembly on rank 0.)"""
+    b = offsets(n, world)
+    out, wait = [], 0.0
+    for r in range(world):
+        blocks = (b[r + 1] - b[r]) / max(1, block_bytes)
+        sp, en = blocks * split_ms_per_block, blocks * encode_ms_per_block
+        out.append((wait, sp, en, wait + sp + en))
+        wait += sp
+    return out
+
+
 def offsets(n, world):
     """Range boundaries B_0..B_world (bytes): geometric lengths, ratio 1/(1 + PLAN_COST)."""
     q = 1.0 / (1.0 + PLAN_COST)

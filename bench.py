@@ -68,6 +68,9 @@ def self_launch(args):
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver of this pool only supports dmabuf IPC; with the legacy mode RCCL's
+    # cross-process buffer registration fails with "hipIpcGetMemHandle: invalid argument" (the image exports the variable
+    # already; a launch from a stripped environment must not lose it)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     return subprocess.call(cmd, env=env)
 
@@ -130,6 +133,40 @@ def main():
     seg_len = max(0, min(seg_bytes, total - rank * seg_bytes))
     seg, wname = corpus.workload(max(1, seg_len), segment=rank)
     seg = seg[:seg_len]
+    calib = None
+    if multi:
+        # how much shorter rank r+1's range is than rank r's follows from what one block costs to CUT (the chain every later
+        # rank waits for) against what it costs to ENCODE: rank 0 measures both on the first bytes of the workload, everyone
+        # takes its figures (sharded.set_plan_cost), and the line carries the chain's arithmetic per rank beside the clocks
+        cal = torch.zeros(3, dtype=torch.float64, device=cdev)
+        if rank == 0 and seg_len:
+            cn = min(seg_len, 30_000_000)
+            d_c = torch.zeros(cn + 16, dtype=torch.uint8, device=dev)
+            d_c[:cn] = torch.from_numpy(seg[:cn]).to(dev)
+            d_co = torch.zeros((cn + cn // 4 + (1 << 20)) & ~3, dtype=torch.uint8, device=dev)
+            with nv.Context(local_rank, LEVEL, 128) as cctx:
+                cctx.encode_device(d_c.data_ptr(), cn, d_co.data_ptr(), d_co.numel())  # (first touch)
+                best_s = best_e = None
+                for _ in range(3):
+                    cctx.plan_tables_device(d_c.data_ptr(), cn)
+                    torch.cuda.synchronize()
+                    tq = time.perf_counter()
+                    cctx.plan_split_device(0, None, crc=False)
+                    torch.cuda.synchronize()
+                    ds = time.perf_counter() - tq
+                    nbk = len(cctx.plan_blocks_np())
+                    tq = time.perf_counter()
+                    cctx.encode_range_device(0, nbk, d_co.data_ptr(), d_co.numel())
+                    torch.cuda.synchronize()
+                    de = time.perf_counter() - tq
+                    best_s = ds if best_s is None or ds < best_s else best_s
+                    best_e = de if best_e is None or de < best_e else best_e
+                cal[0], cal[1], cal[2] = best_s * 1e3 / nbk, best_e * 1e3 / nbk, cn / nbk
+            del d_c, d_co
+        dist.broadcast(cal, src=0)
+        calib = [float(x) for x in cal.tolist()]
+        if calib[1] > 0:
+            sharded.set_plan_cost(calib[0], calib[1])
     lo_res, hi_res = sharded.resident_range(total, rank, world) if multi else (0, total)
     resident = hi_res - lo_res
     d_in = torch.zeros(resident + 16, dtype=torch.uint8, device=dev)
@@ -259,6 +296,9 @@ def main():
         rows = allr.view(world, -1).tolist()
         per_rank = [dict({k: round(v, 3) for k, v in zip(keys, row)}, resident_bytes=int(row[4]), encoded_input_bytes=int(row[5]))
                     for row in rows]
+        if calib and calib[1] > 0:  # the chain's arithmetic from rank 0's calibration (sharded.model_finish_ms), beside the clocks
+            for row, (mw, msp, men, mfin) in zip(per_rank, sharded.model_finish_ms(total, world, calib[0], calib[1], calib[2])):
+                row["model"] = {"wait": round(mw, 3), "split": round(msp, 3), "encode": round(men, 3), "finish": round(mfin, 3)}
         # rank 0 also checks the sharded stream against one GPU encoding the whole input (untimed)
         d_full = torch.zeros(seg_bytes * world + 16, dtype=torch.uint8, device=cdev) if rank == 0 else None
         parts = [d_full[k * seg_bytes:(k + 1) * seg_bytes] for k in range(world)] if rank == 0 else None
@@ -490,6 +530,9 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong" if args.total_bytes else "weak",
             "ranks_seen": dist.get_world_size() if multi else 1, "per_rank": per_rank,
+            "chain_calibration": ({"split_ms_per_block": round(calib[0], 5), "encode_ms_per_block": round(calib[1], 5),
+                                   "input_bytes_per_block": round(calib[2]), "plan_cost": round(sharded.PLAN_COST, 5)}
+                                  if calib and calib[1] > 0 else None),
             "collective_backend": dist.get_backend() if multi else None,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic" if wname != "enwik8" else "enwik8",
             "config": {"workload": f"level {LEVEL} {wname}, {seg_bytes} bytes per GPU, {total} bytes in one stream, "

@@ -1005,3 +1005,35 @@ def test_bench_multi_rank_flow_on_one_gpu(extra):
     assert line["checks"]["sharded_equals_single_gpu"] and line["checks"]["libbz2_roundtrip"]
     assert line["checks"]["bit_exact_vs_oracle_sample"] and all(line["checks"].values())
     assert sum(r["encoded_input_bytes"] for r in line["per_rank"]) == (70000000 if extra[0] == "--total-bytes" else 90000000)
+
+
+@pytest.mark.gpu
+def test_bench_world_eight_on_one_gpu():
+    """World 8 as far as one GPU allows, so that the driver's 8-GPU run is not the first time eight ranks meet: EIGHT real
+    processes through `bench.py --gpus 8 --total-bytes 400000000` (BASELINE config 4's shape at 0.4 x: one stream over
+    eight ranks, 55 blocks a rank), all computing on cuda:0 with the collectives over gloo on host tensors
+    (BZH_BENCH_SHARED_GPU=1) -- the chain of eight 8-byte hand-offs over the side group, the meta row of the
+    all-gather at its world-8 width, eight slabs gathered and funnel-shifted on rank 0, the per-rank rows, and the
+    script's checks: the sharded stream equals one GPU's encode of the same 400 MB and the oracle agrees on its sample."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BZH_BENCH_SHARED_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1",
+                        "--cpu-sample", "4000000", "--no-extra", "--total-bytes", "400000000"], capture_output=True, text=True,
+                       timeout=1500, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and len(line["per_rank"]) == 8 and line["scaling"] == "strong"
+    assert line["checks"]["sharded_equals_single_gpu"] and line["checks"]["bit_exact_vs_oracle_sample"] and all(line["checks"].values())
+    assert sum(r["encoded_input_bytes"] for r in line["per_rank"]) == 400000000
+    # ranges shrink with the rank (each rank waits for the splits before it) and rank 0's is discounted for the gather
+    own = [r["encoded_input_bytes"] for r in line["per_rank"]]
+    assert max(own) < 1.15 * min(own) and all(r["ms_encode"] > 0 for r in line["per_rank"])
+    # the chain's arithmetic from rank 0's calibration stands beside the clocks: later ranks wait longer, in the model too
+    cal = line["chain_calibration"]
+    assert 0 < cal["split_ms_per_block"] < cal["encode_ms_per_block"] and 0 <= cal["plan_cost"] <= 0.05
+    waits = [r["model"]["wait"] for r in line["per_rank"]]
+    assert waits[0] == 0 and all(a < b for a, b in zip(waits, waits[1:]))

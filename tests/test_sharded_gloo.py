@@ -291,3 +291,23 @@ def test_block_range_partition():
             assert got[0][0] == 0 and got[-1][1] == nb
             assert all(got[k][1] == got[k + 1][0] for k in range(world - 1))
             assert max(b - a for a, b in got) - min(b - a for a, b in got) <= 1
+
+
+def test_plan_cost_from_a_measurement_and_the_chain_model():
+    """sharded.set_plan_cost / model_finish_ms (bench.py calibrates on rank 0 and broadcasts): the ranges follow the
+    measured split / encode ratio, every rank computes the same offsets, and the model's wait of rank r is the sum of
+    the splits before it."""
+    from banzai_amd import sharded
+    old = sharded.PLAN_COST
+    try:
+        assert sharded.set_plan_cost(0.002, 0.086) == pytest.approx(0.5 * 0.002 / 0.086)
+        b = sharded.offsets(800_000_000, 8)
+        lens = [b[k + 1] - b[k] for k in range(8)]
+        assert b[0] == 0 and b[-1] == 800_000_000 and all(x > y for x, y in zip(lens[1:], lens[2:]))
+        m = sharded.model_finish_ms(800_000_000, 8, 0.002, 0.086, 1_000_000)
+        assert m[0][0] == 0 and m[3][0] == pytest.approx(sum(x[1] for x in m[:3]))
+        assert all(abs(x[3] - (x[0] + x[1] + x[2])) < 1e-9 for x in m)
+        assert sharded.set_plan_cost(1.0, 0.086) == 0.05 and sharded.set_plan_cost(0.0, 0.086) == 0.0  # clamped
+        assert sharded.set_plan_cost(0.002, 0.0) == 0.0  # (no measurement: unchanged)
+    finally:
+        sharded.PLAN_COST = old
