@@ -433,134 +433,258 @@ __device__ void plan_prefetch(const PlanArrays &pa, uint32_t lane)
     if (sink == 0x9E3779B9u && lane == 77u) pa.nblocks[1] = sink; // (never: keeps the loads alive)
 }
 
-__global__ void __launch_bounds__(128) plan_split(PlanArrays pa)
+// ---- one cut, by one wavefront --------------------------------------------------------------------------------------
+struct CutState { // the granule the wavefront evaluated last (usually needed again by the next step)
+    Gran ev{};
+    uint32_t idx = 0xFFFFFFFFu;
+};
+struct CutEnd { // where a block ends whose largest canonical offset that still fits is `lim` (lim < total)
+    uint32_t end;  // input position of the cut
+    uint32_t R;    // budget that was left for the run the cut falls into
+    uint32_t kt;   // canonical bytes taken from that run (5 per full chunk + literals)
+    uint32_t open; // the cut could move if more input followed
+};
+
+// The second half of a cut: last tile / granule / run start whose canonical offset is <= lim, then the closed form inside
+// that run.  `lo_tile`: a tile known to start at or before lim.  Also what tells where a LATER block would start if
+// every block before it ended exactly on its budget (plan_split's speculation).
+__device__ __forceinline__ CutEnd end_from_lim(const PlanArrays &pa, uint32_t lane, uint64_t lim, uint32_t lo_tile, CutState &cs)
 {
-    if (threadIdx.x >= 64) {
-        plan_prefetch(pa, threadIdx.x - 64u);
+    const uint32_t N = (uint32_t)pa.n, NT = pa.ntiles;
+    // last tile with tc <= lim: probe 64 tiles around the literal-text guess, else 64-ary search
+    uint32_t lo = lo_tile, hi = NT - 1; // tc[lo] <= lim
+    {
+        long long guess = (long long)lo + (long long)((lim - pa.tc[lo]) / RL_TILE) - 40;
+        if (guess < (long long)lo) guess = lo;
+        if (guess > (long long)hi) guess = hi;
+        const uint32_t w0 = (uint32_t)guess; // lo <= w0 <= hi
+        const uint32_t x = w0 + lane;
+        const bool ok = x <= hi && pa.tc[x] <= lim;
+        const unsigned long long m = __ballot(ok); // tc is nondecreasing: a prefix of the window
+        if (m & 1ull) {
+            const uint32_t c = (uint32_t)__popcll(m);
+            lo = w0 + c - 1;
+            if (c < 64) hi = lo; // tc[lo+1] > lim or lo is the last tile
+        } else {
+            hi = w0 - 1; // tc[w0] > lim, and w0 > lo because tc[lo] <= lim
+        }
+    }
+    while (lo < hi) {
+        const uint32_t span = hi - lo;
+        const uint32_t step = (span + 63u) / 64u;
+        const uint64_t x = (uint64_t)lo + (uint64_t)(lane + 1) * step;
+        const bool ok = x <= hi && pa.tc[x] <= lim;
+        const uint32_t c = (uint32_t)__popcll(__ballot(ok));
+        lo += c * step;
+        const uint64_t nh = (uint64_t)lo + step - 1;
+        if (nh < hi) hi = (uint32_t)nh;
+    }
+    const uint32_t tl = lo;
+    // last granule of that tile whose start offset is <= lim
+    const uint32_t gb = tl * GRAN_PER_TILE;
+    const uint32_t gidx = gb + lane;
+    const bool gok = (uint64_t)gidx * GRAN < pa.n && pa.tc[tl] + pa.cg[gidx] <= lim;
+    const uint32_t gx = gb + (uint32_t)__popcll(__ballot(gok)) - 1u; // lane 0 always ok
+    if (gx != cs.idx) {
+        cs.ev = gran_eval(pa, gx, lane);
+        cs.idx = gx;
+    }
+    const Gran &gr = cs.ev;
+    // last run start in the granule that still fits, else the run covering the granule
+    const unsigned long long fit = __ballot(gr.start && gr.cpos <= lim);
+    uint32_t x;
+    uint64_t Cx;
+    if (fit) {
+        const int l = 63 - __clzll((long long)fit);
+        x = gx * GRAN + (uint32_t)l;
+        Cx = __shfl(gr.cpos, l, 64);
+    } else {
+        x = pa.rsg[gx];
+        Cx = __shfl(gr.cpos, 0, 64) - emitted_before(gx * GRAN - x);
+    }
+    CutEnd r;
+    r.R = (uint32_t)(lim - Cx); // budget left for the run starting at x
+    const uint32_t xe = (x / GRAN == cs.idx) ? next_start_in(pa, cs.ev, cs.idx, x) : next_start_after(pa, x, lane);
+    const uint32_t Lx = xe - x;
+    r.open = xe >= N && (uint64_t)Lx < 255ull * (r.R / 5u + 2u);
+    uint32_t k, t;
+    cut_in_run(Lx, r.R, k, t);
+    r.end = x + 255u * k + t;
+    r.kt = 5u * k + t;
+    return r;
+}
+
+struct CutRec {
+    BlockDesc d;
+    BlockAux ax;
+};
+
+// One block cut from input position s (lib/rle.rs:102-253 in closed form, see the head of this file): descriptor + what
+// the emit kernel needs.  Returns the bytes consumed; *origin = lim - M of this cut, the canonical offset the block's
+// budget is counted from (valid unless the budget ran out inside the block's first run: *origin = ~0).
+__device__ __forceinline__ uint32_t cut_block(const PlanArrays &pa, uint32_t lane, uint32_t s, uint64_t total, CutState &cs, CutRec &rec,
+                                              uint64_t *origin)
+{
+    const uint32_t N = (uint32_t)pa.n, M = pa.M;
+    const uint32_t e_first = (s / GRAN == cs.idx) ? next_start_in(pa, cs.ev, cs.idx, s) : next_start_after(pa, s, lane);
+    const uint32_t Lr = e_first - s;
+    const uint32_t A = canon_len(Lr);
+    uint32_t consumed, out, open = 0;
+    uint64_t Ce = 0;
+    *origin = ~0ull;
+    // A cut inside the input's last run is final only if that run is known to hold at least one
+    // more full 255-byte chunk than the budget can take (then its true length cannot matter).
+    if (A > M) { // the budget runs out inside the run the block starts in
+        uint32_t k, t;
+        cut_in_run(Lr, M, k, t);
+        consumed = 255u * k + t;
+        out = 5u * k + t;
+        open = e_first >= N && (uint64_t)Lr < 255ull * (M / 5u + 2u);
+    } else {
+        if (e_first >= N) {
+            Ce = total;
+        } else {
+            if (e_first / GRAN != cs.idx) {
+                cs.ev = gran_eval(pa, e_first / GRAN, lane);
+                cs.idx = e_first / GRAN;
+            }
+            Ce = __shfl(cs.ev.cpos, (int)(e_first % GRAN), 64);
+        }
+        const uint64_t lim = (uint64_t)(M - A) + Ce; // largest canonical offset that still fits
+        *origin = lim - M;
+        if (total <= lim) { // everything to the end of the input fits
+            consumed = N - s;
+            out = A + (uint32_t)(total - Ce);
+            open = 1;
+        } else {
+            const CutEnd ce = end_from_lim(pa, lane, lim, e_first / RL_TILE, cs); // (tc[e_first's tile] <= Ce <= lim)
+            consumed = ce.end - s;
+            out = M - ce.R + ce.kt;
+            open = ce.open;
+        }
+    }
+    rec.d.in_off = s;
+    rec.d.in_len = consumed;
+    rec.d.rle_len = out;
+    rec.d.crc = 0;
+    rec.ax.Ce = Ce;
+    rec.ax.A = A;
+    rec.ax.e_first = e_first;
+    rec.ax.open = open;
+    rec.ax.pad = 0;
+    return consumed;
+}
+
+// ---- the split: SP_W wavefronts cut SP_K blocks each, from starts that are right unless a cut gave bytes away ---------
+// Block k+1 starts where block k ended, and a cut is a chain of dependent table reads (2 us): 112 blocks were 232 us of
+// every step on ONE wavefront -- and in a sharded run every later rank waits for the splits of all ranks before it.
+// But a block that ends exactly on its budget (every block of text: the budget is only missed next to a run of four or
+// more) leaves the next block's budget counted from a canonical offset M further on, so the start of block j is known
+// without cutting blocks 0 .. j-1: it is where a block would end whose budget reaches origin + j M.  Wavefront w takes
+// that start for j = w SP_K (one end_from_lim), cuts its SP_K blocks, and the workgroup keeps the blocks of the
+// wavefronts whose start turned out to be the end of the wavefront before (wavefront 0 starts from the known start):
+// everything else is cut again in the next window, from the last good end -- a window per irregular cut instead of a
+// chain link per block.  The result is the sequential split's, block for block: a wavefront's cuts depend on its start
+// only, and a start is used only if it is the true one.
+constexpr uint32_t SP_W = 15, SP_K = 8; // (+ 1 wavefront that runs ahead and touches the tables: 1024 threads)
+
+__global__ void __launch_bounds__(64 * (SP_W + 1)) plan_split(PlanArrays pa)
+{
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (wave == SP_W) {
+        plan_prefetch(pa, lane);
         return;
     }
-    const uint32_t lane = threadIdx.x;
     const uint32_t N = (uint32_t)pa.n, M = pa.M, NT = pa.ntiles;
     const uint64_t total = pa.tc[NT];
-    uint32_t s = pa.start, nb = 0;
-    // The granule the previous cut fell into is usually also the one the next block starts in: keep its
-    // evaluation (run starts + canonical offsets per byte) instead of recomputing it twice per block.
-    Gran cg_eval{};
-    uint32_t cg_idx = 0xFFFFFFFFu;
-    while (s < N && nb < pa.maxblocks) {
-        const uint32_t e_first = (s / GRAN == cg_idx) ? next_start_in(pa, cg_eval, cg_idx, s) : next_start_after(pa, s, lane);
-        const uint32_t Lr = e_first - s;
-        const uint32_t A = canon_len(Lr);
-        uint32_t consumed, out, open = 0;
-        uint64_t Ce = 0;
-        // A cut inside the input's last run is final only if that run is known to hold at least one
-        // more full 255-byte chunk than the budget can take (then its true length cannot matter).
-        if (A > M) { // the budget runs out inside the run the block starts in
-            uint32_t k, t;
-            cut_in_run(Lr, M, k, t);
-            consumed = 255u * k + t;
-            out = 5u * k + t;
-            open = e_first >= N && (uint64_t)Lr < 255ull * (M / 5u + 2u);
-        } else {
-            if (e_first >= N) {
-                Ce = total;
-            } else {
-                if (e_first / GRAN != cg_idx) {
-                    cg_eval = gran_eval(pa, e_first / GRAN, lane);
-                    cg_idx = e_first / GRAN;
-                }
-                Ce = __shfl(cg_eval.cpos, (int)(e_first % GRAN), 64);
+    __shared__ CutRec rec[SP_W][SP_K];
+    __shared__ uint32_t w_start[SP_W], w_end[SP_W], w_cnt[SP_W], w_fin[SP_W]; // per wavefront: first start, last end, blocks cut, "the split ends here"
+    __shared__ unsigned long long s_origin;
+    __shared__ uint32_t s_s, s_nb, s_done;
+    if (threadIdx.x == 0) {
+        s_s = pa.start;
+        s_nb = 0;
+        s_done = 0;
+    }
+    CutState cs;
+    __syncthreads();
+    for (;;) {
+        const uint32_t s0 = s_s, nb0 = s_nb;
+        if (s_done || s0 >= N || nb0 >= pa.maxblocks) break;
+        // -- wavefront 0 cuts the window's first block: its origin is what the other wavefronts' starts are counted from
+        uint32_t cnt = 0, sw = N, fin = 0;
+        uint64_t origin = ~0ull;
+        if (wave == 0) {
+            const uint32_t used = cut_block(pa, lane, s0, total, cs, rec[0][0], &origin);
+            cnt = 1;
+            fin = s0 >= pa.stop ? 1u : 0u; // the block that belongs to the next range is on record: its start is all that was wanted
+            sw = s0 + used;
+            if (lane == 0) {
+                s_origin = origin;
+                w_start[0] = s0;
             }
-            const uint64_t lim = (uint64_t)(M - A) + Ce; // largest canonical offset that still fits
-            if (total <= lim) { // everything to the end of the input fits
-                consumed = N - s;
-                out = A + (uint32_t)(total - Ce);
-                open = 1;
-            } else {
-                // last tile with tc <= lim: probe 64 tiles around the literal-text guess, else 64-ary search
-                uint32_t lo = e_first / RL_TILE, hi = NT - 1; // tc[lo] <= Ce <= lim
-                {
-                    long long guess = (long long)lo + (long long)((lim - Ce) / RL_TILE) - 40;
-                    if (guess < (long long)lo) guess = lo;
-                    if (guess > (long long)hi) guess = hi;
-                    const uint32_t w0 = (uint32_t)guess; // lo <= w0 <= hi
-                    const uint32_t x = w0 + lane;
-                    const bool ok = x <= hi && pa.tc[x] <= lim;
-                    const unsigned long long m = __ballot(ok); // tc is nondecreasing: a prefix of the window
-                    if (m & 1ull) {
-                        const uint32_t c = (uint32_t)__popcll(m);
-                        lo = w0 + c - 1;
-                        if (c < 64) hi = lo; // tc[lo+1] > lim or lo is the last tile
-                    } else {
-                        hi = w0 - 1; // tc[w0] > lim, and w0 > lo because tc[lo] <= lim
-                    }
-                }
-                while (lo < hi) {
-                    const uint32_t span = hi - lo;
-                    const uint32_t step = (span + 63u) / 64u;
-                    const uint64_t x = (uint64_t)lo + (uint64_t)(lane + 1) * step;
-                    const bool ok = x <= hi && pa.tc[x] <= lim;
-                    const uint32_t c = (uint32_t)__popcll(__ballot(ok));
-                    lo += c * step;
-                    const uint64_t nh = (uint64_t)lo + step - 1;
-                    if (nh < hi) hi = (uint32_t)nh;
-                }
-                const uint32_t tl = lo;
-                // last granule of that tile whose start offset is <= lim
-                const uint32_t gb = tl * GRAN_PER_TILE;
-                const uint32_t gidx = gb + lane;
-                const bool gok = (uint64_t)gidx * GRAN < pa.n && pa.tc[tl] + pa.cg[gidx] <= lim;
-                const uint32_t gx = gb + (uint32_t)__popcll(__ballot(gok)) - 1u; // lane 0 always ok
-                if (gx != cg_idx) {
-                    cg_eval = gran_eval(pa, gx, lane);
-                    cg_idx = gx;
-                }
-                const Gran &gr = cg_eval;
-                // last run start in the granule that still fits, else the run covering the granule
-                const unsigned long long fit = __ballot(gr.start && gr.cpos <= lim);
-                uint32_t x;
-                uint64_t Cx;
-                if (fit) {
-                    const int l = 63 - __clzll((long long)fit);
-                    x = gx * GRAN + (uint32_t)l;
-                    Cx = __shfl(gr.cpos, l, 64);
-                } else {
-                    x = pa.rsg[gx];
-                    Cx = __shfl(gr.cpos, 0, 64) - emitted_before(gx * GRAN - x);
-                }
-                const uint32_t R = (uint32_t)(lim - Cx); // budget left for the run starting at x
-                const uint32_t xe = (x / GRAN == cg_idx) ? next_start_in(pa, cg_eval, cg_idx, x) : next_start_after(pa, x, lane);
-                const uint32_t Lx = xe - x;
-                open = xe >= N && (uint64_t)Lx < 255ull * (R / 5u + 2u);
-                uint32_t k, t;
-                cut_in_run(Lx, R, k, t);
-                consumed = x - s + 255u * k + t;
-                out = M - R + 5u * k + t;
+        }
+        __syncthreads();
+        origin = s_origin;
+        if (wave > 0) {
+            // my first block would be block wave * SP_K of the window: it starts where block wave * SP_K - 1 ends
+            sw = N;
+            const uint64_t lim = origin + (uint64_t)wave * SP_K * M;
+            if (origin != ~0ull && lim < total) {
+                const uint32_t lo = s0 / RL_TILE; // (tc of the window's first tile <= canonical offset at s0 <= lim)
+                sw = end_from_lim(pa, lane, lim, lo, cs).end;
             }
+            if (lane == 0) w_start[wave] = sw;
+        }
+        // -- every wavefront cuts its blocks (wavefront 0 has one already)
+        while (cnt < SP_K && sw < N && !fin) {
+            uint64_t o2;
+            const uint32_t used = cut_block(pa, lane, sw, total, cs, rec[wave][cnt], &o2);
+            fin = sw >= pa.stop ? 1u : 0u;
+            cnt++;
+            sw += used;
         }
         if (lane == 0) {
-            BlockDesc d;
-            d.in_off = s;
-            d.in_len = consumed;
-            d.rle_len = out;
-            d.crc = 0;
-            pa.blocks[nb] = d;
-            BlockAux ax;
-            ax.Ce = Ce;
-            ax.A = A;
-            ax.e_first = e_first;
-            ax.open = open;
-            ax.pad = 0;
-            pa.aux[nb] = ax;
+            w_end[wave] = sw;
+            w_cnt[wave] = cnt;
+            w_fin[wave] = fin;
         }
-        nb++;
-        if (s >= pa.stop) { // the block that belongs to the next range is on record: its start is all that was wanted
-            s = N;
-            break;
+        __syncthreads();
+        // -- keep the wavefronts whose start is the end of the one before; the next window begins behind them
+        uint32_t V = 1, off = 0, mine = 0xFFFFFFFFu, end_all = w_end[0], fin_all = w_fin[0];
+        if (wave == 0) mine = 0;
+        off = w_cnt[0];
+        for (uint32_t w = 1; w < SP_W; w++) {
+            if (fin_all || end_all >= N || w_cnt[w] == 0u || w_start[w] != end_all) break;
+            if (w == wave) mine = off;
+            off += w_cnt[w];
+            end_all = w_end[w];
+            fin_all = w_fin[w];
+            V++;
         }
-        s += consumed;
+        const bool overflow = nb0 + off > pa.maxblocks;
+        if (mine != 0xFFFFFFFFu && !overflow) {
+            // 56-byte records, written by the lanes: 6 + 8 dwords (BlockDesc is 24 bytes, BlockAux 32)
+            for (uint32_t j = 0; j < cnt; j++) {
+                const uint32_t *sd = reinterpret_cast<const uint32_t *>(&rec[wave][j].d);
+                const uint32_t *sa = reinterpret_cast<const uint32_t *>(&rec[wave][j].ax);
+                uint32_t *dd = reinterpret_cast<uint32_t *>(pa.blocks + nb0 + mine + j);
+                uint32_t *da = reinterpret_cast<uint32_t *>(pa.aux + nb0 + mine + j);
+                if (lane < sizeof(BlockDesc) / 4) dd[lane] = sd[lane];
+                if (lane < sizeof(BlockAux) / 4) da[lane] = sa[lane];
+            }
+        }
+        __syncthreads(); // (the records and the per-wavefront words are reused by the next window)
+        if (threadIdx.x == 0) {
+            s_nb = nb0 + off;
+            s_s = overflow ? 0u : (fin_all ? N : end_all);
+            s_done = (overflow || fin_all || end_all >= N) ? 1u : 0u;
+            if (overflow) s_nb = 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        (void)V;
     }
-    if (lane == 0) *pa.nblocks = (s < N) ? 0xFFFFFFFFu : nb; // overflow marker
+    if (threadIdx.x == 0) *pa.nblocks = (s_nb == 0xFFFFFFFFu || (!s_done && s_s < N)) ? 0xFFFFFFFFu : s_nb; // overflow marker
 }
 
 // ---- CRC-32/BZIP2 ----------------------------------------------------------------------------------------
@@ -1050,7 +1174,7 @@ int rle1_plan_split(bzh_ctx *ctx, size_t start, bool with_crc, size_t stop)
     pa.stop = stop >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)stop;
     {
         KSpan ks(ctx, K_PLAN, 0, 1);
-        plan_split<<<dim3(1), 128, 0, st>>>(pa);
+        plan_split<<<dim3(1), 64 * (SP_W + 1), 0, st>>>(pa);
     }
     // The block CRCs are queued right behind the split, over as many blocks as there could be (the kernels read the
     // count on the device), and everything the host needs -- count, descriptors with their CRCs, cut status -- comes
