@@ -144,6 +144,10 @@ static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
     }
     carve(p, bt.chain, NB * 4);
     carve(p, bt.errflag, 64);
+    carve(p, bt.gidof, NB * S);
+    carve(p, bt.grank, 2 * NB * GID_MAX);
+    carve(p, bt.gcount, NB);
+    carve(p, bt.gwide, 64);
     { // bucket-first initial sort (bwt_msd.h): only levels whose blocks can reach MS_MIN_N bytes ever use it
         const size_t MB = M >= MS_MIN_N ? NB : 0;
         carve(p, bt.ms_bgcur, MB * 65536);

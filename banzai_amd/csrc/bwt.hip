@@ -115,6 +115,14 @@ struct SortArgs {
     const uint32_t *chain; // [B][4] near-periodic blocks (period_probe): flags, period, tails that lead the order
     const uint32_t *clist; // [B][2S] those tails, then the other tails, ascending (the block's listD)
     uint32_t fault;        // test hook (bzh_debug_fault): 1 = tile 1 of block 0 never publishes its digit counts
+    // big-list rounds with numbered groups: *gwide == 0 -> the keys are 32 bits, four passes, and the passes run over the
+    // buffers named here instead (active_gen wrote in place; a null src_n: this pass is not needed)
+    const uint32_t *gwide; // the word of THIS round (bt.gwide + (round & 1))
+    const u64 *src_n;
+    u64 *dst_n;
+    uint32_t has_n;        // 1: the alternates above are meaningful for this launch
+    uint32_t only4;        // the host launches four passes only (no list of the round can run out of numbers): a raised *gwide is an error
+    const uint16_t *gidof; // [B][S] (active_gen)
 };
 
 constexpr int NBMAX = 256;
@@ -320,9 +328,14 @@ __global__ void __launch_bounds__(SORT_THREADS) active_gen(SortArgs a, uint32_t 
     for (int k = threadIdx.x; k < 5 * 256; k += SORT_THREADS) hh[k] = 0;
     __syncthreads();
     const size_t base = (size_t)b * a.S;
+    // Numbered groups: the record leaves with the group's NUMBER in place of its rank -- 12 bits, so the key is 32 bits and
+    // four passes sort it -- and in place: the four passes then end in the buffer five would end in.
+    const bool narrow = *a.gwide == 0u;
+    if (!narrow && a.only4 && threadIdx.x == 0) atomicOr(a.err, 4u); // (cannot happen: the host's bound on the lists rules it out)
     const u64 *src = a.src + base;
-    u64 *dst = a.dst + base;
+    u64 *dst = (narrow ? const_cast<u64 *>(a.src) : a.dst) + base;
     const uint32_t *rank = a.rank + base;
+    const uint16_t *gidof = a.gidof + base;
     const int lane = threadIdx.x & 63;
 #pragma unroll 4
     for (int k = 0; k < SORT_ITEMS; k++) {
@@ -332,7 +345,7 @@ __global__ void __launch_bounds__(SORT_THREADS) active_gen(SortArgs a, uint32_t 
         if (ok) {
             const u64 x = src[e];
             const uint32_t i = (uint32_t)(x & SUF_MASK);
-            const uint32_t r = (uint32_t)(x >> 40) & 0xFFFFFu;
+            uint32_t r = (uint32_t)(x >> 40) & 0xFFFFFu;
             uint32_t k2;
             if (h < n) {
                 uint32_t i2 = i + h;
@@ -341,6 +354,7 @@ __global__ void __launch_bounds__(SORT_THREADS) active_gen(SortArgs a, uint32_t 
             } else {
                 k2 = n - 1 - i;
             }
+            if (narrow) r = gidof[r]; // (a group's members read the same word)
             v = ((u64)r << 40) | ((u64)k2 << 20) | i;
             dst[e] = v;
             atomicAdd(&hh[(uint32_t)(v >> 20) & 255u], 1u);
@@ -367,6 +381,39 @@ __global__ void __launch_bounds__(SORT_THREADS) active_gen(SortArgs a, uint32_t 
     uint32_t *tot = dtot + (size_t)b * DB_STRIDE;
     for (int k = threadIdx.x; k < 5 * 256; k += SORT_THREADS)
         if (hh[k]) atomicAdd(&tot[k], hh[k]);
+}
+
+// ---- numbers for the large groups -----------------------------------------------------------------------------------------
+// Called once per large group, by the thread that writes the group's first record: draws the group's number for the round
+// the list is written for (`par` = that round & 1) and records number <-> rank; a block that runs out of numbers makes
+// that round sort on ranks.
+struct GidOut {
+    uint16_t *gidof; // [B][S]
+    uint32_t *grank; // [2][B][GID_MAX]
+    uint32_t *gcount; // [B]
+    uint32_t *gwide;  // [2]
+    uint32_t S, B, par;
+};
+// (the same for a workgroup's worth of groups whose ranks stand in a list: numbers base .. base + count - 1, one of them a thread)
+__device__ __forceinline__ void gid_assign(const GidOut &g, uint32_t b, uint32_t k, uint32_t rank)
+{
+    if (k < GID_MAX) {
+        g.grank[((size_t)g.par * g.B + b) * GID_MAX + k] = rank;
+        g.gidof[(size_t)b * g.S + rank] = (uint16_t)k;
+    } else {
+        atomicOr(&g.gwide[g.par], 1u);
+    }
+}
+__device__ __forceinline__ void gid_draw(const GidOut &g, uint32_t b, uint32_t rank)
+{
+    if (!g.gcount) return;
+    const uint32_t k = atomicAdd(&g.gcount[b], 1u);
+    if (k < GID_MAX) {
+        g.grank[((size_t)g.par * g.B + b) * GID_MAX + k] = rank;
+        g.gidof[(size_t)b * g.S + rank] = (uint16_t)k;
+    } else {
+        atomicOr(&g.gwide[g.par], 1u);
+    }
 }
 
 // One workgroup per listed block: exclusive scan inside each of the ndig digit groups of dtot.
@@ -472,6 +519,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
 {
     constexpr int NB = 1 << BITS;
     constexpr int NW = SORT_THREADS / 64;
+    if (MODE == GEN_LIST && a.has_n && !a.src_n && *a.gwide == 0u) return; // the fifth pass of a round whose keys have 32 bits
     uint32_t b, tile;
     if (!wg_map(a.T, a.lst, b, tile)) return;
     const uint32_t cnt = a.cnt[b], n = a.n[b];
@@ -480,6 +528,10 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
     if (tile >= ntile) return;
     const uint32_t h = MODE == GEN_SWEEP ? a.hb[b] : 0u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (MODE == GEN_LIST && a.has_n && *a.gwide == 0u) { // 32-bit keys this round: the other chain of buffers
+        a.src = a.src_n;
+        a.dst = a.dst_n;
+    }
 
     __shared__ uint32_t cur[NW][NB];  // per-wave counters, then cursors (tile-local positions)
     __shared__ uint32_t binstart[NB]; // tile-local start of each digit's run
@@ -713,6 +765,9 @@ struct RefineArgs {
     int init;
     uint32_t T;
     Lst lst;
+    GidOut gout;           // numbers for the large groups this kernel writes (for the NEXT round's sort)
+    const uint32_t *grank; // [B][GID_MAX] refine_one: the rank of every numbered group of THIS round
+    const uint32_t *gwide; // [1] refine_one: 0 = the sorted list carries group numbers, not ranks (this round's word)
 };
 
 // LDS staging of one tile: coalesced global loads, then each thread owns 16 consecutive elements.
@@ -1004,6 +1059,7 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
                 const uint32_t pos = gbase + q;
                 const uint32_t head = gbase + (uint32_t)cd;
                 const bool single = c == CLS_SINGLE;
+                if (c == CLS_BIG && (f & 2u) && !nolist) gid_draw(a.gout, b, head);
                 rank[rslot(i)] = single ? (head | RANK_RESOLVED) : head;
                 outv[k] = ((u64)c << 62) | ((u64)pos << 40) | ((u64)head << 20) | i;
                 if (sweep && !single) {
@@ -1170,8 +1226,10 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
     __shared__ uint32_t lsu[NW + 2];
     __shared__ int s_cg, s_cd, s_hend;
     __shared__ uint32_t s_offS, s_offB;
+    __shared__ uint32_t s_ng, s_gbase, glist[SORT_TILE / TAIL_G]; // ranks of the large groups that start in the tile (they get numbers, below)
     __shared__ uint32_t bh[INIT ? 256 : 1], bcur[INIT ? 256 : 1], bgo[INIT ? 256 : 1]; // rank binning: counts, cursors, offsets
     if (INIT && threadIdx.x < 256) bh[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_ng = 0;
     stage_tile(list, tile0, cnt, lds);
     if (threadIdx.x < (uint32_t)TAIL_G) halo[1 + threadIdx.x] = tend + threadIdx.x < cnt ? list[tend + threadIdx.x] : 0ull;
     if (threadIdx.x == (uint32_t)TAIL_G) halo[0] = tile0 ? list[tile0 - 1] : 0ull;
@@ -1284,6 +1342,8 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
         s_offB = totB ? atomicAdd(&a.c_big[b], totB) : 0u;
     }
     uint32_t *rank = a.rank + base;
+    const bool narrow = !INIT && *a.gwide == 0u;
+    const uint32_t *grank = a.grank + (size_t)b * GID_MAX; // (this round's half)
     // per element: [class:2 @62][foreign:1 @61][valid:1 @60][head:20 @40][suffix:20 @0]
     u64 outv[SORT_ITEMS];
 #pragma unroll
@@ -1300,9 +1360,11 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
                 const u64 cur = lds[slot_of(e0 + k)];
                 const uint32_t i = (uint32_t)(cur & SUF_MASK);
                 // SA position of the group's first list entry, minus that entry's list index
-                const uint32_t oldr = (uint32_t)(cur >> 40);
+                // (a list sorted on group numbers: the number's rank from gid_scan's table -- the same word for the whole group)
+                const uint32_t oldr = (!INIT && narrow) ? grank[(uint32_t)(cur >> 40)] : (uint32_t)(cur >> 40);
                 const uint32_t gbase = INIT ? 0u : (oldr - (uint32_t)cg);
                 const uint32_t head = gbase + (uint32_t)cd;
+                if (c == CLS_BIG && (f & 2u)) glist[atomicAdd(&s_ng, 1u)] = head; // (a large group has more than TAIL_G members: the list cannot overflow)
                 // (the last column is emitted from the ranks; a rank that did not move and stays unresolved is in place)
                 if (INIT)
                     atomicAdd(&bh[i >> 12], 1u); // every suffix gets a rank: binned by 4096-suffix window, then applied
@@ -1314,6 +1376,10 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
     }
     if (__ballot(progress) && lane == 0) a.c_prog[b] = 1u; // same value from everyone
     __syncthreads(); // every thread is done with the staged tile; s_off* and the bin counts are there
+    // numbers for the tile's large groups: ONE atomic add for all of them, requested now and used at the very end
+    uint32_t pend_g = 0;
+    const uint32_t ng = s_ng;
+    if (threadIdx.x == 0 && ng) pend_g = atomicAdd(&a.gout.gcount[b], ng);
     // records leave through LDS: the tile's small-group records at [0, totS + nH), its large-group records behind them
     {
         uint32_t wS = offS, wB = totS + nH + offB;
@@ -1327,7 +1393,7 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
             }
         }
         if (threadIdx.x < nH) { // same (old and refined) group as the tile's last element
-            const uint32_t oldr = (uint32_t)(halo[1 + threadIdx.x] >> 40);
+            const uint32_t oldr = (!INIT && narrow) ? grank[(uint32_t)(halo[1 + threadIdx.x] >> 40)] : (uint32_t)(halo[1 + threadIdx.x] >> 40);
             const uint32_t head = (INIT ? 0u : oldr - (uint32_t)last_gs) + (uint32_t)last_start;
             lds[totS + threadIdx.x] = ((u64)head << 40) | (halo[1 + threadIdx.x] & SUF_MASK);
         }
@@ -1345,7 +1411,9 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if (threadIdx.x == 0) s_gbase = pend_g;
     __syncthreads();
+    if (threadIdx.x < ng) gid_assign(a.gout, b, s_gbase + threadIdx.x, glist[threadIdx.x]);
     {
         const uint32_t tbase = INIT ? 0u : a.tbase[b];
         u64 *ts = (a.tdst[b] ? a.tail1 : a.tail0) + base + tbase + s_offS;
@@ -1819,7 +1887,7 @@ __global__ void __launch_bounds__(1024) period_probe(ProbeArgs a)
 // round's work lists and gates, clears the counters and the digit totals of the blocks on the big-list
 // path, and writes the summary the host reads one round late.
 // summary words: 0 round, 1 nS, 2 nA, 3 nT, 4 nQ, 5 maxS, 6 maxA, 7 maxT, 8 total unresolved, 9 of them sitting the round out,
-//                10/11 sum of the S lists, 12/13 sum of the A lists, 14 error flag, 15 largest depth in use,
+//                10 sum of the S lists, 11 this round sorts its big lists on ranks (five passes; else on group numbers: four), 12 sum of the A lists, 14 error flag, 15 largest depth in use,
 //                16 S blocks whose refine writes lists this round (the only ones that can leave SWEEP mode next round),
 //                17/18 sum over the rounds so far of the unresolved suffixes entering them, 19 sequence word (last)
 #ifndef QUAD_DIV
@@ -1834,6 +1902,8 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
     const uint32_t b = threadIdx.x;
     const bool valid = b < B;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (valid) bt.gcount[b] = 0u; // numbers are drawn afresh for the lists this round's refinement writes
+    if (threadIdx.x == 0) bt.gwide[(round + 1u) & 1u] = 0u; // ... and so is that round's "a block ran out of numbers"
     // per-wavefront partial results: sums (all, S, A, n, sconv), maxima (S, A, T, depth), list counts
     __shared__ uint32_t psum[6][16], pmax[4][16], pcnt[6][16];
     uint32_t gS = 0, gA = 0, gT = 0, h = 0, n = 0, conv = 0;
@@ -1955,7 +2025,7 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
     if (wave == 0) { // the summary, one word per lane, straight into pinned host memory
         const unsigned long long asum = *bt.stat_A + sum[0]; // unresolved suffixes entering the rounds so far
         const uint32_t words[SUMMARY_WORDS] = {round,  tot[L_S], tot[L_A], tot[L_T], tot[L_Q], mx[0],  mx[1], mx[2], sum[0], sum[5],
-                                               sum[1], 0u,       sum[2],   0u,       *bt.errflag, mx[3], sum[4], (uint32_t)asum,
+                                               sum[1], bt.gwide[round & 1u], sum[2],   0u,       *bt.errflag, mx[3], sum[4], (uint32_t)asum,
                                                (uint32_t)(asum >> 32), 0u};
         uint32_t mine = 0;
 #pragma unroll
@@ -1974,8 +2044,8 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
 // ---- one launch clears everything a sort starts from ---------------------------------------------------------------
 // (a hipMemsetAsync is a kernel of its own, about 5 us each back to back: eight of them were 45 us of every step)
 struct ClearArgs {
-    uint4 *p[10];         // 16-byte aligned regions (carved at 256-byte boundaries)
-    unsigned long long q[10]; // their lengths in 16-byte words, as a running total (region k = [q[k-1], q[k]))
+    uint4 *p[12];         // 16-byte aligned regions (carved at 256-byte boundaries)
+    unsigned long long q[12]; // their lengths in 16-byte words, as a running total (region k = [q[k-1], q[k]))
     int n;
 };
 __global__ void __launch_bounds__(256) bwt_clear(ClearArgs c)
@@ -1991,7 +2061,7 @@ struct ClearList {
     ClearArgs a{};
     void add(void *p, size_t bytes)
     {
-        if (!bytes || a.n >= 10) return;
+        if (!bytes || a.n >= 12) return;
         a.p[a.n] = reinterpret_cast<uint4 *>(p);
         a.q[a.n] = (a.n ? a.q[a.n - 1] : 0ull) + (bytes + 15) / 16; // (regions end at 256-byte boundaries of the arena: rounding up stays inside)
         a.n++;
@@ -2167,6 +2237,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     a.hb = bt.st_h;
     a.S = bt.S;
     a.TPB = bt.TPB;
+    a.gwide = bt.gwide;
+    a.gidof = bt.gidof;
 
     // ---- initial sort on the 8-byte cyclic prefix: LSD, 8 passes of 8 bits.  Passes 0-4 order by bytes 3..7 of
     // the rotation (the element carries all five); pass 5 finds each element's 5-byte group on the way in (the list
@@ -2200,6 +2272,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     // round state: everything from st_mode to the 64-bit counter (one contiguous carve, see layout_batch)
     clr.add(bt.st_mode, (size_t)((uint8_t *)(bt.stat_A + 1) - (uint8_t *)bt.st_mode));
     clr.add(bt.hasbyte, (size_t)B * 256); // (bwt_emit ORs into it at the very end)
+    clr.add(bt.gcount, (size_t)bt.B * sizeof(uint32_t)); // (no large group numbered yet; the two "ran out of numbers" words
+    clr.add(bt.gwide, 16);                                //  lie behind it)
     // The second stream of the suffix sort (created once): the big-list path of a round runs on it beside the small-group
     // kernel, and so do the 8 passes of the blocks that keep them when the rest of the batch takes the bucket-first
     // initial sort.  (With profiling on everything stays on one stream, or the per-kernel spans would overlap.)
@@ -2330,6 +2404,9 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     r.nbig_in = bt.st_nbig;
     r.S = bt.S;
     r.TPB = bt.TPB;
+    r.gout = GidOut{bt.gidof, bt.grank, bt.gcount, bt.gwide, bt.S, bt.B, 0u}; // (the initial refinement writes round 0's lists)
+    r.grank = bt.grank;
+    r.gwide = bt.gwide;
     r.init = 1;
     r.cstat = reinterpret_cast<u64 *>(bt.hist);
     r.carry = reinterpret_cast<u64 *>(bt.tagg);
@@ -2427,6 +2504,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             r0.list = oth; // the sorted list (the big lists went to `cur`)
             r0.big = cur;
             r0.c_big = r0.c_small = r0.c_prog = bt.scratch; // consumed by round_begin already
+            r0.gout.gcount = nullptr; // (its large groups were numbered when the lists were first written)
             r0.cpass = ++a.pass;
             r0.lst = Lst{bt.actS, bt.nlist + L_S, B};
             launch_refine(ctx, r0, nS, nmax, true);
@@ -2493,24 +2571,38 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         a.src = cur;
         a.dst = oth;
         a.T = gt | (few_blocks(nA) ? WG_SPREAD : 0u);
+        // A large group has more than TAIL_G members (and a group that spans several units of the initial sort draws one
+        // number a unit: at most two more per 8192 records), so a list of at most 250,000 records cannot run out of
+        // GID_MAX numbers: the fifth pass is then not even launched.
+        const int npass = maxA <= 250000u ? 4 : 5;
+        a.only4 = npass == 4 ? 1u : 0u;
         {
             KSpan ks(ctx, K_ACTIVE_GEN, 0, 2);
             active_gen<<<dim3(xcd_grid(a.T, nA)), SORT_THREADS, 0, sa>>>(a, bt.dtot);
             active_bases<<<dim3(nA), 256, 0, sa>>>(bt.dtot, bt.dbase, a.lst, 5);
         }
+        // five passes on [rank][key2] from `oth` (where active_gen put the re-keyed list) -- or, the groups being numbered
+        // densely (the usual case, decided on the device: *gwide), four passes on [number][key2] from `cur` (active_gen wrote
+        // in place); either way the sorted list ends in `cur`
         u64 *c = oth, *o = cur;
         hipEvent_t e0 = span_begin(ctx);
         KSpan ks(ctx, K_RADIX_ROUNDS, 0, 5);
-        for (int p = 0; p < 5; p++) {
+        a.has_n = 1u;
+        // (a large group has more than TAIL_G members: lists of at most GID_MAX * (TAIL_G + 1) records cannot run out of
+        // numbers, and the fifth pass is not even launched)
+        for (int p = 0; p < npass; p++) {
             a.shift = 20 + 8 * p;
             a.doff = 256 * p;
             a.src = c;
             a.dst = o;
+            a.src_n = p < 4 ? o : nullptr; // (the narrow chain runs the other way round: cur -> oth -> cur -> oth -> cur)
+            a.dst_n = p < 4 ? c : nullptr;
             launch_pass<8, GEN_LIST>(ctx, a, nA, maxA);
             u64 *t = c;
             c = o;
             o = t;
         }
+        a.has_n = 0u;
         span_end(ctx, e0);
         if (side) {
             ctx->stream = st;
@@ -2534,14 +2626,16 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     };
     auto account = [&](const uint32_t *sm) { // statistics of the round a summary describes
         if (!ctx->profiling) return;
-        const uint64_t tot = (uint64_t)sm[8], eS = (uint64_t)sm[10] | ((uint64_t)sm[11] << 32),
-                       eA = (uint64_t)sm[12] | ((uint64_t)sm[13] << 32);
+        const uint64_t tot = (uint64_t)sm[8], eS = (uint64_t)sm[10], eA = (uint64_t)sm[12];
+        if (sm[2]) { // the big lists of this round: four passes on group numbers, five on ranks (word 11)
+            const uint64_t passes = sm[11] ? 5u : 4u;
+            ctx->stats.bwt_sort_elems += passes * eA;
+            ctx->k_bytes[K_RADIX_ROUNDS] += eA * passes * 16;
+        }
         if (sm[1]) ctx->stats.bwt_sort_elems += 3 * eS;
-        if (sm[2]) ctx->stats.bwt_sort_elems += 5 * eA;
         // algorithmic bytes of the round's kernels (per-element figures: DESIGN.md section 4)
         ctx->k_bytes[K_SWEEP] += eS * (3 * 16 + 12 + 20);           // enumeration + gather, 3 passes, flags + refine
         ctx->k_bytes[K_ACTIVE_GEN] += eA * 20;                      // record in, re-keyed record out, one rank gather
-        ctx->k_bytes[K_RADIX_ROUNDS] += eA * 5 * 16;
         ctx->k_bytes[K_REFINE_ROUNDS] += eA * 20;                   // record in, rank word, list record out
         ctx->k_bytes[K_TAIL_ROUND] += (tot - eS - eA - sm[9]) * 24; // record in, key gather, rank word, survivor out (not the groups that sit the round out)
         if (sm[0] == 0) ctx->k_bytes[nOld == B ? K_REFINE_INIT : K_MSD_FINISH] += tot * 8; // the list records the initial refinement wrote
@@ -2549,6 +2643,11 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
 
     for (uint32_t round = 0; round < (uint32_t)MAX_ROUNDS; round++) {
         a.tag = 1u + round % 31u; // (a block is at work for fewer than 31 rounds: its depth doubles every time)
+        // the numbers of the large groups: this round's lists carry the half written by the round before; this round's
+        // refinement draws the numbers of the next round's groups into the other half
+        a.gwide = r.gwide = bt.gwide + (round & 1u);
+        r.grank = bt.grank + (size_t)(round & 1u) * bt.B * GID_MAX;
+        r.gout.par = (round + 1u) & 1u;
         {
         KSpan ks(ctx, K_ROUND_BEGIN, 0);
         round_begin<<<1, (B + 63u) / 64u * 64u, 0, st>>>(bt, B, round, actP,
@@ -2561,8 +2660,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             const uint64_t total = (uint64_t)s[8];
             err |= s[14];
             if (trace)
-                fprintf(stderr, "[bzhip] round %u h<=%u unresolved=%llu  S blocks=%u (max %u)  A blocks=%u (max %u)  T blocks=%u (quad %u, max %u)\n",
-                        s[0], s[15], (unsigned long long)total, s[1], s[5], s[2], s[6], s[3], s[4], s[7]);
+                fprintf(stderr, "[bzhip] round %u h<=%u unresolved=%llu  S blocks=%u (max %u)  A blocks=%u (max %u, %s)  T blocks=%u (quad %u, max %u)\n",
+                        s[0], s[15], (unsigned long long)total, s[1], s[5], s[2], s[6], s[11] ? "on ranks" : "on group numbers", s[3], s[4], s[7]);
             if (err) break; // a kernel reported an internal error: nothing after it can be trusted
             if (total == 0) { // nothing was left when round-1 began: it and this round_begin were no-ops
                 finished = true;
@@ -2592,8 +2691,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             const uint64_t total = (uint64_t)s[8];
             err |= s[14];
             if (trace)
-                fprintf(stderr, "[bzhip] round %u h<=%u unresolved=%llu  S blocks=%u (max %u)  A blocks=%u (max %u)  T blocks=%u (quad %u, max %u)\n",
-                        s[0], s[15], (unsigned long long)total, s[1], s[5], s[2], s[6], s[3], s[4], s[7]);
+                fprintf(stderr, "[bzhip] round %u h<=%u unresolved=%llu  S blocks=%u (max %u)  A blocks=%u (max %u, %s)  T blocks=%u (quad %u, max %u)\n",
+                        s[0], s[15], (unsigned long long)total, s[1], s[5], s[2], s[6], s[11] ? "on ranks" : "on group numbers", s[3], s[4], s[7]);
             if (total == 0) { // the initial sort resolved everything
                 finished = true;
                 break;

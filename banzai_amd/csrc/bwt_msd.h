@@ -41,6 +41,7 @@ struct Msd {
     u64 *big, *tail, *binned;
     uint32_t *c_big, *c_small, *c_groups;
     uint32_t *err;
+    GidOut gout;         // numbers for the large groups (bwt.hip: round 0 sorts its big lists on them)
     uint32_t force_old;  // every block keeps the 8-pass path (BZH_INIT=lsd)
     uint32_t force_new;  // no block is kept off the buckets for its share of oversized ones (BZH_INIT=msd)
     uint32_t fuse;       // chunk_finish also takes the first doubling step of the small groups (round_begin: r0_fused)
@@ -791,6 +792,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
     // the room claimed in the two lists and in the rank windows are requested as soon as their arguments exist and consumed
     // as late as possible: a global atomic returns after one to two microseconds.
     __shared__ uint32_t s_blk, s_next;
+    __shared__ uint32_t s_ng, s_gbase, glist[MS_TILE / TAIL_G]; // ranks of the unit's large groups (they get numbers: one atomic add a unit)
     const uint32_t NOBLK = 0xFFFFFFFFu;
     uint32_t cur_blk = blockIdx.x & 7u; // (uniform; >= m.B: nothing of my own)
     bool own = true;                    // still inside my XCD's sequence of blocks
@@ -852,7 +854,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
             }
         }
         __syncthreads();
-        const uint32_t ub = s_blk, u = s_unit;
+        const uint32_t ub = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_blk), u = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_unit); // (uniform: scalar registers)
         if (ub == NOBLK) break;
         cur_blk = ub;
         uint32_t pend_ticket = 0;
@@ -876,6 +878,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
         u64 x[MS_ITEMS];
         uint32_t actmask = 0;
         if (tid < 128) HM[tid] = 0ull;
+        if (tid == 0) s_ng = 0;
         ms_clear(cur[0], tid);
         __syncthreads();
         const bool multi = !uniform && nb > 1u;
@@ -939,8 +942,8 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
                 s_wa[wave] = a;
             }
         }
-        __syncthreads();
         if (tid == 0) s_next = pend_ticket; // (requested before the unit's elements were: it is there, and its register is free for the sort)
+        __syncthreads();
         MS_T(0);
         u64 vary = 0ull;
         if (!uniform) {
@@ -1000,9 +1003,10 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
         uint32_t sl[MS_ITEMS / 2]; // the slots my elements were loaded at, 16 bits each; later: where their list records go
 #pragma unroll
         for (int k = 0; k < MS_ITEMS / 2; k++) sl[k] = 0;
-#pragma unroll
+        const uint32_t tq1 = (uint32_t)ms_opaque((int)tid); // (its own copy of the index: the slot addresses of this loop are not kept from the loops before)
+        #pragma unroll
         for (int k = 0; k < MS_ITEMS; k++) {
-            const uint32_t w = k * MS_THREADS + tid;
+            const uint32_t w = k * MS_THREADS + tq1;
             const bool act = w < len;
             u64 key = ~0ull;
             if (act) {
@@ -1035,8 +1039,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
             if (lane == 0) ex = 0;
             rowpre[2 * lane] = (uint32_t)ex;
             rowpre[2 * lane + 1] = (uint32_t)max(ex, v0);
-            const uint32_t nheads = wave_all_add((uint32_t)(__popcll(h0) + __popcll(h1)));
-            if (lane == 0 && nheads) atomicAdd(&m.c_groups[b], nheads);
+            // (the number of groups decides the first mode of blocks on the 8 passes only: nobody counts them here)
         }
         if (tid < 256) bh[tid] = 0; // (the pass counters are free: the last pass ended behind barriers)
         __syncthreads();
@@ -1048,9 +1051,10 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
         uint32_t gi[MS_ITEMS]; // [class : 2 @30][members - 1 : 6 @24 (small groups)][first slot of the group : 13]
         {
             const uint32_t *st32 = reinterpret_cast<const uint32_t *>(stage);
-#pragma unroll
+            const uint32_t tq2 = (uint32_t)ms_opaque((int)tid);
+            #pragma unroll
             for (int k = 0; k < MS_ITEMS; k++) {
-                const uint32_t w = k * MS_THREADS + tid;
+                const uint32_t w = k * MS_THREADS + tq2;
                 sf[k] = 0;
                 gi[k] = 0;
                 if (w < len) {
@@ -1071,19 +1075,23 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
                     uint32_t c = size == 1u ? CLS_SINGLE : (size <= (uint32_t)TAIL_G ? CLS_SMALL : CLS_BIG);
                     if (uniform) c = CLS_BIG; // one tile of a group that spans several units
                     gi[k] = (c << 30) | (((size - 1u) & 63u) << 24) | g;
+                    if (c == CLS_BIG && g == w) glist[atomicAdd(&s_ng, 1u)] = uniform ? tbl : s + g; // (at most one large group per TAIL_G + 1 slots)
                     atomicAdd(&bh[sf[k] >> 12], 1u);
                 }
             }
         }
         __syncthreads(); // the table has been read; the bin counts are complete
+        uint32_t pend_g = 0; // numbers for the unit's large groups: requested now, used at the end
+        if (tid == 0 && s_ng) pend_g = atomicAdd(&m.gout.gcount[b], s_ng);
         MS_T(5);
         // keys of the small groups' members: bytes 7..14 of their rotations, one 8-byte load each -- issued now, in LDS
         // behind the scan of the rank windows (whose barriers they do not need)
         constexpr int KH = 12; // keys in flight across the scan (the rest follows behind it: registers)
         u64 kk[KH];
-#pragma unroll
+        const uint32_t tq3 = (uint32_t)ms_opaque((int)tid);
+        #pragma unroll
         for (int k = 0; k < KH; k++) {
-            const uint32_t w = k * MS_THREADS + tid;
+            const uint32_t w = k * MS_THREADS + tq3;
             kk[k] = 0ull;
             if (fuse && w < len && (gi[k] >> 30) == CLS_SMALL) kk[k] = (m.dbg & 32u) ? (u64)sf[k] * 0x9E3779B97F4A7C15ull : ms_key8(txt, sf[k], n);
         }
@@ -1098,30 +1106,32 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
             *reinterpret_cast<uint4 *>(&bl[4 * lane]) = e4;
             *reinterpret_cast<uint4 *>(&bcur[4 * lane]) = e4;
         }
-        uint32_t pendG = 0;
-        const uint32_t binc = tid < 256 ? bh[tid] : 0u;
+        uint32_t pendG = 0; // (tid < 256: room of my bin in the block's window; the bin's count is re-read from bh where needed)
         if (fuse) {
 #pragma unroll
             for (int k = KH; k < MS_ITEMS; k++) {
                 const uint32_t w = k * MS_THREADS + tid;
                 if (w < len && (gi[k] >> 30) == CLS_SMALL) stage[w] = (m.dbg & 32u) ? (u64)sf[k] * 0x9E3779B97F4A7C15ull : ms_key8(txt, sf[k], n);
             }
-#pragma unroll
+            const uint32_t tq4 = (uint32_t)ms_opaque((int)tid);
+            #pragma unroll
             for (int k = 0; k < KH; k++) {
-                const uint32_t w = k * MS_THREADS + tid;
+                const uint32_t w = k * MS_THREADS + tq4;
                 if (w < len && (gi[k] >> 30) == CLS_SMALL) stage[w] = kk[k];
             }
             __syncthreads();
-            if (binc) pendG = atomicAdd(&m.bincur[(size_t)b * 256 + tid], binc);
+            if (tid < 256 && bh[tid]) pendG = atomicAdd(&m.bincur[(size_t)b * 256 + tid], bh[tid]);
         }
+        if (tid == 0) s_gbase = pend_g; // (it has arrived behind the key gathers: parked, its register is free for the ranking)
         MS_T(6);
         // ---- the first doubling step of the small groups: every member counts the members that sort before it
         // (gi[k] becomes [class : 2 @30][first position of the element's group in the block's order : 20])
         {
             uint32_t nsv = 0; // my records for the two lists: small groups | large groups << 16
-#pragma unroll
+            const uint32_t tq5 = (uint32_t)ms_opaque((int)tid);
+            #pragma unroll
             for (int k = 0; k < MS_ITEMS; k++) {
-                const uint32_t w = k * MS_THREADS + tid;
+                const uint32_t w = k * MS_THREADS + tq5;
                 if (w < len) {
                     uint32_t c = gi[k] >> 30;
                     const uint32_t g = gi[k] & 8191u;
@@ -1151,7 +1161,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
             if (lane == 0) lsv[wave] = nsv;
         }
         __syncthreads(); // the keys have been read: the stage is free
-        if (!fuse && binc) pendG = atomicAdd(&m.bincur[(size_t)b * 256 + tid], binc);
+        if (!fuse && tid < 256 && bh[tid]) pendG = atomicAdd(&m.bincur[(size_t)b * 256 + tid], bh[tid]);
         MS_T(7);
         uint32_t pendS = 0, pendB = 0;
         if (tid == 0) { // (a unit holds at most 8192 records: 16 bits each)
@@ -1164,13 +1174,14 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
         }
         // ---- (rank word, suffix) pairs in bin order in LDS, then out as runs
         if (tid < 256) {
-            const uint32_t w0 = tid * 4096u, wcap = w0 < n ? min(4096u, n - w0) : 0u;
+            const uint32_t w0 = tid * 4096u, wcap = w0 < n ? min(4096u, n - w0) : 0u, binc = bh[tid];
             if (binc && pendG + binc > wcap) atomicOr(m.err, ERR_MSD);
             bgo[tid] = min(n, w0) + pendG;
         }
-#pragma unroll
+        const uint32_t tq6 = (uint32_t)ms_opaque((int)tid);
+        #pragma unroll
         for (int k = 0; k < MS_ITEMS; k++) {
-            const uint32_t w = k * MS_THREADS + tid;
+            const uint32_t w = k * MS_THREADS + tq6;
             if (w < len) {
                 const uint32_t c = gi[k] >> 30, head = gi[k] & 0xFFFFFu;
                 const uint32_t word = c == CLS_SINGLE ? (head | RANK_RESOLVED) : head;
@@ -1189,9 +1200,10 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
         __syncthreads();
         MS_T(8);
         // ---- list records through LDS, each at its place in the new order: a small group's members adjacent, equal keys together
-#pragma unroll
+        const uint32_t tq7 = (uint32_t)ms_opaque((int)tid);
+        #pragma unroll
         for (int k = 0; k < MS_ITEMS; k++) {
-            const uint32_t w = k * MS_THREADS + tid;
+            const uint32_t w = k * MS_THREADS + tq7;
             if (w < len) {
                 const uint32_t c = gi[k] >> 30;
                 const u64 rec = ((u64)(gi[k] & 0xFFFFFu) << 40) | sf[k];
@@ -1203,11 +1215,13 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
             s_offB = pendB;
         }
         __syncthreads();
+        if (tid < s_ng) gid_assign(m.gout, b, s_gbase + tid, glist[tid]);
         {
             u64 o[MS_ITEMS];
-#pragma unroll
+            const uint32_t tq8 = (uint32_t)ms_opaque((int)tid);
+            #pragma unroll
             for (int k = 0; k < MS_ITEMS; k++) {
-                const uint32_t w = k * MS_THREADS + tid;
+                const uint32_t w = k * MS_THREADS + tq8;
                 o[k] = w < len ? stage[w] : LIST_INVALID;
                 const u64 mS = __ballot(o[k] != LIST_INVALID && !(o[k] & MS_REC_BIG)), mB = __ballot(o[k] != LIST_INVALID && (o[k] & MS_REC_BIG));
                 if (lane == 0) wc[k * MS_NW + wave] = (uint32_t)__popcll(mS) | ((uint32_t)__popcll(mB) << 16);
@@ -1272,6 +1286,7 @@ static int msd_initial_sort(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t nt
     m.c_small = bt.c_small;
     m.c_groups = bt.c_groups;
     m.err = bt.errflag;
+    m.gout = GidOut{bt.gidof, bt.grank, bt.gcount, bt.gwide, bt.S, bt.B, 0u};
     m.force_old = force_old ? 1u : 0u;
     m.fuse = fuse;
     {

@@ -54,6 +54,7 @@ constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS; // 8192 elements per workgr
                                                      // scan overhead per element against 256 x 16, -7 % on the bench)
 constexpr uint32_t RANK_RESOLVED = 0x80000000u;      // suffix is alone in its group
 constexpr int SUMMARY_WORDS = 20; // round summary: see round_begin (bwt.hip)
+constexpr uint32_t GID_MAX = 4096;  // large groups of a block a round can number densely (12 key bits)
 constexpr int RS_ROWS = 22;       // per-block rows of the suffix sort's round state (layout_batch, api.hip)
 constexpr uint32_t MS_BG_ROW = 65552, MS_LEVELS = 5, MS_SEG_SLOTS = 112, MS_SEG_ROW = 264, MS_UNIT_CAP = 4096, MS_ITEM_CAP = 224,
                    MS_CNT_WORDS = 48, MS_MIN_N = 131072; // (levels whose blocks stay below MS_MIN_N bytes keep the 8-pass path: no tables for them)
@@ -111,6 +112,15 @@ struct Batch {
     uint32_t *summary;  // [SUMMARY_WORDS] what the host reads, one round late
     unsigned long long *stat_A; // [1] sum over rounds of the unresolved suffixes entering them
     uint32_t *errflag; // [1]
+    // Numbers for the large groups of a round (bwt.hip): whoever writes a large group to a big list (chunk_finish,
+    // refine_one, refine) draws a number for it -- one atomic add per GROUP -- and leaves number -> rank and rank -> number;
+    // the big lists are then sorted on [number : 12][key2 : 20] in FOUR 8-bit passes instead of on [rank : 20][key2 : 20]
+    // in five.  (The order of the groups among each other does not matter: only that a group's records meet.)
+    uint16_t *gidof;   // [B][S]  number of the large group whose rank this is (written for the ranks of large groups only)
+    uint32_t *grank;   // [2][B][GID_MAX] rank of every numbered group; [round & 1]: a round's refine_one reads one half
+                       //         while it fills the other for the next round
+    uint32_t *gcount;  // [B]     numbers drawn for the lists being written (round_begin clears it)
+    uint32_t *gwide;   // [2]     [round & 1] != 0: some block ran out of numbers for that round: its lists are sorted on ranks
     // bucket-first initial sort (bwt_msd.h): 2-byte buckets, oversized buckets split level by level, every bucket
     // that fits a tile finished inside one workgroup
     uint32_t *ms_bgcur;  // [B][65536] bigram counts, then claim cursors of the partition
