@@ -2314,6 +2314,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     static_assert(sizeof(u64) == 2 * sizeof(uint32_t), "sa and headp together hold one 64-bit word per suffix");
     volatile uint32_t *const hrec0 = ctx->h_pinned + (size_t)mb * 8 + 64; // [MAX_ROUNDS + 1][SUMMARY_WORDS]
     const uint32_t epoch = (++ctx->bwt_epoch & 0xFFFFFFu) << 6;
+    Msd msd_keep{};
     if (use_msd) { // (its counters, rank-window cursors and bigram counts join the one clearing launch)
         clr.add(bt.ms_cnt, (MS_CNT_WORDS + (size_t)(MS_LEVELS + 2) * B) * sizeof(uint32_t));
         clr.add(bt.ms_bincur, (size_t)B * 256 * sizeof(uint32_t));
@@ -2323,20 +2324,10 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     }
     clr.launch(st);
     if (use_msd) {
-        BZH_TRY(msd_initial_sort(ctx, B, nmax, ntotal, bufB, bufD, bufA, bufC, binned, false, r0_fused,
-                                 hrec0 + (size_t)MAX_ROUNDS * SUMMARY_WORDS, epoch + 63u, &nOld, side ? ctx->side_ev[0] : nullptr));
+        BZH_TRY(msd_sort_begin(ctx, B, nmax, ntotal, bufB, bufD, bufA, bufC, binned, false, r0_fused,
+                               hrec0 + (size_t)MAX_ROUNDS * SUMMARY_WORDS, epoch + 63u, &nOld, side ? ctx->side_ev[0] : nullptr, &msd_keep));
         oldl = Lst{bt.ms_old, bt.ms_cnt + MC_OLD, B};
         a.lst = oldl;
-        if (getenv("BZH_TRACE_ROUNDS")) { // (debugging aid: waits for the device)
-            uint32_t c[MS_CNT_WORDS];
-            if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(c, bt.ms_cnt, sizeof c, hipMemcpyDeviceToHost) == hipSuccess)
-                fprintf(stderr, "[bzhip] initial sort: %u blocks bucket-first, %u blocks 8-pass; %u units; %.1f %% of the suffixes in oversized 2-byte buckets; oversized buckets per level %u %u %u %u %u (tiles %u %u %u %u %u)\n",
-                        c[MC_NEW], c[MC_OLD], c[MC_UNITS], 100.0 * 1024.0 * c[23] / (double)std::max<uint64_t>(1, ntotal), c[MC_SEGS + 1], c[MC_SEGS + 2], c[MC_SEGS + 3], c[MC_SEGS + 4], c[MC_SEGS + 5],
-                        c[MC_ITEMS + 1], c[MC_ITEMS + 2], c[MC_ITEMS + 3], c[MC_ITEMS + 4], c[MC_ITEMS + 5]);
-            if (c[32] | c[35])
-                fprintf(stderr, "[bzhip] chunk_finish, 16-cycle ticks over all workgroups: ticket+load+bucket index %u, ranking %u, stage scatter+barrier %u, reload %u, heads+suffix table %u, suffixes+extents+bins %u, keys+bin scan %u, all pairs %u, rank pairs out %u, lists out %u\n",
-                        c[32], c[33], c[34], c[35], c[36], c[37], c[38], c[39], c[40], c[41]);
-        }
     }
     const uint64_t ntotal_old = nOld == B ? ntotal : ntotal * nOld / B; // (statistics only)
     u64 *cur = bufA, *oth = bufB;
@@ -2425,11 +2416,24 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             KSpan ks(ctx, K_REFINE_INIT, 16 * ntotal_old);
             launch_refine_one<true>(ctx, r, nOld, nmax, binned);
         }
-        if (old_beside) { // the main stream goes on only behind the second stream's work
+        if (old_beside) {
             ctx->stream = st;
             hipEventRecord(ctx->side_ev[1], side);
-            hipStreamWaitEvent(st, ctx->side_ev[1], 0);
         }
+        if (use_msd) { // the rest of the bucket-first sort: deeper levels if level 1 left any, the finishing kernel
+            BZH_TRY(msd_sort_finish(ctx, st, msd_keep, ntotal, hrec0 + (size_t)MAX_ROUNDS * SUMMARY_WORDS, epoch + 63u));
+        if (getenv("BZH_TRACE_ROUNDS")) { // (debugging aid: waits for the device)
+            uint32_t c[MS_CNT_WORDS];
+            if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(c, bt.ms_cnt, sizeof c, hipMemcpyDeviceToHost) == hipSuccess)
+                fprintf(stderr, "[bzhip] initial sort: %u blocks bucket-first, %u blocks 8-pass; %u units; %.1f %% of the suffixes in oversized 2-byte buckets; oversized buckets per level %u %u %u %u %u (tiles %u %u %u %u %u)\n",
+                        c[MC_NEW], c[MC_OLD], c[MC_UNITS], 100.0 * 1024.0 * c[23] / (double)std::max<uint64_t>(1, ntotal), c[MC_SEGS + 1], c[MC_SEGS + 2], c[MC_SEGS + 3], c[MC_SEGS + 4], c[MC_SEGS + 5],
+                        c[MC_ITEMS + 1], c[MC_ITEMS + 2], c[MC_ITEMS + 3], c[MC_ITEMS + 4], c[MC_ITEMS + 5]);
+            if (c[32] | c[35])
+                fprintf(stderr, "[bzhip] chunk_finish, 16-cycle ticks over all workgroups: ticket+load+bucket index %u, ranking %u, stage scatter+barrier %u, reload %u, heads+suffix table %u, suffixes+extents+bins %u, keys+bin scan %u, all pairs %u, rank pairs out %u, lists out %u\n",
+                        c[32], c[33], c[34], c[35], c[36], c[37], c[38], c[39], c[40], c[41]);
+        }
+        }
+        if (old_beside) hipStreamWaitEvent(st, ctx->side_ev[1], 0); // the main stream goes on only behind the second stream's work
         KSpan ks(ctx, K_RANK_APPLY, 12 * ntotal);
         rank_apply<<<dim3((nmax + APPLY_W - 1) / APPLY_W, B), 256, 0, st>>>(binned, bt.n, bt.rank, bt.S);
     }
@@ -2686,7 +2690,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             // paths go first with full-size launches (they take a millisecond), by then round 0's own summary is
             // there and the SWEEP path runs with exact sizes -- or, mostly, not at all.
             run_A();
-            run_T();
+            if (!(r0_fused && nOld == 0)) run_T(); // (every block on the bucket-first sort: all small groups sit round 0 out -- not even an empty launch)
             if (const hipError_t we = wait_summary(0, s); we != hipSuccess) return fail_wait(we);
             const uint64_t total = (uint64_t)s[8];
             err |= s[14];

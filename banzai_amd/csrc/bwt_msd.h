@@ -601,7 +601,7 @@ __global__ void __launch_bounds__(MS_THREADS) seg_count(Msd m, uint32_t L)
     }
 }
 
-__global__ void __launch_bounds__(256) seg_plan(Msd m, uint32_t L)
+__global__ void __launch_bounds__(256) seg_plan(Msd m, uint32_t L, uint32_t *hrec = nullptr, uint32_t seq = 0)
 {
     const uint32_t nsegs = m.cnt[MC_SEGS + L];
     const uint32_t tid = threadIdx.x;
@@ -657,6 +657,17 @@ __global__ void __launch_bounds__(256) seg_plan(Msd m, uint32_t L)
             }
         }
         __syncthreads();
+    }
+    // Level 1 tells the host how many buckets are still oversized: text mostly has none, and the host then leaves the twelve
+    // launches of levels 2-5 out (it reads this while seg_scatter of level 1 runs: nothing waits).  Words 4 and 5 of the
+    // plan's record; the last workgroup to finish writes them.
+    if (hrec && tid == 0) {
+        __threadfence();
+        if (atomicAdd(&m.cnt[5], 1u) == gridDim.x - 1) {
+            hrec[4] = atomicAdd(&m.cnt[MC_SEGS + L + 1], 0u);
+            __threadfence_system();
+            __hip_atomic_store(hrec + 5, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -1256,12 +1267,17 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
 // device in bt.ms_cnt[MC_OLD]).  Outputs for the blocks it handles: (rank word, suffix) pairs binned into `binned`,
 // small-group lists in `tail`, big lists in `big`, c_small / c_big / c_groups -- what refine_one<init> leaves.
 // X / Y: the two list buffers the partition levels alternate between (X also receives the 2-byte partition).
-static int msd_initial_sort(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal, u64 *X, u64 *Y, u64 *big, u64 *tail, u64 *binned,
-                            bool force_old, uint32_t fuse, volatile uint32_t *hrec, uint32_t seq, uint32_t *n_old, hipEvent_t ev_plan)
+// In two halves: msd_sort_begin queues everything up to level 1 of the oversized buckets and returns as soon as the plan has
+// reported (the blocks that keep the 8 passes are then queued on the second stream, beside all this); msd_sort_finish
+// waits for level 1's report -- which arrives while its scatter runs -- queues the deeper levels only if a bucket is
+// still oversized (text: mostly none; twelve empty launches were 68 us of every step), then the finishing kernel.
+static int msd_sort_begin(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal, u64 *X, u64 *Y, u64 *big, u64 *tail, u64 *binned,
+                          bool force_old, uint32_t fuse, volatile uint32_t *hrec, uint32_t seq, uint32_t *n_old, hipEvent_t ev_plan, Msd *keep)
 {
     Batch &bt = ctx->bt;
     hipStream_t st = ctx->stream;
-    Msd m{};
+    Msd &m = *keep;
+    m = Msd{};
     m.blk = bt.rle;
     m.n = bt.n;
     m.S = bt.S;
@@ -1316,15 +1332,9 @@ static int msd_initial_sort(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t nt
         }
         {
             KSpan ks(ctx, K_MSD_LEVELS, 0, 3 * MS_LEVELS);
-            for (uint32_t L = 1; L <= MS_LEVELS; L++) {
-                seg_count<<<dim3(1024), MS_THREADS, 0, st>>>(m, L);
-                seg_plan<<<dim3(256), 256, 0, st>>>(m, L);
-                seg_scatter<<<dim3(1024), MS_THREADS, 0, st>>>(m, L);
-            }
-        }
-        {
-            KSpan ks(ctx, K_MSD_FINISH, 16 * ntotal);
-            chunk_finish<<<dim3(512), MS_THREADS, 0, st>>>(m);
+            seg_count<<<dim3(1024), MS_THREADS, 0, st>>>(m, 1);
+            seg_plan<<<dim3(256), 256, 0, st>>>(m, 1, const_cast<uint32_t *>(hrec), seq);
+            seg_scatter<<<dim3(1024), MS_THREADS, 0, st>>>(m, 1);
         }
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -1342,5 +1352,38 @@ static int msd_initial_sort(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t nt
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     *n_old = hrec[0];
+    return BZH_OK;
+}
+
+static int msd_sort_finish(bzh_ctx *ctx, hipStream_t st, const Msd &m, uint64_t ntotal, volatile uint32_t *hrec, uint32_t seq)
+{
+    if (m.force_old) return BZH_OK;
+    {
+        KSpan ks(ctx, K_MSD_LEVELS, 0, 3 * (MS_LEVELS - 1));
+        // what level 1 left oversized (it reports while its scatter runs)
+        for (uint64_t it = 0, idle = 0; hrec[5] != seq; it++) {
+            if ((it & 0xFFFu) == 0xFFFu) {
+                const hipError_t e = hipStreamQuery(st);
+                if (e != hipSuccess && e != hipErrorNotReady) HIP_TRY(ctx, e);
+                if (e == hipSuccess && ++idle > 64) {
+                    bzh_set_error(ctx, "BWT: level 1 of the initial sort never reported (internal error)");
+                    return BZH_E_HIP;
+                }
+            }
+            __builtin_ia32_pause();
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        const uint32_t deeper = hrec[4];
+        for (uint32_t L = 2; L <= MS_LEVELS && deeper; L++) {
+            seg_count<<<dim3(1024), MS_THREADS, 0, st>>>(m, L);
+            seg_plan<<<dim3(256), 256, 0, st>>>(m, L);
+            seg_scatter<<<dim3(1024), MS_THREADS, 0, st>>>(m, L);
+        }
+    }
+    {
+        KSpan ks(ctx, K_MSD_FINISH, 16 * ntotal);
+        chunk_finish<<<dim3(512), MS_THREADS, 0, st>>>(m);
+    }
+    HIP_TRY(ctx, hipGetLastError());
     return BZH_OK;
 }
