@@ -291,6 +291,7 @@ __global__ void __launch_bounds__(64) mtf_walk_par(Batch bt, const int32_t *tlas
     __shared__ uint8_t names[256];
     __shared__ uint32_t ls[4];
     __shared__ uint16_t Etab[256];         // list position of every name
+    __shared__ __attribute__((aligned(16))) uint32_t MF[8]; // per chunk: the list places of its new symbols, one bit each
     // (the tile is walked in halves of 1024 bytes so that a wavefront needs under 5 KB of LDS: the walk is a chain of
     // dependent steps per wavefront, what hides its latency is the number of wavefronts a compute unit can hold)
     __shared__ uint8_t hsym[1024];     // names of the run heads of the half, in order
@@ -305,9 +306,9 @@ __global__ void __launch_bounds__(64) mtf_walk_par(Batch bt, const int32_t *tlas
     // ---- list at tile entry: E[name] = names with a larger key
     int k[4] = {keys[lane], keys[64 + lane], keys[128 + lane], keys[192 + lane]};
     int front;
+    const uint32_t regs = (num_names + 63u) / 64u; // registers of 64 names in use (text: two or three of four)
     {
         uint32_t e[4] = {0, 0, 0, 0};
-        const uint32_t regs = (num_names + 63u) / 64u;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             if ((uint32_t)r < regs) {
@@ -433,24 +434,35 @@ __global__ void __launch_bounds__(64) mtf_walk_par(Batch bt, const int32_t *tlas
         int pos;
         unsigned long long firsts = __ballot(act && p < 0); // one lane per distinct symbol of the chunk
         const bool more = hb + 64 < H || !last_half;
-        int eo[4] = {0, 0, 0, 0}, add[4] = {0, 0, 0, 0};
-        if (more) {
-            eo[0] = (int)Etab[lane];
-            eo[1] = (int)Etab[64 + lane];
-            eo[2] = (int)Etab[128 + lane];
-            eo[3] = (int)Etab[192 + lane];
-        }
-        // a symbol that is new in the chunk: its place in the list at chunk entry + the new symbols before it that were
-        // behind it (one step per distinct symbol; the same steps move the unseen symbols of the list back)
+        // MF: the places (in the list at chunk entry) of the chunk's new symbols, a bit each -- places are distinct
+        if (lane < 8) MF[lane] = 0u;
+        if (act && p < 0) atomicOr(&MF[(uint32_t)Eown >> 5], 1u << ((uint32_t)Eown & 31u));
+        // a symbol that is new in the chunk: its place in the list at chunk entry + the new symbols BEFORE it in the chunk
+        // that were behind it in the list (one scalar step per distinct new symbol)
         int cntB = 0;
         while (firsts) {
             const int u = __ffsll((long long)firsts) - 1;
             firsts &= firsts - 1ull;
             const int eu = rdlane(Eown, u);
             cntB += (u < lane && eu > Eown) ? 1 : 0;
-            if (more) {
+        }
+        // the list when the next chunk begins: an unseen symbol moves back by the new symbols that were behind it = the
+        // bits of MF above its place (no loop over the new symbols: a shift and two population counts per name)
+        int eo[4] = {0, 0, 0, 0}, add[4] = {0, 0, 0, 0};
+        if (more) {
+            const uint4 ma = *reinterpret_cast<const uint4 *>(&MF[0]), mb = *reinterpret_cast<const uint4 *>(&MF[4]);
+            const unsigned long long W0 = ((unsigned long long)ma.y << 32) | ma.x, W1 = ((unsigned long long)ma.w << 32) | ma.z,
+                                     W2 = ((unsigned long long)mb.y << 32) | mb.x, W3 = ((unsigned long long)mb.w << 32) | mb.z;
+            const int T2 = (int)__popcll(W3), T1 = T2 + (int)__popcll(W2), T0 = T1 + (int)__popcll(W1);
 #pragma unroll
-                for (int q = 0; q < 4; q++) add[q] += eu > eo[q] ? 1 : 0;
+            for (int q = 0; q < 4; q++) {
+                if ((uint32_t)q < regs) {
+                    eo[q] = (int)Etab[q * 64 + lane];
+                    const uint32_t e = (uint32_t)eo[q], sel = e >> 6;
+                    const unsigned long long Ws = sel == 0u ? W0 : sel == 1u ? W1 : sel == 2u ? W2 : W3;
+                    const int Ts = sel == 0u ? T0 : sel == 1u ? T1 : sel == 2u ? T2 : 0;
+                    add[q] = (int)__popcll((Ws >> (e & 63u)) >> 1) + Ts;
+                }
             }
         }
         // a symbol seen before in the chunk, last at lane p: the distinct symbols between p and me
@@ -458,7 +470,8 @@ __global__ void __launch_bounds__(64) mtf_walk_par(Batch bt, const int32_t *tlas
         if (act) opos[hoff[idx]] = (uint8_t)pos;
         if (more) { // the list when the next chunk begins
 #pragma unroll
-            for (int q = 0; q < 4; q++) Etab[q * 64 + lane] = (uint16_t)(eo[q] + add[q]);
+            for (int q = 0; q < 4; q++)
+                if ((uint32_t)q < regs) Etab[q * 64 + lane] = (uint16_t)(eo[q] + add[q]);
             // (seen symbols are overwritten: position = distinct symbols whose last occurrence comes later)
             const unsigned long long lasts = __ballot(islast);
             if (islast) Etab[c] = (uint16_t)__popcll(lasts & ~upto);
