@@ -375,6 +375,26 @@ __device__ __forceinline__ uint32_t wave_all_and(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) & (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
 }
 
+// Inclusive OR-scan over the 64 lanes by data-parallel primitives (no lane addresses, no compares): four shifts inside the
+// rows of 16 (a lane without a source reads 0), then the last lane of a row to the rows behind it.  OR is idempotent, so
+// the plain doubling needs no bank masks.
+#define BZH_DPP_OR(v, ctrl, rowmask) ((v) | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rowmask), 0xF, true))
+__device__ __forceinline__ uint32_t wave_incl_or(uint32_t v)
+{
+    v = BZH_DPP_OR(v, 0x111, 0xF); // row_shr:1
+    v = BZH_DPP_OR(v, 0x112, 0xF); // row_shr:2
+    v = BZH_DPP_OR(v, 0x114, 0xF); // row_shr:4
+    v = BZH_DPP_OR(v, 0x118, 0xF); // row_shr:8
+    v = BZH_DPP_OR(v, 0x142, 0xA); // row_bcast:15 -> rows 1 and 3
+    v = BZH_DPP_OR(v, 0x143, 0xC); // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+// the value of the lane below (0 into lane 0)
+__device__ __forceinline__ uint32_t wave_from_below(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true); // wave_shr:1
+}
+
 // Workgroup exclusive add-scan of one value per thread.  `lds` needs (threads/64)+1 words.
 // Returns the exclusive prefix; *total receives the workgroup sum.
 // (`tid`: the thread's index as the caller holds it -- a kernel that loops over work items and has made its index opaque

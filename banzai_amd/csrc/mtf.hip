@@ -417,19 +417,9 @@ __global__ void __launch_bounds__(64) mtf_walk_par(Batch bt, const int32_t *tlas
         // seen so far.  They are all lower lanes except the predecessors q_v of the lanes v below me: a prefix OR of
         // one bit per lane, six shuffle steps on the two halves of the mask.
         uint32_t xlo = (act && p >= 0 && p < 32) ? 1u << p : 0u, xhi = (act && p >= 32) ? 1u << (p - 32) : 0u;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t tl = (uint32_t)__shfl_up((int)xlo, d, 64), th = (uint32_t)__shfl_up((int)xhi, d, 64);
-            if (lane >= d) {
-                xlo |= tl;
-                xhi |= th;
-            }
-        }
-        { // exclusive: the predecessors of the lanes strictly below me
-            const uint32_t tl = (uint32_t)__shfl_up((int)xlo, 1, 64), th = (uint32_t)__shfl_up((int)xhi, 1, 64);
-            xlo = lane ? tl : 0u;
-            xhi = lane ? th : 0u;
-        }
+        // (a prefix OR by data-parallel primitives, then one lane down: exclusive -- the predecessors of the lanes strictly below me)
+        xlo = wave_from_below(wave_incl_or(xlo));
+        xhi = wave_from_below(wave_incl_or(xhi));
         const unsigned long long A = lower & ~(((unsigned long long)xhi << 32) | xlo);
         int pos;
         unsigned long long firsts = __ballot(act && p < 0); // one lane per distinct symbol of the chunk
