@@ -82,8 +82,9 @@ BZH_API int bzh_set_profiling(bzh_ctx *ctx, int enabled);
 enum { BZH_MODE_REFERENCE = 0, BZH_MODE_FIXED = 1 };
 BZH_API int bzh_set_mode(bzh_ctx *ctx, int mode);
 /* 1 (default): batches run one after the other on the context's stream.  2: two half-batch lanes on
- * internal streams and host threads.  Since the suffix-sort rounds stopped waiting for the host the GPU is
- * busy without it and 2 lanes measure the same throughput as 1; kept for experiments. */
+ * internal streams and host threads.  Measured on the 100 MB headline (one batch split in two): 2 lanes are 3-5 % SLOWER
+ * than 1 (round 5: 9.72 against 9.39 ms; the per-batch latency chains -- huff_build, the late doubling rounds -- are paid
+ * twice and overlap less than they cost); kept for experiments only. */
 BZH_API int bzh_set_lanes(bzh_ctx *ctx, int lanes);
 BZH_API int bzh_get_stats(const bzh_ctx *ctx, bzh_stats *out);
 /* Test hook: inject a fault into the next suffix sort of this context (kind 1: one tile of the first block never
