@@ -403,7 +403,10 @@ class Context:
         if chunk_bytes is not None:
             self.check(lib().bzh_stream_set_chunk(self._h, chunk_bytes))
         self.check(lib().bzh_stream_begin(self._h))
-        self._sbuf = None
+        # (the output buffer of the previous stream is kept: a fresh numpy array costs a page fault per 4 KiB the library
+        # writes -- several milliseconds per stream for the ~30 MB a 100 MB input produces)
+        if not hasattr(self, "_sbuf"):
+            self._sbuf = None
 
     def stream_feed(self, data, eof=False):
         """-> stream bytes that became final with this feed"""

@@ -1887,7 +1887,7 @@ __global__ void __launch_bounds__(1024) period_probe(ProbeArgs a)
 // round's work lists and gates, clears the counters and the digit totals of the blocks on the big-list
 // path, and writes the summary the host reads one round late.
 // summary words: 0 round, 1 nS, 2 nA, 3 nT, 4 nQ, 5 maxS, 6 maxA, 7 maxT, 8 total unresolved, 9 of them sitting the round out,
-//                10 sum of the S lists, 11 this round sorts its big lists on ranks (five passes; else on group numbers: four), 12 sum of the A lists, 14 error flag, 15 largest depth in use,
+//                10 sum of the S lists, 11 this round sorts its big lists on ranks (five passes; else on group numbers: four), 12 sum of the A lists, 13 (round 0) members of small groups that entered the first doubling step inside chunk_finish, 14 error flag, 15 largest depth in use,
 //                16 S blocks whose refine writes lists this round (the only ones that can leave SWEEP mode next round),
 //                17/18 sum over the rounds so far of the unresolved suffixes entering them, 19 sequence word (last)
 #ifndef QUAD_DIV
@@ -2023,9 +2023,12 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
         if (fl[k]) dst[k][off + pre[k]] = b;
     }
     if (wave == 0) { // the summary, one word per lane, straight into pinned host memory
-        const unsigned long long asum = *bt.stat_A + sum[0]; // unresolved suffixes entering the rounds so far
+        // unresolved suffixes entering the rounds so far.  The first doubling step of a bucket-first block's small groups
+        // runs inside chunk_finish (depth 7 -> 15): the members that ENTERED it count for round 0 (chunk_finish's counter),
+        // not the survivors that sit round 0 out.
+        const unsigned long long asum = *bt.stat_A + sum[0] + ((round == 0 && r0_fused) ? (unsigned long long)bt.ms_cnt[6] - sum[5] : 0ull);
         const uint32_t words[SUMMARY_WORDS] = {round,  tot[L_S], tot[L_A], tot[L_T], tot[L_Q], mx[0],  mx[1], mx[2], sum[0], sum[5],
-                                               sum[1], bt.gwide[round & 1u], sum[2],   0u,       *bt.errflag, mx[3], sum[4], (uint32_t)asum,
+                                               sum[1], bt.gwide[round & 1u], sum[2],   (round == 0 && r0_fused) ? bt.ms_cnt[6] : 0u, *bt.errflag, mx[3], sum[4], (uint32_t)asum,
                                                (uint32_t)(asum >> 32), 0u};
         uint32_t mine = 0;
 #pragma unroll
@@ -2642,7 +2645,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         ctx->k_bytes[K_ACTIVE_GEN] += eA * 20;                      // record in, re-keyed record out, one rank gather
         ctx->k_bytes[K_REFINE_ROUNDS] += eA * 20;                   // record in, rank word, list record out
         ctx->k_bytes[K_TAIL_ROUND] += (tot - eS - eA - sm[9]) * 24; // record in, key gather, rank word, survivor out (not the groups that sit the round out)
-        if (sm[0] == 0) ctx->k_bytes[nOld == B ? K_REFINE_INIT : K_MSD_FINISH] += tot * 8; // the list records the initial refinement wrote
+        if (sm[0] == 0) ctx->k_bytes[nOld == B ? K_REFINE_INIT : K_MSD_FINISH] += tot * 8 + (uint64_t)sm[13] * 8; // the list records the initial refinement wrote + the 8 text bytes each member of a small group was keyed on
     };
 
     for (uint32_t round = 0; round < (uint32_t)MAX_ROUNDS; round++) {

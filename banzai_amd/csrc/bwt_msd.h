@@ -1138,9 +1138,9 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
         // ---- the first doubling step of the small groups: every member counts the members that sort before it
         // (gi[k] becomes [class : 2 @30][first position of the element's group in the block's order : 20])
         {
-            uint32_t nsv = 0; // my records for the two lists: small groups | large groups << 16
+            uint32_t nsv = 0, nin = 0; // my records for the two lists: small groups | large groups << 16; my members of small groups
             const uint32_t tq5 = (uint32_t)ms_opaque((int)tid);
-            #pragma unroll
+#pragma unroll
             for (int k = 0; k < MS_ITEMS; k++) {
                 const uint32_t w = k * MS_THREADS + tq5;
                 if (w < len) {
@@ -1148,6 +1148,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
                     const uint32_t g = gi[k] & 8191u;
                     uint32_t hp = s + g, dest = w;
                     if (fuse && c == CLS_SMALL && !(m.dbg & 64u)) {
+                        nin++; // (a member of a small group ENTERS the first doubling step: counted in A, bwt.hip round_begin)
                         const uint32_t ge = g + ((gi[k] >> 24) & 63u) + 1u;
                         const u64 my = stage[w];
                         uint32_t less = 0, eq = 0, eqb = 0;
@@ -1169,7 +1170,11 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
                 }
             }
             nsv = wave_all_add(nsv);
-            if (lane == 0) lsv[wave] = nsv;
+            nin = wave_all_add(nin);
+            if (lane == 0) {
+                lsv[wave] = nsv;
+                if (nin) atomicAdd(&m.cnt[6], nin);
+            }
         }
         __syncthreads(); // the keys have been read: the stage is free
         if (!fuse && tid < 256 && bh[tid]) pendG = atomicAdd(&m.bincur[(size_t)b * 256 + tid], bh[tid]);

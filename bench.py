@@ -559,10 +559,11 @@ def main():
                          # the whole path by SURVEY 8(d)'s fixed accounting, over the TIMED region (all ranks)
                          "path_alg_bytes_per_step": round(alg), "path_achieved": round(path_gbs, 1),
                          "path_frac": round(path_gbs / (HBM_PEAK_GBS * world), 4),
-                         "path_A_convention": "A = unresolved suffixes entering each doubling round actually run (a block on "
-                                              "the bucket-first initial sort enters round 0 at depth 7 with the small groups "
-                                              "already at depth 15 -- they are counted in round 0's A all the same; a block on "
-                                              "the 8 passes enters at depth 8)"},
+                         "path_A_convention": "A = unresolved suffixes entering each doubling round actually run.  A block on the "
+                                              "bucket-first initial sort enters round 0 at depth 7; the round-0 step of its small "
+                                              "groups (8 text bytes per member, ranked in LDS) runs inside chunk_finish and its "
+                                              "members count for round 0 as they would in a kernel of their own; a block on the "
+                                              "8 passes enters at depth 8"},
             "cpu_baseline": cpu,
             "value_host_inclusive": host_incl,
             "value_stream_api": stream_api,
