@@ -1794,10 +1794,26 @@ __global__ void __launch_bounds__(1024) period_probe(ProbeArgs a)
     if (p == 0xFFFFFFFFu || 2ull * p > n) return;
     const uint32_t r = n % p;
     if (r == 0) return;
-    // 2. is p a period of the text?  (S[u] == S[u + p] for every u < n - p)
+    // 2. is p a period of the text?  (S[u] == S[u + p] for every u < n - p)  16 bytes a step (the block's base is 16-byte
+    //    aligned; the second operand is read unaligned), four independent steps in flight: one workgroup per block walks
+    //    0.9 MB here, and a byte per dependent load was most of the kernel's 1.4 ms
     {
         bool bad = false;
-        for (uint32_t u = tid; u < n - p && !bad; u += 1024) bad = s[u] != s[u + p];
+        const uint32_t lim = n - p;
+        for (uint32_t u0 = tid * 16u; u0 < lim && !bad; u0 += 1024u * 16u * 4u) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t u = u0 + (uint32_t)q * 1024u * 16u;
+                if (u + 16u <= lim) {
+                    uint4 x, y;
+                    __builtin_memcpy(&x, s + u, 16);
+                    __builtin_memcpy(&y, s + u + p, 16);
+                    bad |= x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w;
+                } else {
+                    for (uint32_t v = u; v < lim; v++) bad |= s[v] != s[v + p];
+                }
+            }
+        }
         if (bad) sh_bad = 1;
     }
     __syncthreads();
@@ -1815,7 +1831,12 @@ __global__ void __launch_bounds__(1024) period_probe(ProbeArgs a)
     }
     // flags of the tail rotations n-p+1 .. n-1 (slot a - (n-p+1)): tf[k] = leads the order, tf[p + k] = has a plainly
     // congruent neighbour (2p <= n <= S)
-    for (uint32_t k = tid; k < 2 * p; k += 1024) tf[k] = 0;
+    for (uint32_t k = tid * 16u; k < 2 * p; k += 1024u * 16u) { // (tf = the block's flag bytes: 16-byte aligned, 2p <= n <= S)
+        if (k + 16u <= 2 * p)
+            *reinterpret_cast<uint4 *>(tf + k) = make_uint4(0u, 0u, 0u, 0u);
+        else
+            for (uint32_t v = k; v < 2 * p; v++) tf[v] = 0;
+    }
     __syncthreads();
     const uint32_t d0 = sh_d0;
     if (d0 == 0xFFFFFFFFu) return; // (cannot happen for a minimal period with r != 0)
@@ -1826,25 +1847,49 @@ __global__ void __launch_bounds__(1024) period_probe(ProbeArgs a)
     const uint32_t tail0 = n - p + 1;
     {
         bool bad = false;
-        for (uint32_t e = 1 + tid; e < n; e += 1024) {
-            if (headp[e] != headp[e - 1]) continue;
-            const uint32_t x = sa[e - 1], y = sa[e];
-            const uint32_t mx = x % p, my = y % p;
-            if (mx == my) {
-                if (x >= tail0) tf[p + x - tail0] = 1;
-                if (y >= tail0) tf[p + y - tail0] = 1;
-                continue;
+        // x mod p without a division: p is fixed for the block (x < 2^20, p >= 1: floor(x * ceil(2^32 / p) / 2^32) is the
+        // quotient or one less... exact here because x * p < 2^40 keeps the error below one: corrected by one compare)
+        const uint32_t pinv = (uint32_t)((0x100000000ull + p - 1u) / p);
+        auto modp = [&](uint32_t x) -> uint32_t {
+            uint32_t q = __umulhi(x, pinv);
+            uint32_t rem = x - q * p;       // q may be one too large: then rem wrapped
+            if ((int32_t)rem < 0) rem += p;
+            if (rem >= p) rem -= p;
+            return rem;
+        };
+        for (uint32_t e0 = 1 + tid; e0 < n && !bad; e0 += 1024u * 8u) {
+            uint32_t hx[8], hy[8], sx[8], sy[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) { // eight independent steps: the loads of all of them are in flight together
+                const uint32_t e = e0 + (uint32_t)q * 1024u;
+                const bool in = e < n;
+                hy[q] = in ? headp[e] : 0u;
+                hx[q] = in ? headp[e - 1] : 1u;
+                sx[q] = in ? sa[e - 1] : 0u;
+                sy[q] = in ? sa[e] : 0u;
             }
-            // x - n = x + (p - r) (mod p)
-            const bool xt = x >= tail0 && n - x <= h, yt = y >= tail0 && n - y <= h;
-            const uint32_t ex = (mx + p - r) % p, ey = (my + p - r) % p;
-            if (xt && !(y >= tail0) && ex == my) {
-                tf[x - tail0] = 1;
-            } else if (yt && !(x >= tail0) && ey == mx) {
-                tf[y - tail0] = 1;
-            } else {
-                bad = true;
-                break;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (hy[q] != hx[q]) continue; // (also the steps past the end)
+                const uint32_t x = sx[q], y = sy[q];
+                const uint32_t mx = modp(x), my = modp(y);
+                if (mx == my) {
+                    if (x >= tail0) tf[p + x - tail0] = 1;
+                    if (y >= tail0) tf[p + y - tail0] = 1;
+                    continue;
+                }
+                // x - n = x + (p - r) (mod p)
+                const bool xt = x >= tail0 && n - x <= h, yt = y >= tail0 && n - y <= h;
+                uint32_t ex = mx + p - r, ey = my + p - r;
+                if (ex >= p) ex -= p;
+                if (ey >= p) ey -= p;
+                if (xt && !(y >= tail0) && ex == my) {
+                    tf[x - tail0] = 1;
+                } else if (yt && !(x >= tail0) && ey == mx) {
+                    tf[y - tail0] = 1;
+                } else {
+                    bad = true;
+                }
             }
         }
         if (bad) sh_bad = 1;
