@@ -120,6 +120,7 @@ static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
     carve(p, bt.rank, NB * S);
     carve(p, bt.sa, NB * S);
     carve(p, bt.headp, NB * S);
+    carve(p, bt.binned, NB * S);
     carve(p, bt.listA, NB * S);
     carve(p, bt.listB, NB * S);
     carve(p, bt.listC, NB * S);

@@ -765,6 +765,7 @@ struct RefineArgs {
     int init;
     uint32_t T;
     Lst lst;
+    uint32_t dig_stride;   // words between two blocks' digit rows (sweep_bases; 0: TPB * 512, the rows of `hist`)
     GidOut gout;           // numbers for the large groups this kernel writes (for the NEXT round's sort)
     const uint32_t *grank; // [B][GID_MAX] refine_one: the rank of every numbered group of THIS round
     const uint32_t *gwide; // [1] refine_one: 0 = the sorted list carries group numbers, not ranks (this round's word)
@@ -1228,7 +1229,9 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
     __shared__ uint32_t s_offS, s_offB;
     __shared__ uint32_t s_ng, s_gbase, glist[SORT_TILE / TAIL_G]; // ranks of the large groups that start in the tile (they get numbers, below)
     __shared__ uint32_t bh[INIT ? 256 : 1], bcur[INIT ? 256 : 1], bgo[INIT ? 256 : 1]; // rank binning: counts, cursors, offsets
+    __shared__ uint32_t dh[INIT ? 384 : 1]; // INIT: counts of the three 7-bit digits of the unresolved heads (a SWEEP start needs them)
     if (INIT && threadIdx.x < 256) bh[threadIdx.x] = 0;
+    if (INIT && threadIdx.x < 384) dh[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_ng = 0;
     stage_tile(list, tile0, cnt, lds);
     if (threadIdx.x < (uint32_t)TAIL_G) halo[1 + threadIdx.x] = tend + threadIdx.x < cnt ? list[tend + threadIdx.x] : 0ull;
@@ -1342,16 +1345,24 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
         s_offB = totB ? atomicAdd(&a.c_big[b], totB) : 0u;
     }
     uint32_t *rank = a.rank + base;
+    // INIT: a block may turn out to start in SWEEP mode (round_begin decides from the number of groups this kernel counts):
+    // it then needs the suffixes in SA order, the group head at every position and the digit counts of its unresolved
+    // heads, so they are left for every block here -- 8 coalesced bytes per suffix and a few LDS adds per run of equal
+    // heads -- instead of refining such blocks a second time with the three-kernel form (0.57 ms for the 28 blocks of a
+    // near-periodic quarter of config 5).
     const bool narrow = !INIT && *a.gwide == 0u;
     const uint32_t *grank = a.grank + (size_t)b * GID_MAX; // (this round's half)
     // per element: [class:2 @62][foreign:1 @61][valid:1 @60][head:20 @40][suffix:20 @0]
     u64 outv[SORT_ITEMS];
+    uint32_t isuf[INIT ? SORT_ITEMS : 1], ihead[INIT ? SORT_ITEMS : 1]; // INIT: SA order and heads of my 16 positions
+    uint32_t ph = 0, pc = 0, ph7 = 0, pc7 = 0;                          // INIT: open runs of the digit counting
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; k++) outv[k] = 0ull;
     if (q0 < cnt) {
 #pragma unroll
         for (int k = 0; k < SORT_ITEMS; k++) {
             const uint32_t q = q0 + k;
+            if (INIT) isuf[k] = ihead[k] = 0u;
             if (q < cnt) {
                 const uint32_t f = (packed >> (2 * k)) & 3u;
                 if (f & 1u) cg = (int)q;
@@ -1366,16 +1377,64 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
                 const uint32_t head = gbase + (uint32_t)cd;
                 if (c == CLS_BIG && (f & 2u)) glist[atomicAdd(&s_ng, 1u)] = head; // (a large group has more than TAIL_G members: the list cannot overflow)
                 // (the last column is emitted from the ranks; a rank that did not move and stays unresolved is in place)
-                if (INIT)
+                if (INIT) {
                     atomicAdd(&bh[i >> 12], 1u); // every suffix gets a rank: binned by 4096-suffix window, then applied
+                    isuf[k] = i;
+                    ihead[k] = head;
+                    if (c != CLS_SINGLE) { // heads rise with q: runs counted in registers, LDS touched once per run (as refine)
+                        if (head != ph) {
+                            if (pc) atomicAdd(&dh[ph & 127u], pc);
+                            ph = head;
+                            pc = 0;
+                        }
+                        pc++;
+                        if ((head >> 7) != ph7) {
+                            if (pc7) {
+                                atomicAdd(&dh[128 + (ph7 & 127u)], pc7);
+                                atomicAdd(&dh[256 + (ph7 >> 7)], pc7);
+                            }
+                            ph7 = head >> 7;
+                            pc7 = 0;
+                        }
+                        pc7++;
+                    }
+                }
                 else if (head != oldr) // (see tail_round: a SPLIT-mode block's "resolved" bits have no reader)
                     rank[rslot(i)] = c == CLS_SINGLE ? (head | RANK_RESOLVED) : head;
                 outv[k] = ((u64)c << 62) | ((u64)((foreign >> k) & 1u) << 61) | (1ull << 60) | ((u64)head << 40) | i;
             }
         }
     }
+    if (INIT) {
+        if (pc) atomicAdd(&dh[ph & 127u], pc);
+        if (pc7) {
+            atomicAdd(&dh[128 + (ph7 & 127u)], pc7);
+            atomicAdd(&dh[256 + (ph7 >> 7)], pc7);
+        }
+        if (q0 < cnt) { // my 16 consecutive SA positions (q0 is a multiple of 16; a ragged end is written entry by entry)
+            uint32_t *sap = a.sa + base + q0, *hpp = a.headp + base + q0;
+            if (q0 + SORT_ITEMS <= cnt) {
+#pragma unroll
+                for (int k = 0; k < SORT_ITEMS; k += 4) {
+                    *reinterpret_cast<uint4 *>(sap + k) = make_uint4(isuf[k], isuf[k + 1], isuf[k + 2], isuf[k + 3]);
+                    *reinterpret_cast<uint4 *>(hpp + k) = make_uint4(ihead[k], ihead[k + 1], ihead[k + 2], ihead[k + 3]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < SORT_ITEMS; k++)
+                    if (q0 + k < cnt) {
+                        sap[k] = isuf[k];
+                        hpp[k] = ihead[k];
+                    }
+            }
+        }
+    }
     if (__ballot(progress) && lane == 0) a.c_prog[b] = 1u; // same value from everyone
     __syncthreads(); // every thread is done with the staged tile; s_off* and the bin counts are there
+    if (INIT) { // the tile's digit row (read by sweep_bases in round 0 if the block starts in SWEEP mode)
+        uint32_t *row = a.dig + (size_t)b * a.dig_stride + (size_t)tile * 512;
+        for (int k = threadIdx.x; k < 384; k += SORT_THREADS) row[k] = dh[k];
+    }
     // numbers for the tile's large groups: ONE atomic add for all of them, requested now and used at the very end
     uint32_t pend_g = 0;
     const uint32_t ng = s_ng;
@@ -2169,7 +2228,7 @@ __global__ void __launch_bounds__(768) sweep_bases(RefineArgs a, uint32_t *dbase
     const uint32_t col = threadIdx.x % 384, seg = threadIdx.x / 384;
     const uint32_t half = (ntile + 1) / 2;
     const uint32_t t0 = seg ? half : 0u, t1 = seg ? ntile : half;
-    const uint32_t *p = a.dig + (size_t)b * a.TPB * 512 + col;
+    const uint32_t *p = a.dig + (size_t)b * (a.dig_stride ? a.dig_stride : a.TPB * 512u) + col;
     uint32_t sum = 0, t = t0;
     for (; t + 8 <= t1; t += 8) {
         uint32_t v[8];
@@ -2358,8 +2417,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     const uint32_t r0_fused = (use_msd && !r0_off) ? 1u : 0u;
     uint32_t nOld = B;
     Lst oldl = all;
-    u64 *const binned = reinterpret_cast<u64 *>(bt.sa);
-    static_assert(sizeof(u64) == 2 * sizeof(uint32_t), "sa and headp together hold one 64-bit word per suffix");
+    u64 *const binned = reinterpret_cast<u64 *>(bt.binned);
     volatile uint32_t *const hrec0 = ctx->h_pinned + (size_t)mb * 8 + 64; // [MAX_ROUNDS + 1][SUMMARY_WORDS]
     const uint32_t epoch = (++ctx->bwt_epoch & 0xFFFFFFu) << 6;
     Msd msd_keep{};
@@ -2461,8 +2519,12 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         // round 0 (below).  rank_apply then writes the rank array as whole lines.
         r.bpass = ++a.pass;
         if (nOld) {
-            KSpan ks(ctx, K_REFINE_INIT, 16 * ntotal_old);
+            KSpan ks(ctx, K_REFINE_INIT, 24 * ntotal_old);
+            r.dig = reinterpret_cast<uint32_t *>(bt.flg); // (the digit rows of the initial refinement: the flag bytes are free, `hist` holds its look-back words)
+            r.dig_stride = bt.S / 4;
             launch_refine_one<true>(ctx, r, nOld, nmax, binned);
+            r.dig = bt.hist;
+            r.dig_stride = 0;
         }
         if (old_beside) {
             ctx->stream = st;
@@ -2547,19 +2609,14 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         if (!nS) return;
         KSpan ks(ctx, K_SWEEP, 0, 3);
         if (round == 0) {
-            // round_begin has just picked the blocks that start in SWEEP mode: they need provisional SA entries,
-            // group heads by position and digit bases, which the one-kernel refinement does not produce -- the
-            // three-kernel refinement runs again over the sorted list of those blocks only (same ranks, same lists)
+            // round_begin has just picked the blocks that start in SWEEP mode: SA order, heads by position and digit rows are
+            // there (refine_one<init> leaves them for every block on the 8 passes); the rows become the bases of the passes
             RefineArgs r0 = r;
-            r0.init = 1;
             r0.cnt = bt.n;
-            r0.list = oth; // the sorted list (the big lists went to `cur`)
-            r0.big = cur;
-            r0.c_big = r0.c_small = r0.c_prog = bt.scratch; // consumed by round_begin already
-            r0.gout.gcount = nullptr; // (its large groups were numbered when the lists were first written)
-            r0.cpass = ++a.pass;
+            r0.dig = reinterpret_cast<uint32_t *>(bt.flg);
+            r0.dig_stride = bt.S / 4;
             r0.lst = Lst{bt.actS, bt.nlist + L_S, B};
-            launch_refine(ctx, r0, nS, nmax, true);
+            sweep_bases<<<dim3(nS), 768, 0, st>>>(r0, bt.dbase); // (before period_probe: it uses the flag bytes next)
         }
         {
             // near-periodic blocks are finished in this round (period_probe sets their depth to "h >= n")

@@ -82,6 +82,8 @@ struct Batch {
     uint32_t *rank; // [B][S]
     uint32_t *sa;   // [B][S]
     uint32_t *headp; // [B][S] group rank by SA position (SWEEP rounds read it instead of gathering)
+    uint2 *binned;   // [B][S] (rank word, suffix) pairs of the initial sort, binned by 4096-suffix window (rank_apply); memory of
+                     //        its own since round 5: a block on the 8 passes leaves its SA order in sa / headp at the same time
     uint2 *listA;   // [B][S] sort elements (ping-pong of the radix passes; the big-group list between rounds)
     uint2 *listB;   // [B][S]
     uint2 *listC;   // [B][S] small-group (TAIL) list of the block
