@@ -11,6 +11,13 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profiles_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
+# the PMC passes first: the bench line names the newest PMC file under profiles/ as the source of `roofline.traffic`, and that
+# has to be THIS round's (the file is written into the box's copy of profiles/ as well as into $OUT)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c -d "$OUT/pmc_$c" --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu --no-extra > "$OUT/pmc_$c.log" 2>&1
+done
+python3 scripts/pmc_summary.py "$OUT" "$TAG" > "$OUT/${TAG}_pmc_traffic.json"
+cp "$OUT/${TAG}_pmc_traffic.json" profiles/
 python3 bench.py > "$OUT/${TAG}_bench_n1.json" 2> "$OUT/bench.err"
 # BZH_NO_OVERLAP=1: the product runs the big-list passes on a second stream beside tail_round; a trace of that pass shows
 # kernel durations stretched by the sharing.  The roofline figure is defined on the serialized pass (HIP events, profiling
@@ -20,10 +27,6 @@ export BZH_NO_OVERLAP=1
 rocprofv3 --kernel-trace --stats -d "$OUT/prof" --output-format csv -- python3 bench.py --no-extra > "$OUT/${TAG}_bench_n1_under_rocprof.json" 2> "$OUT/prof.err"
 unset BZH_NO_OVERLAP
 cp "$(ls "$OUT"/prof/*/*kernel_stats.csv | head -1)" "$OUT/${TAG}_kernel_stats_bench_n1.csv"
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c -d "$OUT/pmc_$c" --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu --no-extra > "$OUT/pmc_$c.log" 2>&1
-done
-python3 scripts/pmc_summary.py "$OUT" "$TAG" > "$OUT/${TAG}_pmc_traffic.json"
 rm -rf "$OUT/prof" "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE
 # ---- round 4: the bucket-first initial sort (default for text since round 4) next to the 8 radix passes it replaces
 # (BZH_INIT=lsd; same box, same command), the kernel table of the 8-pass run and the cycles per phase of chunk_finish;
