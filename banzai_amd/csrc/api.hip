@@ -157,7 +157,7 @@ static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
         carve(p, bt.ms_units, MB * MS_UNIT_CAP);
         carve(p, bt.ms_segs, (size_t)(MS_LEVELS + 1) * MB * MS_SEG_SLOTS);
         carve(p, bt.ms_items, (size_t)(MS_LEVELS + 1) * MB * MS_ITEM_CAP);
-        carve(p, bt.ms_cnt, MS_CNT_WORDS + (size_t)(MS_LEVELS + 2) * NB);
+        carve(p, bt.ms_cnt, MS_CNT_WORDS + (size_t)(MS_LEVELS + 6) * NB + 2 + 4 * NB * MS_UNIT_CAP);
         carve(p, bt.ms_np, NB);
         carve(p, bt.ms_old, NB);
         carve(p, bt.ms_new, NB);

@@ -123,7 +123,12 @@ struct SortArgs {
     uint32_t has_n;        // 1: the alternates above are meaningful for this launch
     uint32_t only4;        // the host launches four passes only (no list of the round can run out of numbers): a raised *gwide is an error
     const uint16_t *gidof; // [B][S] (active_gen)
+    // round 0 of a batch on the bucket-first initial sort: the blocks whose large groups mid_sort orders in LDS (bwt_msd.h) are
+    // not this path's -- mid_np[b] != 0 (the block took that sort) and mid_spans[b] == 0 (no group spans several units); null:
+    // every listed block is
+    const uint32_t *mid_np, *mid_spans;
 };
+__device__ __forceinline__ bool ms_block_is_mid(const uint32_t *np, const uint32_t *spans, uint32_t b) { return np[b] != 0u && spans[b] == 0u; }
 
 constexpr int NBMAX = 256;
 constexpr u64 LIST_INVALID = ~0ull; // list slot without an unresolved suffix
@@ -320,6 +325,7 @@ __global__ void __launch_bounds__(SORT_THREADS) active_gen(SortArgs a, uint32_t 
 {
     uint32_t b, tile;
     if (!wg_map(a.T, a.lst, b, tile)) return;
+    if (a.mid_np && ms_block_is_mid(a.mid_np, a.mid_spans, b)) return; // (mid_sort's)
     const uint32_t cnt = a.cnt[b], n = a.n[b], h = a.hb[b];
     const uint32_t ntile = (cnt + SORT_TILE - 1) / SORT_TILE;
     launch_check(a.T, a.lst, tile, ntile, a.err);
@@ -522,6 +528,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
     if (MODE == GEN_LIST && a.has_n && !a.src_n && *a.gwide == 0u) return; // the fifth pass of a round whose keys have 32 bits
     uint32_t b, tile;
     if (!wg_map(a.T, a.lst, b, tile)) return;
+    if (MODE == GEN_LIST && a.mid_np && ms_block_is_mid(a.mid_np, a.mid_spans, b)) return; // (round 0: mid_sort's blocks)
     const uint32_t cnt = a.cnt[b], n = a.n[b];
     const uint32_t ntile = (cnt + SORT_TILE - 1) / SORT_TILE;
     launch_check(a.T, a.lst, tile, ntile, a.err);
@@ -2001,7 +2008,7 @@ constexpr uint32_t QUAD_BIT = 0x80000000u; // in st_ntail-derived gates: this ro
 enum ListId : int { L_S = 0, L_A = 1, L_R = 2, L_T = 3, L_Q = 4, L_P = 5 };
 
 __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32_t round, uint32_t *actP, uint32_t *hsum, uint32_t seq, uint32_t sweep_div,
-                                                    uint32_t r0_fused)
+                                                    uint32_t r0_fused, uint32_t mid_on)
 {
     const uint32_t b = threadIdx.x;
     const bool valid = b < B;
@@ -2009,7 +2016,7 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
     if (valid) bt.gcount[b] = 0u; // numbers are drawn afresh for the lists this round's refinement writes
     if (threadIdx.x == 0) bt.gwide[(round + 1u) & 1u] = 0u; // ... and so is that round's "a block ran out of numbers"
     // per-wavefront partial results: sums (all, S, A, n, sconv), maxima (S, A, T, depth), list counts
-    __shared__ uint32_t psum[6][16], pmax[4][16], pcnt[6][16];
+    __shared__ uint32_t psum[7][16], pmax[4][16], pcnt[6][16];
     uint32_t gS = 0, gA = 0, gT = 0, h = 0, n = 0, conv = 0;
     bool sit = false; // the block's small groups sit this round out (below)
     if (valid) {
@@ -2073,11 +2080,13 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
         bt.c_nolist[b] = 0;
     }
     const uint32_t gTl = sit ? 0u : gT; // what this round's small-group kernels see
+    // round 0: the records of the big lists that mid_sort orders in LDS (bwt_msd.h) instead of the global passes
+    const uint32_t gAm = (valid && round == 0 && mid_on && ms_block_is_mid(bt.ms_np, bt.ms_cnt + MS_CNT_WORDS + (size_t)(MS_LEVELS + 2) * B, b)) ? gA : 0u;
     { // (every sum stays below 2^30: at most 1024 blocks of fewer than 2^20 suffixes)
-        const uint32_t v[6] = {gS + gA + gT, gS, gA, n, conv, sit ? gT : 0u};
+        const uint32_t v[7] = {gS + gA + gT, gS, gA, n, conv, sit ? gT : 0u, gAm};
         const uint32_t m[4] = {gS, gA, gT, (gS | gA | gT) ? h : 0u};
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
+        for (int k = 0; k < 7; k++) {
             const uint32_t r = wave_reduce_add(v[k]);
             if (lane == 0) psum[k][wave] = r;
         }
@@ -2090,10 +2099,10 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
         }
     }
     __syncthreads();
-    uint32_t sum[6] = {0, 0, 0, 0, 0, 0}, mx[4] = {0, 0, 0, 0};
+    uint32_t sum[7] = {0, 0, 0, 0, 0, 0, 0}, mx[4] = {0, 0, 0, 0};
     for (uint32_t w = 0; w < nw; w++) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) sum[k] += psum[k][w];
+        for (int k = 0; k < 7; k++) sum[k] += psum[k][w];
 #pragma unroll
         for (int k = 0; k < 4; k++) mx[k] = max(mx[k], pmax[k][w]);
     }
@@ -2133,7 +2142,7 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
         const unsigned long long asum = *bt.stat_A + sum[0] + ((round == 0 && r0_fused) ? (unsigned long long)bt.ms_cnt[6] - sum[5] : 0ull);
         const uint32_t words[SUMMARY_WORDS] = {round,  tot[L_S], tot[L_A], tot[L_T], tot[L_Q], mx[0],  mx[1], mx[2], sum[0], sum[5],
                                                sum[1], bt.gwide[round & 1u], sum[2],   (round == 0 && r0_fused) ? bt.ms_cnt[6] : 0u, *bt.errflag, mx[3], sum[4], (uint32_t)asum,
-                                               (uint32_t)(asum >> 32), 0u};
+                                               (uint32_t)(asum >> 32), sum[6], 0u, 0u, 0u, 0u};
         uint32_t mine = 0;
 #pragma unroll
         for (int k = 0; k < SUMMARY_WORDS - 1; k++) mine = lane == (uint32_t)k ? words[k] : mine;
@@ -2415,6 +2424,10 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     // chunk_finish takes the first doubling step of the small groups itself, keyed on the text (BZH_R0=0: A/B timing)
     static const bool r0_off = getenv("BZH_R0") && !strcmp(getenv("BZH_R0"), "0");
     const uint32_t r0_fused = (use_msd && !r0_off) ? 1u : 0u;
+    // round 0 orders the large groups of a bucket-first block unit by unit in LDS (mid_sort; BZH_MID=0: the global passes, A/B timing)
+    static const bool mid_off = getenv("BZH_MID") && !strcmp(getenv("BZH_MID"), "0");
+    const bool mid_on = use_msd && !mid_off;
+    bool msd_deeper = false; // the levels behind the first ran: a block may hold a group that spans several units
     uint32_t nOld = B;
     Lst oldl = all;
     u64 *const binned = reinterpret_cast<u64 *>(bt.binned);
@@ -2422,7 +2435,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     const uint32_t epoch = (++ctx->bwt_epoch & 0xFFFFFFu) << 6;
     Msd msd_keep{};
     if (use_msd) { // (its counters, rank-window cursors and bigram counts join the one clearing launch)
-        clr.add(bt.ms_cnt, (MS_CNT_WORDS + (size_t)(MS_LEVELS + 2) * B) * sizeof(uint32_t));
+        clr.add(bt.ms_cnt, (MS_CNT_WORDS + (size_t)(MS_LEVELS + 6) * B) * sizeof(uint32_t)); // (the counters; the tables of runs and tiles behind them are written before they are read)
         clr.add(bt.ms_bincur, (size_t)B * 256 * sizeof(uint32_t));
         clr.add(bt.ms_bgcur, (size_t)B * MS_BG * sizeof(uint32_t));
     } else {
@@ -2531,7 +2544,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             hipEventRecord(ctx->side_ev[1], side);
         }
         if (use_msd) { // the rest of the bucket-first sort: deeper levels if level 1 left any, the finishing kernel
-            BZH_TRY(msd_sort_finish(ctx, st, msd_keep, ntotal, hrec0 + (size_t)MAX_ROUNDS * SUMMARY_WORDS, epoch + 63u));
+            BZH_TRY(msd_sort_finish(ctx, st, msd_keep, ntotal, hrec0 + (size_t)MAX_ROUNDS * SUMMARY_WORDS, epoch + 63u, &msd_deeper));
         if (getenv("BZH_TRACE_ROUNDS")) { // (debugging aid: waits for the device)
             uint32_t c[MS_CNT_WORDS];
             if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(c, bt.ms_cnt, sizeof c, hipMemcpyDeviceToHost) == hipSuccess)
@@ -2665,7 +2678,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         bzh_set_error(ctx, "%s:%d waiting for a round summary -> %s", __FILE__, __LINE__, hipGetErrorString(e));
         return BZH_E_HIP;
     };
-    auto run_A = [&]() {
+    auto run_A = [&](uint32_t round) {
         const uint32_t gt = (maxA + SORT_TILE - 1) / SORT_TILE;
         if (!nA || !gt) return;
         hipStream_t sa = st;
@@ -2680,6 +2693,24 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         a.src = cur;
         a.dst = oth;
         a.T = gt | (few_blocks(nA) ? WG_SPREAD : 0u);
+        // Round 0 of the bucket-first blocks: their big lists are ordered run by run in LDS, in place (the sorted list is
+        // wanted in `cur` either way); the global passes below then skip them, and are not even launched when no block can
+        // need them (none on the 8 passes, no group that spans several units: only level 5 of the initial sort makes those)
+        const bool mid = round == 0 && mid_on;
+        if (mid) {
+            KSpan ks(ctx, K_MID_SORT, 0);
+            MidArgs ma{cur, bt.rank, bt.st_h, bt.gateA, bt.gidof, a.gwide, a.tag, ms_tiles(msd_keep, 0), ms_mid_tiles(msd_keep, 0), ms_spans(msd_keep, 0), bt.ms_np,
+                       bt.n, ms_mid_ticket(msd_keep, 0), bt.errflag, bt.S, B, getenv("BZH_MID_DBG") ? (uint32_t)atoi(getenv("BZH_MID_DBG")) : 0u};
+            mid_sort<<<dim3(512), MS_THREADS, 0, sa>>>(ma);
+        }
+        const bool global_path = !mid || nOld || msd_deeper;
+        a.mid_np = mid ? bt.ms_np : nullptr;
+        a.mid_spans = mid ? bt.ms_cnt + MS_CNT_WORDS + (size_t)(MS_LEVELS + 2) * B : nullptr;
+        if (mid && side) { // the few blocks left to the global passes run them on the main stream, beside mid_sort
+            sa = st;
+            ctx->stream = st;
+        }
+        if (global_path) {
         // A large group has more than TAIL_G members (and a group that spans several units of the initial sort draws one
         // number a unit: at most two more per 8192 records), so a list of at most 250,000 records cannot run out of
         // GID_MAX numbers: the fifth pass is then not even launched.
@@ -2713,6 +2744,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         }
         a.has_n = 0u;
         span_end(ctx, e0);
+        } // (global_path)
+        a.mid_np = a.mid_spans = nullptr;
         if (side) {
             ctx->stream = st;
             hipEventRecord(ctx->side_ev[1], side);
@@ -2735,18 +2768,19 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     };
     auto account = [&](const uint32_t *sm) { // statistics of the round a summary describes
         if (!ctx->profiling) return;
-        const uint64_t tot = (uint64_t)sm[8], eS = (uint64_t)sm[10], eA = (uint64_t)sm[12];
+        const uint64_t tot = (uint64_t)sm[8], eS = (uint64_t)sm[10], eAm = (uint64_t)sm[19], eA = (uint64_t)sm[12] - eAm; // (eAm: mid_sort's records, round 0)
         if (sm[2]) { // the big lists of this round: four passes on group numbers, five on ranks (word 11)
             const uint64_t passes = sm[11] ? 5u : 4u;
             ctx->stats.bwt_sort_elems += passes * eA;
             ctx->k_bytes[K_RADIX_ROUNDS] += eA * passes * 16;
         }
+        ctx->k_bytes[K_MID_SORT] += eAm * 20; // record in, ordered record out, one rank gather
         if (sm[1]) ctx->stats.bwt_sort_elems += 3 * eS;
         // algorithmic bytes of the round's kernels (per-element figures: DESIGN.md section 4)
         ctx->k_bytes[K_SWEEP] += eS * (3 * 16 + 12 + 20);           // enumeration + gather, 3 passes, flags + refine
         ctx->k_bytes[K_ACTIVE_GEN] += eA * 20;                      // record in, re-keyed record out, one rank gather
-        ctx->k_bytes[K_REFINE_ROUNDS] += eA * 20;                   // record in, rank word, list record out
-        ctx->k_bytes[K_TAIL_ROUND] += (tot - eS - eA - sm[9]) * 24; // record in, key gather, rank word, survivor out (not the groups that sit the round out)
+        ctx->k_bytes[K_REFINE_ROUNDS] += (eA + eAm) * 20;           // record in, rank word, list record out
+        ctx->k_bytes[K_TAIL_ROUND] += (tot - eS - eA - eAm - sm[9]) * 24; // record in, key gather, rank word, survivor out (not the groups that sit the round out)
         if (sm[0] == 0) ctx->k_bytes[nOld == B ? K_REFINE_INIT : K_MSD_FINISH] += tot * 8 + (uint64_t)sm[13] * 8; // the list records the initial refinement wrote + the 8 text bytes each member of a small group was keyed on
     };
 
@@ -2761,7 +2795,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         KSpan ks(ctx, K_ROUND_BEGIN, 0);
         round_begin<<<1, (B + 63u) / 64u * 64u, 0, st>>>(bt, B, round, actP,
                                                           const_cast<uint32_t *>(hsum) + (size_t)round * SUMMARY_WORDS, epoch + round + 1u,
-                                                          sweep_div, r0_fused);
+                                                          sweep_div, r0_fused, mid_on ? 1u : 0u);
         }
         if (round > 1) {
             // the summary of the PREVIOUS round: where every block stood when that round began
@@ -2794,7 +2828,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             // Nothing is known yet, and text-like batches have no block in SWEEP mode: the big-list and small-group
             // paths go first with full-size launches (they take a millisecond), by then round 0's own summary is
             // there and the SWEEP path runs with exact sizes -- or, mostly, not at all.
-            run_A();
+            run_A(0);
             if (!(r0_fused && nOld == 0)) run_T(); // (every block on the bucket-first sort: all small groups sit round 0 out -- not even an empty launch)
             if (const hipError_t we = wait_summary(0, s); we != hipSuccess) return fail_wait(we);
             const uint64_t total = (uint64_t)s[8];
@@ -2842,7 +2876,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             continue;
         }
         run_S(round);
-        run_A();
+        run_A(round);
         run_T();
         join_side();
         // -- every block that went through radix passes: flags, group extents, ranks, routing (SWEEP-mode blocks in

@@ -41,6 +41,9 @@ struct Msd {
     u64 *big, *tail, *binned;
     uint32_t *c_big, *c_small, *c_groups;
     uint32_t *err;
+    uint32_t midcap;     // records a tile of mid_sort holds at most (mid_plan; a longer run is a tile of its own)
+    uint32_t *runq;      // ms_runq(m, 0): records | runs << 20 of every block's big list
+    uint2 *runs;         // ms_runs(m, 0): where the units' large-group records stand in the big lists (chunk_finish -> mid_plan)
     GidOut gout;         // numbers for the large groups (bwt.hip: round 0 sorts its big lists on them)
     uint32_t force_old;  // every block keeps the 8-pass path (BZH_INIT=lsd)
     uint32_t force_new;  // no block is kept off the buckets for its share of oversized ones (BZH_INIT=msd)
@@ -272,8 +275,24 @@ __device__ __forceinline__ void ms_push_seg(const Msd &m, uint32_t L, uint32_t b
 
 // The units of a block form a list of their own (row 0 of the per-block counters: its length, row MS_LEVELS + 1: the
 // tickets chunk_finish hands out over it): the finishing kernel works through a block's units on ONE XCD.
-__device__ __forceinline__ uint32_t *ms_unit_count(const Msd &m, uint32_t b) { return m.cnt + MS_CNT_WORDS + b; }
+__host__ __device__ __forceinline__ uint32_t *ms_unit_count(const Msd &m, uint32_t b) { return m.cnt + MS_CNT_WORDS + b; }
 __device__ __forceinline__ uint32_t *ms_unit_ticket(const Msd &m, uint32_t b) { return m.cnt + MS_CNT_WORDS + (size_t)(MS_LEVELS + 1) * m.B + b; }
+// (row MS_LEVELS + 2: the block holds a group that spans several units -- more than MS_TILE rotations share 7 bytes; row
+// MS_LEVELS + 3: the tickets of mid_sort, which goes through the same units once more)
+__host__ __device__ __forceinline__ uint32_t *ms_spans(const Msd &m, uint32_t b) { return m.cnt + MS_CNT_WORDS + (size_t)(MS_LEVELS + 2) * m.B + b; }
+__host__ __device__ __forceinline__ uint32_t *ms_mid_ticket(const Msd &m, uint32_t b) { return m.cnt + MS_CNT_WORDS + (size_t)(MS_LEVELS + 3) * m.B + b; }
+__host__ __device__ __forceinline__ uint32_t *ms_mid_tiles(const Msd &m, uint32_t b) { return m.cnt + MS_CNT_WORDS + (size_t)(MS_LEVELS + 4) * m.B + b; }
+// (per block: records of the big list so far | runs so far << 20 -- one atomic add gives a unit's run its place in the list
+// AND its number in the order of the list, so the table of runs needs no sorting.  A block has fewer than 2^20 rotations and at
+// most MS_UNIT_CAP = 4096 units: the 4096th run wraps the upper field to 0, which only the reader of the final value sees --
+// "records but no runs" reads as 4096 runs)
+__host__ __device__ __forceinline__ uint32_t *ms_runq(const Msd &m, uint32_t b) { return m.cnt + MS_CNT_WORDS + (size_t)(MS_LEVELS + 5) * m.B + b; }
+// the runs of a block's big list in list order, (first record, records) each, and the tiles mid_plan packs them into
+__host__ __device__ __forceinline__ uint2 *ms_runs(const Msd &m, uint32_t b)
+{
+    return reinterpret_cast<uint2 *>(m.cnt + ((MS_CNT_WORDS + (size_t)(MS_LEVELS + 6) * m.B + 1) & ~(size_t)1)) + (size_t)b * MS_UNIT_CAP;
+}
+__host__ __device__ __forceinline__ uint2 *ms_tiles(const Msd &m, uint32_t b) { return ms_runs(m, 0) + ((size_t)m.B + b) * MS_UNIT_CAP; }
 __device__ __forceinline__ void ms_push_unit(const Msd &m, uint4 u)
 {
     const uint32_t b = u.x & 1023u;
@@ -653,6 +672,7 @@ __global__ void __launch_bounds__(256) seg_plan(Msd m, uint32_t L, uint32_t *hre
             } else if (L < MS_LEVELS) {
                 ms_push_seg(m, L + 1, b, us, ue);
             } else { // bytes 0..6 all equal: ONE group, in tiles
+                *ms_spans(m, b) = 1u; // (mid_sort orders whole groups inside one unit's records: not this block's)
                 for (uint32_t q = us; q < ue; q += MS_TILE) ms_push_unit(m, ms_unit(b, L & 1u, 1u, 0u, q, min(ue, q + (uint32_t)MS_TILE), us));
             }
         }
@@ -783,7 +803,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
     __shared__ uint32_t wc[128];     // per row of the sorted order: surviving small-group records | large-group records << 16
     __shared__ uint32_t ls[MS_NW + 2], lsv[MS_NW];
     __shared__ u64 s_wo[MS_NW], s_wa[MS_NW]; // per wavefront: OR / AND of its elements
-    __shared__ uint32_t s_unit, s_offS, s_offB;
+    __shared__ uint32_t s_unit, s_offS, s_offB, s_totB;
     uint32_t *const bh = reinterpret_cast<uint32_t *>(&cur[0][0][0]); // 4 x 256 words: counts, local starts, cursors, offsets
     uint32_t *const bl = bh + 256, *const bcur = bh + 512, *const bgo = bh + 768;
     // (timing experiments, BZH_MSD_DBG & 16: cycles per phase, summed over all units, to cnt[32 ..]; the last reading lives in
@@ -1179,14 +1199,15 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
         __syncthreads(); // the keys have been read: the stage is free
         if (!fuse && tid < 256 && bh[tid]) pendG = atomicAdd(&m.bincur[(size_t)b * 256 + tid], bh[tid]);
         MS_T(7);
-        uint32_t pendS = 0, pendB = 0;
+        uint32_t pendS = 0, pendB = 0; // (pendB: first record | number of the run << 20)
         if (tid == 0) { // (a unit holds at most 8192 records: 16 bits each)
             uint32_t t2 = 0;
 #pragma unroll
             for (int w = 0; w < MS_NW; w++) t2 += lsv[w];
             const uint32_t totS = t2 & 0xFFFFu, totB = t2 >> 16;
             pendS = totS ? atomicAdd(&m.c_small[b], totS) : 0u;
-            pendB = totB ? atomicAdd(&m.c_big[b], totB) : 0u;
+            pendB = totB ? atomicAdd(&m.runq[b], (1u << 20) | totB) : 0u; // (mid_plan leaves the list's length where round_begin looks for it)
+            s_totB = totB;
         }
         // ---- (rank word, suffix) pairs in bin order in LDS, then out as runs
         if (tid < 256) {
@@ -1228,9 +1249,13 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
         }
         if (tid == 0) {
             s_offS = pendS;
-            s_offB = pendB;
+            s_offB = pendB; // (first record | number of the run << 20)
         }
         __syncthreads();
+        // where the unit's large-group records stand in the block's big list: mid_sort (bwt.hip, round 0) orders the list run
+        // by run -- every group is whole inside its unit's run.  (Everything from LDS, by a thread of its own: no register of
+        // the unit's long phases is held for it.)
+        if (tid == MS_THREADS - 1 && s_totB) m.runs[(size_t)s_blk * MS_UNIT_CAP + (s_offB >> 20)] = make_uint2(s_offB & 0xFFFFFu, s_totB);
         if (tid < s_ng) gid_assign(m.gout, b, s_gbase + tid, glist[tid]);
         {
             u64 o[MS_ITEMS];
@@ -1248,7 +1273,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
             const uint32_t inc = wave_incl_add(c0 + c1, ms_opaque(lane));
             const uint32_t ex0 = inc - c0 - c1, ex1 = inc - c1;
             u64 *ts = m.tail + (size_t)b * m.S + s_offS;
-            u64 *bs = m.big + (size_t)b * m.S + s_offB;
+            u64 *bs = m.big + (size_t)b * m.S + (s_offB & 0xFFFFFu);
 #pragma unroll
             for (int k = 0; k < MS_ITEMS; k++) {
                 const int row = k * MS_NW + wave;
@@ -1264,6 +1289,297 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
         __syncthreads(); // the stage, the bins and s_unit are reused by the next unit
     }
 #undef MS_T
+}
+
+// ---- round 0 of the large groups, unit by unit ---------------------------------------------------------------------------
+// What chunk_finish leaves in a block's big list are runs of records, one run per unit, and a group is whole inside its
+// unit's run (units are whole buckets; a block with a group that spans several units -- ms_spans -- is not touched here and
+// takes the global passes).  Ordering a run by (group, key2 = rank[i + h]) is therefore all round 0's big-list path has to
+// do for such a block before refine_one: this kernel does it in LDS -- one workgroup per tile of runs (mid_plan), the records gathered and
+// keyed once, four counting passes of 7 bits (20 bits of key2, then the group's index inside the run: a large group has
+// more than TAIL_G members, so a run holds fewer than 128), written back in place in the form refine_one expects -- instead of
+// active_gen + four (five) global radix passes over every record (8 + 4 x 16 bytes a record through HBM, and the round's
+// critical path: round 0 has no small-group kernel to hide behind once chunk_finish takes their first step).
+// Tiles are taken block by block on the block's XCD, as chunk_finish takes its units (the rank gathers stay inside one L2).
+// One workgroup per bucket-first block, behind chunk_finish: the length of the block's big list where round_begin looks for it,
+// and the runs of that list (in list order: ms_runq) packed greedily into tiles of at most MS_TILE records -- a tile is a
+// stretch of the list made of whole runs, i.e. of whole groups, and mid_sort orders a tile at a time (a unit's run alone
+// averages 1,200 records on text: seven times the workgroup rounds, each with its chain of dependent loads).
+__global__ void __launch_bounds__(256) mid_plan(Msd m)
+{
+    const uint32_t b = blockIdx.x;
+    if (b >= m.B || m.np[b] == 0u) return; // (a block on the 8 passes: refine_one<init> writes its lists)
+    __shared__ uint2 R[MS_UNIT_CAP];
+    const uint32_t q = m.runq[b], recs = q & 0xFFFFFu;
+    uint32_t runs = q >> 20;
+    if (recs && !runs) runs = MS_UNIT_CAP; // (the 4096th run wrapped the field)
+    const uint2 *rt = m.runs + (size_t)b * MS_UNIT_CAP;
+    for (uint32_t k = threadIdx.x; k < runs; k += 256) R[k] = rt[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m.c_big[b] = recs;
+        uint2 *tt = m.runs + ((size_t)m.B + b) * MS_UNIT_CAP; // (ms_tiles)
+        uint32_t nt = 0, ts = 0, tl = 0;
+        bool bad = false;
+        for (uint32_t k = 0; k < runs; k++) {
+            const uint2 r = R[k];
+            bad |= r.x != ts + tl || r.y == 0u || r.y > (uint32_t)MS_TILE; // (runs follow one another in the list)
+            if (tl && tl + r.y > m.midcap) {
+                tt[nt++] = make_uint2(ts, tl);
+                ts = r.x;
+                tl = 0;
+            }
+            tl += r.y;
+        }
+        if (tl) tt[nt++] = make_uint2(ts, tl);
+        if (bad || ts + tl != recs) atomicOr(m.err, ERR_MSD);
+        *ms_mid_tiles(m, b) = nt;
+    }
+}
+
+struct MidArgs {
+    u64 *list;             // [B][S] the big lists, ordered in place
+    const uint32_t *rank;  // [B][S]
+    const uint32_t *hb;    // [B] depth of the block's round
+    const uint32_t *len;   // [B] records in the block's big list (gateA)
+    const uint16_t *gidof; // [B][S] rank -> number of a numbered group
+    const uint32_t *gwide; // this round's word: 0 = the sorted list carries group numbers (refine_one reads it the same way)
+    uint32_t tag;          // this round's id in the rank words
+    // of the initial sort's state (Msd): the tiles of the big lists and their number per block (mid_plan), this kernel's
+    // tickets, "a group spans several units", "took the bucket-first sort", block sizes
+    const uint2 *tiles;
+    const uint32_t *ucount, *spans, *np, *n;
+    uint32_t *ticket, *err;
+    uint32_t S, B;
+    uint32_t dbg;          // timing experiments only (BZH_MID_DBG: 1 = no counting passes, 2 = no rank gather, 4 = no stores; wrong results)
+};
+
+__global__ void __launch_bounds__(MS_THREADS, 4) mid_sort(MidArgs a)
+{
+    __shared__ u64 stage[MS_SLOTS];
+    __shared__ MsCnt cur[2];
+    __shared__ u64 HM[128];          // group heads by load position (bit per slot)
+    __shared__ uint32_t rowpre[128]; // group heads before a row
+    __shared__ uint32_t G[128];      // group index inside the run -> what the record carries in its place (number or rank)
+    __shared__ uint32_t ls[MS_NW + 2];
+    __shared__ u64 s_wo[MS_NW], s_wa[MS_NW];
+    __shared__ uint32_t s_blk, s_unit, s_next;
+    const uint32_t NOBLK = 0xFFFFFFFFu;
+    const uint32_t *spans = a.spans;
+    uint32_t cur_blk = blockIdx.x & 7u;
+    bool own = true;
+    uint32_t cur_cnt = 0;
+    if (cur_blk >= a.B) {
+        own = false;
+        cur_blk = NOBLK;
+    } else {
+        cur_cnt = ms_block_is_mid(a.np, spans, cur_blk) ? min(a.ucount[cur_blk], MS_UNIT_CAP) : 0u;
+    }
+    if (threadIdx.x == 0 && cur_blk != NOBLK) s_next = cur_cnt ? atomicAdd(a.ticket + cur_blk, 1u) : 0u;
+    const bool narrow = *a.gwide == 0u;
+    uint32_t tid = threadIdx.x;
+    for (;;) {
+        asm volatile("" : "+v"(tid)); // (opaque once per unit: what depends on it alone is not kept across the loop -- see chunk_finish)
+        const int lane = (int)(tid & 63u), wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+        if (wave == 0) { // which unit next (chunk_finish's scheme: my XCD's blocks in turn, then whichever block has the most left)
+            uint32_t bq = cur_blk, t = s_next;
+            for (uint32_t tries = 0;; tries++) {
+                if (bq != NOBLK && t < cur_cnt) break;
+                if (own && bq != NOBLK && bq + 8u < a.B) {
+                    bq += 8u;
+                } else {
+                    own = false;
+                    uint32_t best = 0, bb = NOBLK;
+                    for (uint32_t b0 = 0; b0 < a.B; b0 += 64) {
+                        const uint32_t bx = b0 + (uint32_t)lane;
+                        uint32_t left = 0;
+                        if (bx < a.B && ms_block_is_mid(a.np, spans, bx)) {
+                            const uint32_t c = min(a.ucount[bx], MS_UNIT_CAP);
+                            const uint32_t k = __hip_atomic_load(a.ticket + bx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            left = c > k ? c - k : 0u;
+                        }
+                        const uint32_t mx = wave_all_max(left);
+                        if (mx > best) {
+                            best = mx;
+                            const u64 who = __ballot(left == mx);
+                            bb = b0 + (uint32_t)__ffsll((long long)who) - 1u;
+                        }
+                    }
+                    bq = bb;
+                    if (bq == NOBLK || tries > 4096u) {
+                        bq = NOBLK;
+                        break;
+                    }
+                }
+                cur_cnt = ms_block_is_mid(a.np, spans, bq) ? min(a.ucount[bq], MS_UNIT_CAP) : 0u;
+                uint32_t tt = 0;
+                if (lane == 0 && cur_cnt) tt = atomicAdd(a.ticket + bq, 1u);
+                t = (uint32_t)__builtin_amdgcn_readfirstlane((int)tt);
+            }
+            cur_blk = bq;
+            if (lane == 0) {
+                s_blk = bq;
+                s_unit = t;
+            }
+        }
+        __syncthreads();
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_blk), u = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_unit);
+        if (b == NOBLK) break;
+        cur_blk = b;
+        uint32_t pend_ticket = 0;
+        if (tid == 0) pend_ticket = atomicAdd(a.ticket + b, 1u); // (consumed at the end of the unit)
+        const uint2 ud = a.tiles[(size_t)b * MS_UNIT_CAP + u];
+        const uint32_t start = ud.x, len = ud.y;
+        const uint32_t blen = a.len[b];
+        if (len > (uint32_t)MS_TILE || start + len > blen) { // (not what mid_plan writes)
+            if (tid == 0) {
+                atomicOr(a.err, ERR_MSD);
+                s_next = pend_ticket;
+            }
+            __syncthreads();
+            continue;
+        }
+        if (len == 0) { // (never written)
+            if (tid == 0) s_next = pend_ticket;
+            __syncthreads();
+            continue;
+        }
+        const uint32_t n = a.n[b], h = a.hb[b];
+        u64 *recs = a.list + (size_t)b * a.S + start;
+        const uint32_t *rank = a.rank + (size_t)b * a.S;
+        const int R = (int)((len + 511u) / 512u);
+        const uint32_t Lw = (uint32_t)R * 64u;
+        if (tid < 128) HM[tid] = 0ull;
+        ms_clear(cur[0], tid);
+        __syncthreads();
+        // ---- load (slot p = wave * Lw + k * 64 + lane), key2, group heads
+        u64 x[MS_ITEMS];
+        uint32_t actmask = 0;
+#pragma unroll
+        for (int k = 0; k < MS_ITEMS; k++) {
+            const uint32_t p = (uint32_t)wave * Lw + (uint32_t)k * 64u + (uint32_t)lane;
+            const bool act = k < R && p < len;
+            actmask |= (act ? 1u : 0u) << k;
+            x[k] = recs[act ? p : 0u];
+        }
+        // (the record before my wavefront's first slot: the head test of that slot compares with it -- requested with the rest)
+        u64 xprev = 0ull;
+        if (lane == 0 && wave > 0 && (uint32_t)wave * Lw < len) xprev = recs[(uint32_t)wave * Lw - 1u];
+        uint32_t k2[MS_ITEMS];
+#pragma unroll
+        for (int k = 0; k < MS_ITEMS; k++) {
+            k2[k] = 0;
+            if ((actmask >> k) & 1u) {
+                const uint32_t i = (uint32_t)(x[k] & SUF_MASK);
+                if (h < n) {
+                    uint32_t i2 = i + h;
+                    if (i2 >= n) i2 -= n;
+                    k2[k] = (a.dbg & 2u) ? i2 * 2654435761u >> 12 : rank[rslot(i2)];
+                } else {
+                    k2[k] = n - 1u - i; // identical rotations: larger index first -- a plain rank, no tag
+                }
+            }
+        }
+        {
+            uint32_t last = (uint32_t)(xprev >> 40) & 0xFFFFFu; // (lane 0: the rank in the slot before the row)
+#pragma unroll
+            for (int k = 0; k < MS_ITEMS; k++) {
+                if (k < R) {
+                    const uint32_t p = (uint32_t)wave * Lw + (uint32_t)k * 64u + (uint32_t)lane;
+                    const bool act = (actmask >> k) & 1u;
+                    const uint32_t r = (uint32_t)(x[k] >> 40) & 0xFFFFFu;
+                    uint32_t pr = (uint32_t)__shfl_up((int)r, 1, 64);
+                    if (lane == 0) pr = last;
+                    const bool head = act && (p == 0u || pr != r);
+                    const u64 hm = __ballot(head);
+                    if (lane == 0) HM[wave * R + k] = hm;
+                    last = (uint32_t)__shfl((int)r, 63, 64);
+                }
+            }
+        }
+        __syncthreads();
+        if (wave == 0) { // group heads before every row of 64 slots
+            const uint32_t p0 = (uint32_t)__popcll(HM[2 * lane]), p1 = (uint32_t)__popcll(HM[2 * lane + 1]);
+            const uint32_t inc = wave_incl_add(p0 + p1, lane);
+            rowpre[2 * lane] = inc - p0 - p1;
+            rowpre[2 * lane + 1] = inc - p1;
+            if (lane == 63) ls[MS_NW + 1] = inc;
+        }
+        __syncthreads();
+        if (ls[MS_NW + 1] > 128u && tid == 0) atomicOr(a.err, ERR_MSD); // (a large group has more than TAIL_G members)
+        {
+            u64 o = 0ull, an = ~0ull;
+#pragma unroll
+            for (int k = 0; k < MS_ITEMS; k++) {
+                if ((actmask >> k) & 1u) {
+                    const uint32_t p = (uint32_t)wave * Lw + (uint32_t)k * 64u + (uint32_t)lane, row = p >> 6;
+                    const u64 hm = HM[row];
+                    const uint32_t gi = (rowpre[row] + (uint32_t)__popcll(hm & ((2ull << (p & 63u)) - 1ull)) - 1u) & 127u;
+                    const uint32_t r = (uint32_t)(x[k] >> 40) & 0xFFFFFu;
+                    if ((hm >> (p & 63u)) & 1ull) G[gi] = r;
+                    const uint32_t key = h < n ? rank_at(k2[k], a.tag) : k2[k];
+                    x[k] = ((u64)gi << 41) | ((u64)key << 20) | (x[k] & SUF_MASK);
+                    o |= x[k];
+                    an &= x[k];
+                }
+            }
+            o = ((u64)wave_all_or((uint32_t)(o >> 32)) << 32) | wave_all_or((uint32_t)o);
+            an = ((u64)wave_all_and((uint32_t)(an >> 32)) << 32) | wave_all_and((uint32_t)an);
+            if (lane == 0) {
+                s_wo[wave] = o;
+                s_wa[wave] = an;
+            }
+        }
+        if (tid == 0) s_next = pend_ticket;
+        __syncthreads();
+        // (a numbered group's record carries the number: one gather for all the tile's groups, consumed after the passes)
+        if (narrow && tid < min(ls[MS_NW + 1], 128u)) G[tid] = (uint32_t)a.gidof[(size_t)b * a.S + G[tid]];
+        u64 vary;
+        {
+            u64 o = 0ull, an = ~0ull;
+#pragma unroll
+            for (int w = 0; w < MS_NW; w++) {
+                o |= s_wo[w];
+                an &= s_wa[w];
+            }
+            vary = o & ~an;
+        }
+        {
+            uint32_t pos[MS_ITEMS / 2];
+            int par = 0;
+            bool staged = false;
+#pragma unroll 1
+            for (int pass = 0; pass < 4; pass++) {
+                const int sh = 20 + 7 * pass; // key2: bits 20..39 (+ bit 40, always 0); group index: bits 41..47
+                if (((vary >> sh) & 127ull) == 0ull || (a.dbg & 1u)) continue;
+                tile_rank<7>(x, sh, actmask, R, cur[par], cur[par ^ 1], ls, pos, tid);
+                par ^= 1;
+#pragma unroll
+                for (int k = 0; k < MS_ITEMS; k++)
+                    if ((actmask >> k) & 1u) stage[ms_slot((pos[k >> 1] >> (16 * (k & 1))) & 0xFFFFu)] = x[k];
+                __syncthreads();
+                staged = true;
+                bool again = false;
+                for (int q = pass + 1; q < 4; q++) again |= ((vary >> (20 + 7 * q)) & 127ull) != 0ull;
+                if (again) {
+#pragma unroll
+                    for (int k = 0; k < MS_ITEMS; k++) x[k] = stage[ms_slot(((uint32_t)wave * Lw + (uint32_t)k * 64u + (uint32_t)lane) & 8191u)];
+                }
+            }
+            if (!staged) {
+#pragma unroll
+                for (int k = 0; k < MS_ITEMS; k++)
+                    if ((actmask >> k) & 1u) stage[ms_slot((uint32_t)wave * Lw + (uint32_t)k * 64u + (uint32_t)lane)] = x[k];
+                __syncthreads();
+            }
+        }
+        // ---- out, in place: [number or rank : 20 @40][key2 : 20 @20][suffix : 20]
+        for (uint32_t q = tid; q < len && !(a.dbg & 4u); q += MS_THREADS) {
+            const u64 y = stage[ms_slot(q)];
+            recs[q] = ((u64)G[(uint32_t)(y >> 41) & 127u] << 40) | (y & 0xFFFFFFFFFFull);
+        }
+        __syncthreads(); // the stage, G and s_unit are reused by the next unit
+    }
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
@@ -1308,6 +1624,9 @@ static int msd_sort_begin(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntot
     m.c_groups = bt.c_groups;
     m.err = bt.errflag;
     m.gout = GidOut{bt.gidof, bt.grank, bt.gcount, bt.gwide, bt.S, bt.B, 0u};
+    m.runs = ms_runs(m, 0);
+    m.runq = ms_runq(m, 0);
+    m.midcap = getenv("BZH_MID_CAP") ? std::min<uint32_t>(MS_TILE, std::max(1, atoi(getenv("BZH_MID_CAP")))) : (uint32_t)MS_TILE;
     m.force_old = force_old ? 1u : 0u;
     m.fuse = fuse;
     {
@@ -1360,8 +1679,9 @@ static int msd_sort_begin(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntot
     return BZH_OK;
 }
 
-static int msd_sort_finish(bzh_ctx *ctx, hipStream_t st, const Msd &m, uint64_t ntotal, volatile uint32_t *hrec, uint32_t seq)
+static int msd_sort_finish(bzh_ctx *ctx, hipStream_t st, const Msd &m, uint64_t ntotal, volatile uint32_t *hrec, uint32_t seq, bool *deeper_out)
 {
+    *deeper_out = false;
     if (m.force_old) return BZH_OK;
     {
         KSpan ks(ctx, K_MSD_LEVELS, 0, 3 * (MS_LEVELS - 1));
@@ -1379,6 +1699,7 @@ static int msd_sort_finish(bzh_ctx *ctx, hipStream_t st, const Msd &m, uint64_t 
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         const uint32_t deeper = hrec[4];
+        *deeper_out = deeper != 0u; // (only level 5 makes units out of a group that spans several: without the deeper levels no block has one)
         for (uint32_t L = 2; L <= MS_LEVELS && deeper; L++) {
             seg_count<<<dim3(1024), MS_THREADS, 0, st>>>(m, L);
             seg_plan<<<dim3(256), 256, 0, st>>>(m, L);
@@ -1388,6 +1709,7 @@ static int msd_sort_finish(bzh_ctx *ctx, hipStream_t st, const Msd &m, uint64_t 
     {
         KSpan ks(ctx, K_MSD_FINISH, 16 * ntotal);
         chunk_finish<<<dim3(512), MS_THREADS, 0, st>>>(m);
+        mid_plan<<<dim3(m.B), 256, 0, st>>>(m);
     }
     HIP_TRY(ctx, hipGetLastError());
     return BZH_OK;

@@ -53,7 +53,7 @@ constexpr int SORT_ITEMS = 16;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS; // 8192 elements per workgroup (512 x 16: halves the look-back /
                                                      // scan overhead per element against 256 x 16, -7 % on the bench)
 constexpr uint32_t RANK_RESOLVED = 0x80000000u;      // suffix is alone in its group
-constexpr int SUMMARY_WORDS = 20; // round summary: see round_begin (bwt.hip)
+constexpr int SUMMARY_WORDS = 24; // round summary: see round_begin (bwt.hip)
 constexpr uint32_t GID_MAX = 4096;  // large groups of a block a round can number densely (12 key bits)
 constexpr int RS_ROWS = 22;       // per-block rows of the suffix sort's round state (layout_batch, api.hip)
 constexpr uint32_t MS_BG_ROW = 65552, MS_LEVELS = 5, MS_SEG_SLOTS = 112, MS_SEG_ROW = 264, MS_UNIT_CAP = 4096, MS_ITEM_CAP = 224,
@@ -131,7 +131,10 @@ struct Batch {
     uint4 *ms_units;     // [B * MS_UNIT_CAP] work list of the finishing kernel
     uint4 *ms_segs;      // [MS_LEVELS + 1][B * MS_SEG_SLOTS] oversized buckets per level
     uint32_t *ms_items;  // [MS_LEVELS + 1][B * MS_ITEM_CAP] (oversized bucket, tile) pairs per level
-    uint32_t *ms_cnt;    // [MS_CNT_WORDS + (MS_LEVELS + 2) * B] counters; behind them per block: units, slot counters of the levels, unit tickets
+    uint32_t *ms_cnt;    // [MS_CNT_WORDS + (MS_LEVELS + 6) * B] counters; behind the first MS_CNT_WORDS per block: units, slot counters
+                         // of the levels, unit tickets, "holds a group that spans several units", tickets and tile counts of
+                         // mid_sort, records | runs << 20 of the big list chunk_finish writes; then [2][B][MS_UNIT_CAP] x 2 words:
+                         // the runs of that list and the tiles mid_plan packs them into (bwt_msd.h)
     uint32_t *ms_np;     // [B] 1: the block takes the bucket-first path (its first doubling round has depth 7)
     uint32_t *ms_old, *ms_new; // [B] ids of the blocks on the 8-pass path / on the bucket-first path
     uint32_t *ms_bincur; // [B][256] rank binning: pairs already claimed in each 4096-suffix window
@@ -176,7 +179,7 @@ constexpr uint32_t FX_HDR_BYTES = 64 + 6 * 1152; // + up to 6 delta-coded tables
 enum KClass : int {
     K_PLAN = 0, K_CRC, K_RLE1_EMIT, K_BYTE_COUNT, K_RADIX_INIT, K_RADIX_GID, K_REFINE_INIT, K_RANK_APPLY,
     K_ROUND_BEGIN, K_SWEEP, K_ACTIVE_GEN, K_RADIX_ROUNDS, K_TAIL_ROUND, K_REFINE_ROUNDS, K_BWT_EMIT, K_MTF_LAST,
-    K_MTF_WALK, K_RLE2, K_HUFF, K_PACK, K_MSD_PLAN, K_MSD_SCATTER, K_MSD_LEVELS, K_MSD_FINISH, K_COUNT
+    K_MTF_WALK, K_RLE2, K_HUFF, K_PACK, K_MSD_PLAN, K_MSD_SCATTER, K_MSD_LEVELS, K_MSD_FINISH, K_MID_SORT, K_COUNT
 };
 static const char *const KCLASS_NAME[K_COUNT] = {
     "plan (granules, carries, split)", "crc_tiles", "rle1_emit", "byte_count", "radix_scatter (initial sort)",
@@ -184,7 +187,8 @@ static const char *const KCLASS_NAME[K_COUNT] = {
     "SWEEP path (3 passes + 3-kernel refine)", "active_gen", "radix_scatter (big-list rounds)", "tail_round",
     "refine_one (rounds)", "bwt_emit", "mtf_tile_last + mtf_prefix", "mtf_walk", "rle2 (tiles, block, emit)",
     "huffman (segments, build, header)", "pack_symbols", "bigram_hist + bigram_plan", "bigram_scatter (2-byte buckets)",
-    "seg_count/plan/scatter (oversized buckets)", "chunk_finish (bucket sort + ranks in LDS)"};
+    "seg_count/plan/scatter (oversized buckets)", "chunk_finish (bucket sort + ranks in LDS)",
+    "mid_sort (round 0: large groups in LDS)"};
 
 struct Timer {
     hipEvent_t a = nullptr, b = nullptr;
