@@ -157,7 +157,7 @@ static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
         carve(p, bt.ms_units, MB * MS_UNIT_CAP);
         carve(p, bt.ms_segs, (size_t)(MS_LEVELS + 1) * MB * MS_SEG_SLOTS);
         carve(p, bt.ms_items, (size_t)(MS_LEVELS + 1) * MB * MS_ITEM_CAP);
-        carve(p, bt.ms_cnt, MS_CNT_WORDS + (size_t)(MS_LEVELS + 6) * NB + 2 + 4 * NB * MS_UNIT_CAP);
+        carve(p, bt.ms_cnt, MS_CNT_WORDS + (size_t)(MS_LEVELS + 7) * NB + 2 + 6 * NB * MS_UNIT_CAP);
         carve(p, bt.ms_np, NB);
         carve(p, bt.ms_old, NB);
         carve(p, bt.ms_new, NB);
@@ -283,6 +283,12 @@ extern "C" void bzh_destroy(bzh_ctx *ctx)
         hipEventDestroy(c->side_ev[1]);
         hipStreamDestroy(c->side_stream);
         c->side_stream = nullptr;
+        if (c->side2_stream) {
+            hipStreamSynchronize(c->side2_stream);
+            hipEventDestroy(c->side_ev[2]);
+            hipStreamDestroy(c->side2_stream);
+            c->side2_stream = nullptr;
+        }
     };
     drop_side(ctx);
     for (bzh_ctx *l : ctx->lanes) drop_side(l);

@@ -91,6 +91,19 @@ struct Lst {
     uint32_t B;
 };
 
+// ---- the large groups of a bucket-first block, round by round (bwt_msd.h: mid_plan / mid_sort) --------------------------
+// Rows of per-block words behind the counters of the initial sort (Batch::ms_cnt) and, behind the rows, three tables of
+// MS_UNIT_CAP (first record, records) pairs per block: the RUNS of the big list a round's refinement (round 0: chunk_finish)
+// writes -- every writer claims its run's room with one atomic add on records | runs << 20, which also numbers the runs in
+// list order --, two halves by the parity of the round that READS the list, and the TILES mid_plan packs a list's runs into.
+constexpr uint32_t MSR_SPANS = MS_LEVELS + 2, MSR_MTICKET = MS_LEVELS + 3, MSR_MTILES = MS_LEVELS + 4, MSR_RUNQ = MS_LEVELS + 5; // (MSR_RUNQ: two rows)
+__host__ __device__ __forceinline__ uint32_t *msc_row(uint32_t *cnt, uint32_t B, uint32_t row) { return cnt + MS_CNT_WORDS + (size_t)row * B; }
+__host__ __device__ __forceinline__ uint2 *msc_runs(uint32_t *cnt, uint32_t B, uint32_t par)
+{
+    return reinterpret_cast<uint2 *>(cnt + ((MS_CNT_WORDS + (size_t)(MS_LEVELS + 7) * B + 1) & ~(size_t)1)) + (size_t)par * B * MS_UNIT_CAP;
+}
+__host__ __device__ __forceinline__ uint2 *msc_tiles(uint32_t *cnt, uint32_t B) { return msc_runs(cnt, B, 2); }
+
 struct SortArgs {
     const uint8_t *blk;   // [B][S]
     const uint32_t *n;    // [B]
@@ -776,6 +789,14 @@ struct RefineArgs {
     GidOut gout;           // numbers for the large groups this kernel writes (for the NEXT round's sort)
     const uint32_t *grank; // [B][GID_MAX] refine_one: the rank of every numbered group of THIS round
     const uint32_t *gwide; // [1] refine_one: 0 = the sorted list carries group numbers, not ranks (this round's word)
+    // refine_one, blocks whose big lists mid_sort orders (bwt_msd.h; mid_np null: none): the list is refined tile by tile of
+    // mid_plan's table -- whole groups, so no carries and no look-back --, the records carry ranks, and the large groups
+    // leave as ONE RUN per tile, claimed on the block's run counter of the next round (the next mid_plan packs those runs)
+    const uint32_t *mid_np, *mid_spans;
+    const uint2 *mid_tiles;      // [B][MS_UNIT_CAP]
+    const uint32_t *mid_ntiles;  // [B]
+    uint32_t *mid_runq;          // [B] records | runs << 20 of the list being written
+    uint2 *mid_runs;             // [B][MS_UNIT_CAP]
 };
 
 // LDS staging of one tile: coalesced global loads, then each thread owns 16 consecutive elements.
@@ -1218,12 +1239,25 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
 {
     uint32_t b, tile;
     if (!wg_map(a.T, a.lst, b, tile)) return;
-    const uint32_t cnt = a.cnt[b];
-    const uint32_t ntile = (cnt + SORT_TILE - 1) / SORT_TILE;
-    launch_check(a.T, a.lst, tile, ntile, a.err);
-    if (tile >= ntile) return;
+    uint32_t cnt = a.cnt[b];
     const size_t base = (size_t)b * a.S;
     const u64 *list = a.list + base;
+    // A block of mid_sort's: my tile is a tile of mid_plan's table, refined as a list of its own (it holds whole groups: what
+    // follows sees tile 0 of a list of `cnt` records that begins at the tile's first record)
+    const bool midb = !INIT && a.mid_np && ms_block_is_mid(a.mid_np, a.mid_spans, b);
+    if (midb) {
+        const uint32_t nt = a.mid_ntiles[b];
+        launch_check(a.T, a.lst, tile, nt, a.err);
+        if (tile >= nt) return;
+        const uint2 t = a.mid_tiles[(size_t)b * MS_UNIT_CAP + tile];
+        list += t.x;
+        cnt = t.y;
+        tile = 0;
+    } else {
+        const uint32_t ntile = (cnt + SORT_TILE - 1) / SORT_TILE;
+        launch_check(a.T, a.lst, tile, ntile, a.err);
+        if (tile >= ntile) return;
+    }
     const uint32_t tile0 = tile * SORT_TILE, tend = tile0 + SORT_TILE;
     constexpr int NW = SORT_THREADS / 64;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1292,9 +1326,10 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
     ex1[threadIdx.x] = td;
     int nxt = block_excl_min_rev(firstbd, l01); // barrier inside: ex0 / ex1 / s_hend visible
     if (wave == 0) {
-        int cgi, cdi;
-        carry_lookback(a.carry + (size_t)b * a.TPB * 2 + 1, tile, a.cpass, ex0[SORT_THREADS - 1], ex1[SORT_THREADS - 1], !INIT,
-                       cgi, cdi, a.err);
+        int cgi = -1, cdi = -1;
+        if (!midb)
+            carry_lookback(a.carry + (size_t)b * a.TPB * 2 + 1, tile, a.cpass, ex0[SORT_THREADS - 1], ex1[SORT_THREADS - 1], !INIT,
+                           cgi, cdi, a.err);
         if (lane == 0) {
             s_cg = cgi;
             s_cd = cdi;
@@ -1349,7 +1384,14 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
     const uint32_t offB = block_excl_add(nB, lsu, &totB);
     if (threadIdx.x == 0) {
         s_offS = (totS + nH) ? atomicAdd(&a.c_small[b], totS + nH) : 0u;
-        s_offB = totB ? atomicAdd(&a.c_big[b], totB) : 0u;
+        if (midb && totB) { // one run of whole groups: its room and its number in list order from ONE atomic add
+            const uint32_t q = atomicAdd(&a.mid_runq[b], (1u << 20) | totB);
+            s_offB = q & 0xFFFFFu;
+            a.mid_runs[(size_t)b * MS_UNIT_CAP + (q >> 20)] = make_uint2(q & 0xFFFFFu, totB);
+            atomicAdd(&a.c_big[b], totB); // (the list's length where round_begin looks for it)
+        } else {
+            s_offB = totB ? atomicAdd(&a.c_big[b], totB) : 0u;
+        }
     }
     uint32_t *rank = a.rank + base;
     // INIT: a block may turn out to start in SWEEP mode (round_begin decides from the number of groups this kernel counts):
@@ -1357,7 +1399,7 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
     // heads, so they are left for every block here -- 8 coalesced bytes per suffix and a few LDS adds per run of equal
     // heads -- instead of refining such blocks a second time with the three-kernel form (0.57 ms for the 28 blocks of a
     // near-periodic quarter of config 5).
-    const bool narrow = !INIT && *a.gwide == 0u;
+    const bool narrow = !INIT && !midb && *a.gwide == 0u;
     const uint32_t *grank = a.grank + (size_t)b * GID_MAX; // (this round's half)
     // per element: [class:2 @62][foreign:1 @61][valid:1 @60][head:20 @40][suffix:20 @0]
     u64 outv[SORT_ITEMS];
@@ -1444,7 +1486,7 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
     }
     // numbers for the tile's large groups: ONE atomic add for all of them, requested now and used at the very end
     uint32_t pend_g = 0;
-    const uint32_t ng = s_ng;
+    const uint32_t ng = midb ? 0u : s_ng; // (mid_sort's lists carry ranks: no numbers)
     if (threadIdx.x == 0 && ng) pend_g = atomicAdd(&a.gout.gcount[b], ng);
     // records leave through LDS: the tile's small-group records at [0, totS + nH), its large-group records behind them
     {
@@ -2000,7 +2042,8 @@ __global__ void __launch_bounds__(1024) period_probe(ProbeArgs a)
 // summary words: 0 round, 1 nS, 2 nA, 3 nT, 4 nQ, 5 maxS, 6 maxA, 7 maxT, 8 total unresolved, 9 of them sitting the round out,
 //                10 sum of the S lists, 11 this round sorts its big lists on ranks (five passes; else on group numbers: four), 12 sum of the A lists, 13 (round 0) members of small groups that entered the first doubling step inside chunk_finish, 14 error flag, 15 largest depth in use,
 //                16 S blocks whose refine writes lists this round (the only ones that can leave SWEEP mode next round),
-//                17/18 sum over the rounds so far of the unresolved suffixes entering them, 19 sequence word (last)
+//                17/18 sum over the rounds so far of the unresolved suffixes entering them, 19 the part of word 12 that mid_sort orders,
+//                20-22 unused, 23 sequence word (last)
 #ifndef QUAD_DIV
 #define QUAD_DIV 10u
 #endif
@@ -2080,8 +2123,9 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
         bt.c_nolist[b] = 0;
     }
     const uint32_t gTl = sit ? 0u : gT; // what this round's small-group kernels see
-    // round 0: the records of the big lists that mid_sort orders in LDS (bwt_msd.h) instead of the global passes
-    const uint32_t gAm = (valid && round == 0 && mid_on && ms_block_is_mid(bt.ms_np, bt.ms_cnt + MS_CNT_WORDS + (size_t)(MS_LEVELS + 2) * B, b)) ? gA : 0u;
+    // the records of the big lists that mid_sort orders in LDS (bwt_msd.h) instead of the global passes
+    const uint32_t gAm = (valid && mid_on && ms_block_is_mid(bt.ms_np, msc_row(bt.ms_cnt, B, MSR_SPANS), b)) ? gA : 0u;
+    if (valid && mid_on) msc_row(bt.ms_cnt, B, MSR_RUNQ + ((round + 1u) & 1u))[b] = 0u; // the runs this round's refinement writes: the next round's list
     { // (every sum stays below 2^30: at most 1024 blocks of fewer than 2^20 suffixes)
         const uint32_t v[7] = {gS + gA + gT, gS, gA, n, conv, sit ? gT : 0u, gAm};
         const uint32_t m[4] = {gS, gA, gT, (gS | gA | gT) ? h : 0u};
@@ -2405,7 +2449,15 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             }
         }
         side = ctx->side_stream;
+        if (side && !ctx->side2_stream) { // (optional: without it the global passes follow mid_sort on the second stream)
+            if (hipStreamCreateWithFlags(&ctx->side2_stream, hipStreamNonBlocking) != hipSuccess) ctx->side2_stream = nullptr;
+            if (ctx->side2_stream && hipEventCreateWithFlags(&ctx->side_ev[2], hipEventDisableTiming) != hipSuccess) {
+                hipStreamDestroy(ctx->side2_stream);
+                ctx->side2_stream = nullptr;
+            }
+        }
     }
+    hipStream_t side2 = side ? ctx->side2_stream : nullptr;
     // ---- which blocks take which initial sort (bwt_msd.h): text-like blocks the bucket-first one (the plan decides per
     // block, on the device), repetitive, random and binary blocks the 8 passes below (`oldl`; all blocks at level 1,
     // whose blocks are too short for the tables to pay).  BZH_INIT=lsd keeps every block on the 8 passes (A/B timing).
@@ -2435,7 +2487,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     const uint32_t epoch = (++ctx->bwt_epoch & 0xFFFFFFu) << 6;
     Msd msd_keep{};
     if (use_msd) { // (its counters, rank-window cursors and bigram counts join the one clearing launch)
-        clr.add(bt.ms_cnt, (MS_CNT_WORDS + (size_t)(MS_LEVELS + 6) * B) * sizeof(uint32_t)); // (the counters; the tables of runs and tiles behind them are written before they are read)
+        clr.add(bt.ms_cnt, (MS_CNT_WORDS + (size_t)(MS_LEVELS + 7) * B) * sizeof(uint32_t)); // (the counters; the tables of runs and tiles behind them are written before they are read)
         clr.add(bt.ms_bincur, (size_t)B * 256 * sizeof(uint32_t));
         clr.add(bt.ms_bgcur, (size_t)B * MS_BG * sizeof(uint32_t));
     } else {
@@ -2567,6 +2619,15 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     }
     r.init = 0;
     r.cnt = bt.gateR;
+    if (mid_on) {
+        r.mid_np = bt.ms_np;
+        r.mid_spans = msc_row(bt.ms_cnt, B, MSR_SPANS);
+        r.mid_tiles = msc_tiles(bt.ms_cnt, B);
+        r.mid_ntiles = msc_row(bt.ms_cnt, B, MSR_MTILES);
+    }
+    // (greedy packing: two neighbouring tiles hold more than SORT_TILE records, so a list of L records makes at most
+    // 2 L / SORT_TILE + 1 tiles -- the bound refine_one's launch is sized with when such blocks exist)
+    auto refine_bound = [&](uint32_t maxcnt) { return mid_on ? (2u * ((maxcnt + SORT_TILE - 1) / SORT_TILE) + 1u) * SORT_TILE : maxcnt; };
 
     TailArgs ta{};
     ta.n = bt.n;
@@ -2613,6 +2674,9 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     static const uint32_t sweep_div = getenv("BZH_SWEEP_DIV") ? (uint32_t)atoi(getenv("BZH_SWEEP_DIV")) : 256u;
     // bounds for the launches of the round being queued (exact lists live on the device)
     uint32_t nS = B, nA = B, nT = B, nQ = B, maxS = nmax, maxA = nmax, maxT = nmax;
+    // do the blocks of mid_sort / the blocks of the global passes have big lists?  (round 0: what the initial sort's plan says;
+    // later: the sums of the last summary -- a big list only shrinks, and only a block in SWEEP mode can still join the others)
+    bool have_mid = mid_on, have_glob = !mid_on || nOld != 0u || msd_deeper;
     uint32_t err = 0;
     bool finished = false;
     uint32_t s[SUMMARY_WORDS];
@@ -2664,19 +2728,38 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     // one thing they share -- the rank array, read by the first, written by the second -- keeps both versions of a
     // word (rank_at), so the two run side by side: the big-list path on a second stream between two events.  (With
     // profiling on everything stays on one stream, or the per-kernel spans would overlap.)
-    bool side_busy = false;
-    auto join_side = [&]() { // the main stream goes on only behind what the side stream was given
+    bool side_busy = false, side2_busy = false;
+    auto join_side = [&]() { // the main stream goes on only behind what the side streams were given
         if (side_busy) hipStreamWaitEvent(st, ctx->side_ev[1], 0);
-        side_busy = false;
+        if (side2_busy) hipStreamWaitEvent(st, ctx->side_ev[2], 0);
+        side_busy = side2_busy = false;
     };
     // An error return hands the context back: nothing of this call may still be running on the second stream
     // against the arena when the next call queues its memsets (bzh_debug_fault promises a usable context).
     auto fail_wait = [&](hipError_t e) -> int {
         if (side_busy && side) hipStreamSynchronize(side);
-        side_busy = false;
+        if (side2_busy && side2) hipStreamSynchronize(side2);
+        side_busy = side2_busy = false;
         ctx->stream = st;
         bzh_set_error(ctx, "%s:%d waiting for a round summary -> %s", __FILE__, __LINE__, hipGetErrorString(e));
         return BZH_E_HIP;
+    };
+    // The tiles of the NEXT round's big lists, planned as soon as this round's refinement has written them -- on the second
+    // stream, beside round_begin: mid_sort can then start with its round (a plan queued in front of it started it late, when
+    // tail_round held every CU's LDS, and it waited for room: 374 us for 2 M records).
+    auto plan_ahead = [&](uint32_t round) {
+        if (!(mid_on && have_mid)) return;
+        KSpan ks(ctx, K_MID_SORT, 0);
+        Msd mp = msd_keep;
+        mp.runq = msc_row(bt.ms_cnt, B, MSR_RUNQ + ((round + 1u) & 1u));
+        mp.runs = msc_runs(bt.ms_cnt, B, (round + 1u) & 1u);
+        hipStream_t sp = st;
+        if (side) {
+            hipEventRecord(ctx->side_ev[0], st);
+            hipStreamWaitEvent(side, ctx->side_ev[0], 0);
+            sp = side;
+        }
+        mid_plan<<<dim3(B), 256, 0, sp>>>(mp, 0u);
     };
     auto run_A = [&](uint32_t round) {
         const uint32_t gt = (maxA + SORT_TILE - 1) / SORT_TILE;
@@ -2693,22 +2776,32 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         a.src = cur;
         a.dst = oth;
         a.T = gt | (few_blocks(nA) ? WG_SPREAD : 0u);
-        // Round 0 of the bucket-first blocks: their big lists are ordered run by run in LDS, in place (the sorted list is
-        // wanted in `cur` either way); the global passes below then skip them, and are not even launched when no block can
-        // need them (none on the 8 passes, no group that spans several units: only level 5 of the initial sort makes those)
-        const bool mid = round == 0 && mid_on;
+        // The bucket-first blocks without a group that spans several units: their big lists are ordered tile by tile in LDS, in
+        // place (the sorted list is wanted in `cur` either way); the global passes below skip them, and are not even launched
+        // when no block can need them (none on the 8 passes or in SWEEP mode, no spanning group: only level 5 of the initial
+        // sort makes those) -- nor is mid_sort once no block of its kind has a big list left (the sums of the last summary).
+        // Round 0 has the device to itself (the small groups of a bucket-first block sit it out): two workgroups a CU, and
+        // the few blocks left to the global passes run them on the main stream; from round 1 on tail_round runs beside it
+        // and needs room on every CU: one workgroup a CU.
+        const bool mid = mid_on && have_mid;
         if (mid) {
-            KSpan ks(ctx, K_MID_SORT, 0);
-            MidArgs ma{cur, bt.rank, bt.st_h, bt.gateA, bt.gidof, a.gwide, a.tag, ms_tiles(msd_keep, 0), ms_mid_tiles(msd_keep, 0), ms_spans(msd_keep, 0), bt.ms_np,
-                       bt.n, ms_mid_ticket(msd_keep, 0), bt.errflag, bt.S, B, getenv("BZH_MID_DBG") ? (uint32_t)atoi(getenv("BZH_MID_DBG")) : 0u};
-            mid_sort<<<dim3(512), MS_THREADS, 0, sa>>>(ma);
+            KSpan ks(ctx, K_MID_SORT, 0); // (the tiles were planned behind the refinement that wrote the lists: plan_ahead)
+            MidArgs ma{cur, bt.rank, bt.st_h, bt.gateA, a.tag, msc_tiles(bt.ms_cnt, B), msc_row(bt.ms_cnt, B, MSR_MTILES), msc_row(bt.ms_cnt, B, MSR_SPANS),
+                       bt.ms_np, bt.n, msc_row(bt.ms_cnt, B, MSR_MTICKET), bt.errflag, bt.S, B, getenv("BZH_MID_DBG") ? (uint32_t)atoi(getenv("BZH_MID_DBG")) : 0u};
+            mid_sort<<<dim3(round ? 256 : 512), MS_THREADS, 0, sa>>>(ma);
         }
-        const bool global_path = !mid || nOld || msd_deeper;
-        a.mid_np = mid ? bt.ms_np : nullptr;
-        a.mid_spans = mid ? bt.ms_cnt + MS_CNT_WORDS + (size_t)(MS_LEVELS + 2) * B : nullptr;
-        if (mid && side) { // the few blocks left to the global passes run them on the main stream, beside mid_sort
+        const bool global_path = !mid_on || have_glob;
+        a.mid_np = mid_on ? bt.ms_np : nullptr;
+        a.mid_spans = mid_on ? msc_row(bt.ms_cnt, B, MSR_SPANS) : nullptr;
+        bool on_side2 = false;
+        if (mid && side && round == 0) {
             sa = st;
             ctx->stream = st;
+        } else if (mid && side2 && global_path) { // (from round 1 on the main stream is tail_round's: a third stream)
+            hipStreamWaitEvent(side2, ctx->side_ev[0], 0);
+            sa = side2;
+            ctx->stream = side2;
+            on_side2 = true;
         }
         if (global_path) {
         // A large group has more than TAIL_G members (and a group that spans several units of the initial sort draws one
@@ -2750,6 +2843,10 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             ctx->stream = st;
             hipEventRecord(ctx->side_ev[1], side);
             side_busy = true;
+            if (on_side2) {
+                hipEventRecord(ctx->side_ev[2], side2);
+                side2_busy = true;
+            }
         }
     };
     // -- small groups: one kernel per form (depth x2 / depth x4); survivors move to the other list buffer
@@ -2791,6 +2888,10 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         a.gwide = r.gwide = bt.gwide + (round & 1u);
         r.grank = bt.grank + (size_t)(round & 1u) * bt.B * GID_MAX;
         r.gout.par = (round + 1u) & 1u;
+        if (mid_on) { // (the runs this round's refinement writes are the next round's list)
+            r.mid_runq = msc_row(bt.ms_cnt, B, MSR_RUNQ + ((round + 1u) & 1u));
+            r.mid_runs = msc_runs(bt.ms_cnt, B, (round + 1u) & 1u);
+        }
         {
         KSpan ks(ctx, K_ROUND_BEGIN, 0);
         round_begin<<<1, (B + 63u) / 64u * 64u, 0, st>>>(bt, B, round, actP,
@@ -2816,6 +2917,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             // small lists; big lists shrink, small lists gain at most what the big lists lose.
             // SWEEP blocks only leave that mode with lists in hand: cS of them wrote lists in the round before.
             const uint32_t pS = s[1], pA = s[2], pT = s[3], mS = s[5], mA = s[6], mT = s[7], cS = s[16];
+            have_mid = mid_on && s[19] != 0u;
+            have_glob = !mid_on || s[12] != s[19] || pS != 0u || cS != 0u;
             nS = pS;
             maxS = mS;
             nA = std::min(B, pA + cS);
@@ -2849,6 +2952,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             const uint32_t pA = s[2], pT = s[3], mA = s[6], mT = s[7], cS = s[16];
             nA = pA;
             maxA = mA;
+            have_mid = mid_on && s[19] != 0u;
+            have_glob = !mid_on || s[12] != s[19] || s[1] != 0u || cS != 0u;
             join_side();
             if (nS | nA) {
                 r.list = cur;
@@ -2863,7 +2968,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
                     r.cpass = ++a.pass;
                     r.lst = Lst{bt.actA, bt.nlist + L_A, B};
                     KSpan ks(ctx, K_REFINE_ROUNDS, 0);
-                    launch_refine_one<false>(ctx, r, nA, maxA);
+                    launch_refine_one<false>(ctx, r, nA, refine_bound(maxA));
+                    plan_ahead(0);
                 }
                 std::swap(cur, oth);
             }
@@ -2894,7 +3000,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
                 r.cpass = ++a.pass;
                 r.lst = Lst{bt.actA, bt.nlist + L_A, B};
                 KSpan ks(ctx, K_REFINE_ROUNDS, 0);
-                launch_refine_one<false>(ctx, r, nA, maxA);
+                launch_refine_one<false>(ctx, r, nA, refine_bound(maxA));
+                plan_ahead(round);
             }
             std::swap(cur, oth);
         }

@@ -42,8 +42,12 @@ struct Msd {
     uint32_t *c_big, *c_small, *c_groups;
     uint32_t *err;
     uint32_t midcap;     // records a tile of mid_sort holds at most (mid_plan; a longer run is a tile of its own)
-    uint32_t *runq;      // ms_runq(m, 0): records | runs << 20 of every block's big list
-    uint2 *runs;         // ms_runs(m, 0): where the units' large-group records stand in the big lists (chunk_finish -> mid_plan)
+    // the big lists' runs (bwt.hip: msc_*): the counters records | runs << 20 and the table chunk_finish fills (round 0's
+    // half); mid_plan: the half it reads, the tiles and their number per block it writes, mid_sort's tickets it clears
+    uint32_t *runq;
+    uint2 *runs;
+    uint2 *tiles;
+    uint32_t *ntiles, *mticket;
     GidOut gout;         // numbers for the large groups (bwt.hip: round 0 sorts its big lists on them)
     uint32_t force_old;  // every block keeps the 8-pass path (BZH_INIT=lsd)
     uint32_t force_new;  // no block is kept off the buckets for its share of oversized ones (BZH_INIT=msd)
@@ -277,22 +281,9 @@ __device__ __forceinline__ void ms_push_seg(const Msd &m, uint32_t L, uint32_t b
 // tickets chunk_finish hands out over it): the finishing kernel works through a block's units on ONE XCD.
 __host__ __device__ __forceinline__ uint32_t *ms_unit_count(const Msd &m, uint32_t b) { return m.cnt + MS_CNT_WORDS + b; }
 __device__ __forceinline__ uint32_t *ms_unit_ticket(const Msd &m, uint32_t b) { return m.cnt + MS_CNT_WORDS + (size_t)(MS_LEVELS + 1) * m.B + b; }
-// (row MS_LEVELS + 2: the block holds a group that spans several units -- more than MS_TILE rotations share 7 bytes; row
-// MS_LEVELS + 3: the tickets of mid_sort, which goes through the same units once more)
-__host__ __device__ __forceinline__ uint32_t *ms_spans(const Msd &m, uint32_t b) { return m.cnt + MS_CNT_WORDS + (size_t)(MS_LEVELS + 2) * m.B + b; }
-__host__ __device__ __forceinline__ uint32_t *ms_mid_ticket(const Msd &m, uint32_t b) { return m.cnt + MS_CNT_WORDS + (size_t)(MS_LEVELS + 3) * m.B + b; }
-__host__ __device__ __forceinline__ uint32_t *ms_mid_tiles(const Msd &m, uint32_t b) { return m.cnt + MS_CNT_WORDS + (size_t)(MS_LEVELS + 4) * m.B + b; }
-// (per block: records of the big list so far | runs so far << 20 -- one atomic add gives a unit's run its place in the list
-// AND its number in the order of the list, so the table of runs needs no sorting.  A block has fewer than 2^20 rotations and at
-// most MS_UNIT_CAP = 4096 units: the 4096th run wraps the upper field to 0, which only the reader of the final value sees --
-// "records but no runs" reads as 4096 runs)
-__host__ __device__ __forceinline__ uint32_t *ms_runq(const Msd &m, uint32_t b) { return m.cnt + MS_CNT_WORDS + (size_t)(MS_LEVELS + 5) * m.B + b; }
-// the runs of a block's big list in list order, (first record, records) each, and the tiles mid_plan packs them into
-__host__ __device__ __forceinline__ uint2 *ms_runs(const Msd &m, uint32_t b)
-{
-    return reinterpret_cast<uint2 *>(m.cnt + ((MS_CNT_WORDS + (size_t)(MS_LEVELS + 6) * m.B + 1) & ~(size_t)1)) + (size_t)b * MS_UNIT_CAP;
-}
-__host__ __device__ __forceinline__ uint2 *ms_tiles(const Msd &m, uint32_t b) { return ms_runs(m, 0) + ((size_t)m.B + b) * MS_UNIT_CAP; }
+// (rows MS_LEVELS + 2 ..: bwt.hip, msc_row -- "the block holds a group that spans several units", i.e. more than MS_TILE
+// rotations share 7 bytes; the tickets and tile counts of mid_sort; the run counters of the big lists)
+__host__ __device__ __forceinline__ uint32_t *ms_spans(const Msd &m, uint32_t b) { return msc_row(m.cnt, m.B, MSR_SPANS) + b; }
 __device__ __forceinline__ void ms_push_unit(const Msd &m, uint4 u)
 {
     const uint32_t b = u.x & 1023u;
@@ -1301,11 +1292,12 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
 // active_gen + four (five) global radix passes over every record (8 + 4 x 16 bytes a record through HBM, and the round's
 // critical path: round 0 has no small-group kernel to hide behind once chunk_finish takes their first step).
 // Tiles are taken block by block on the block's XCD, as chunk_finish takes its units (the rank gathers stay inside one L2).
-// One workgroup per bucket-first block, behind chunk_finish: the length of the block's big list where round_begin looks for it,
-// and the runs of that list (in list order: ms_runq) packed greedily into tiles of at most MS_TILE records -- a tile is a
-// stretch of the list made of whole runs, i.e. of whole groups, and mid_sort orders a tile at a time (a unit's run alone
-// averages 1,200 records on text: seven times the workgroup rounds, each with its chain of dependent loads).
-__global__ void __launch_bounds__(256) mid_plan(Msd m)
+// One workgroup per bucket-first block, before mid_sort: the runs of the block's big list (in list order, by construction of
+// their claims) packed greedily into tiles of at most MS_TILE records -- a tile is a stretch of the list made of whole runs,
+// i.e. of whole groups, and mid_sort orders a tile at a time (a unit's run alone averages 1,200 records on text: seven times
+// the workgroup rounds, each with its chain of dependent loads).  `first`: behind chunk_finish -- it also leaves the list's
+// length where round_begin looks for it (chunk_finish's one atomic per unit is the run claim; refine_one makes both).
+__global__ void __launch_bounds__(256) mid_plan(Msd m, uint32_t first)
 {
     const uint32_t b = blockIdx.x;
     if (b >= m.B || m.np[b] == 0u) return; // (a block on the 8 passes: refine_one<init> writes its lists)
@@ -1317,8 +1309,9 @@ __global__ void __launch_bounds__(256) mid_plan(Msd m)
     for (uint32_t k = threadIdx.x; k < runs; k += 256) R[k] = rt[k];
     __syncthreads();
     if (threadIdx.x == 0) {
-        m.c_big[b] = recs;
-        uint2 *tt = m.runs + ((size_t)m.B + b) * MS_UNIT_CAP; // (ms_tiles)
+        if (first) m.c_big[b] = recs;
+        m.mticket[b] = 0u;
+        uint2 *tt = m.tiles + (size_t)b * MS_UNIT_CAP;
         uint32_t nt = 0, ts = 0, tl = 0;
         bool bad = false;
         for (uint32_t k = 0; k < runs; k++) {
@@ -1333,7 +1326,7 @@ __global__ void __launch_bounds__(256) mid_plan(Msd m)
         }
         if (tl) tt[nt++] = make_uint2(ts, tl);
         if (bad || ts + tl != recs) atomicOr(m.err, ERR_MSD);
-        *ms_mid_tiles(m, b) = nt;
+        m.ntiles[b] = nt;
     }
 }
 
@@ -1342,8 +1335,6 @@ struct MidArgs {
     const uint32_t *rank;  // [B][S]
     const uint32_t *hb;    // [B] depth of the block's round
     const uint32_t *len;   // [B] records in the block's big list (gateA)
-    const uint16_t *gidof; // [B][S] rank -> number of a numbered group
-    const uint32_t *gwide; // this round's word: 0 = the sorted list carries group numbers (refine_one reads it the same way)
     uint32_t tag;          // this round's id in the rank words
     // of the initial sort's state (Msd): the tiles of the big lists and their number per block (mid_plan), this kernel's
     // tickets, "a group spans several units", "took the bucket-first sort", block sizes
@@ -1360,7 +1351,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) mid_sort(MidArgs a)
     __shared__ MsCnt cur[2];
     __shared__ u64 HM[128];          // group heads by load position (bit per slot)
     __shared__ uint32_t rowpre[128]; // group heads before a row
-    __shared__ uint32_t G[128];      // group index inside the run -> what the record carries in its place (number or rank)
+    __shared__ uint32_t G[128];      // group index inside the tile -> the group's rank (the record leaves with it in front)
     __shared__ uint32_t ls[MS_NW + 2];
     __shared__ u64 s_wo[MS_NW], s_wa[MS_NW];
     __shared__ uint32_t s_blk, s_unit, s_next;
@@ -1376,7 +1367,6 @@ __global__ void __launch_bounds__(MS_THREADS, 4) mid_sort(MidArgs a)
         cur_cnt = ms_block_is_mid(a.np, spans, cur_blk) ? min(a.ucount[cur_blk], MS_UNIT_CAP) : 0u;
     }
     if (threadIdx.x == 0 && cur_blk != NOBLK) s_next = cur_cnt ? atomicAdd(a.ticket + cur_blk, 1u) : 0u;
-    const bool narrow = *a.gwide == 0u;
     uint32_t tid = threadIdx.x;
     for (;;) {
         asm volatile("" : "+v"(tid)); // (opaque once per unit: what depends on it alone is not kept across the loop -- see chunk_finish)
@@ -1532,8 +1522,6 @@ __global__ void __launch_bounds__(MS_THREADS, 4) mid_sort(MidArgs a)
         }
         if (tid == 0) s_next = pend_ticket;
         __syncthreads();
-        // (a numbered group's record carries the number: one gather for all the tile's groups, consumed after the passes)
-        if (narrow && tid < min(ls[MS_NW + 1], 128u)) G[tid] = (uint32_t)a.gidof[(size_t)b * a.S + G[tid]];
         u64 vary;
         {
             u64 o = 0ull, an = ~0ull;
@@ -1573,7 +1561,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) mid_sort(MidArgs a)
                 __syncthreads();
             }
         }
-        // ---- out, in place: [number or rank : 20 @40][key2 : 20 @20][suffix : 20]
+        // ---- out, in place: [rank : 20 @40][key2 : 20 @20][suffix : 20] (refine_one reads a block of this kind that way whatever the round's other lists carry)
         for (uint32_t q = tid; q < len && !(a.dbg & 4u); q += MS_THREADS) {
             const u64 y = stage[ms_slot(q)];
             recs[q] = ((u64)G[(uint32_t)(y >> 41) & 127u] << 40) | (y & 0xFFFFFFFFFFull);
@@ -1624,8 +1612,11 @@ static int msd_sort_begin(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntot
     m.c_groups = bt.c_groups;
     m.err = bt.errflag;
     m.gout = GidOut{bt.gidof, bt.grank, bt.gcount, bt.gwide, bt.S, bt.B, 0u};
-    m.runs = ms_runs(m, 0);
-    m.runq = ms_runq(m, 0);
+    m.runq = msc_row(bt.ms_cnt, B, MSR_RUNQ); // (round 0 reads the half of parity 0)
+    m.runs = msc_runs(bt.ms_cnt, B, 0);
+    m.tiles = msc_tiles(bt.ms_cnt, B);
+    m.ntiles = msc_row(bt.ms_cnt, B, MSR_MTILES);
+    m.mticket = msc_row(bt.ms_cnt, B, MSR_MTICKET);
     m.midcap = getenv("BZH_MID_CAP") ? std::min<uint32_t>(MS_TILE, std::max(1, atoi(getenv("BZH_MID_CAP")))) : (uint32_t)MS_TILE;
     m.force_old = force_old ? 1u : 0u;
     m.fuse = fuse;
@@ -1709,7 +1700,7 @@ static int msd_sort_finish(bzh_ctx *ctx, hipStream_t st, const Msd &m, uint64_t 
     {
         KSpan ks(ctx, K_MSD_FINISH, 16 * ntotal);
         chunk_finish<<<dim3(512), MS_THREADS, 0, st>>>(m);
-        mid_plan<<<dim3(m.B), 256, 0, st>>>(m);
+        mid_plan<<<dim3(m.B), 256, 0, st>>>(m, 1u);
     }
     HIP_TRY(ctx, hipGetLastError());
     return BZH_OK;

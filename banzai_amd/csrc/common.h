@@ -131,10 +131,11 @@ struct Batch {
     uint4 *ms_units;     // [B * MS_UNIT_CAP] work list of the finishing kernel
     uint4 *ms_segs;      // [MS_LEVELS + 1][B * MS_SEG_SLOTS] oversized buckets per level
     uint32_t *ms_items;  // [MS_LEVELS + 1][B * MS_ITEM_CAP] (oversized bucket, tile) pairs per level
-    uint32_t *ms_cnt;    // [MS_CNT_WORDS + (MS_LEVELS + 6) * B] counters; behind the first MS_CNT_WORDS per block: units, slot counters
+    uint32_t *ms_cnt;    // [MS_CNT_WORDS + (MS_LEVELS + 7) * B] counters; behind the first MS_CNT_WORDS per block: units, slot counters
                          // of the levels, unit tickets, "holds a group that spans several units", tickets and tile counts of
-                         // mid_sort, records | runs << 20 of the big list chunk_finish writes; then [2][B][MS_UNIT_CAP] x 2 words:
-                         // the runs of that list and the tiles mid_plan packs them into (bwt_msd.h)
+                         // mid_sort, records | runs << 20 of the big list being written (two rows, by round parity); then
+                         // [3][B][MS_UNIT_CAP] x 2 words: the runs of those lists (two halves) and the tiles mid_plan packs them
+                         // into (bwt.hip: msc_* accessors)
     uint32_t *ms_np;     // [B] 1: the block takes the bucket-first path (its first doubling round has depth 7)
     uint32_t *ms_old, *ms_new; // [B] ids of the blocks on the 8-pass path / on the bucket-first path
     uint32_t *ms_bincur; // [B][256] rank binning: pairs already claimed in each 4096-suffix window
@@ -205,7 +206,8 @@ struct bzh_ctx {
     uint32_t max_batch = 0;
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;   // second stream of the suffix sort (big-list path beside the small groups)
-    hipEvent_t side_ev[2] = {nullptr, nullptr};
+    hipStream_t side2_stream = nullptr;  // third stream: the global passes of the blocks mid_sort does not take, beside it (rounds >= 1)
+    hipEvent_t side_ev[3] = {nullptr, nullptr, nullptr};
     int profiling = 0;
     int mode = 0;                     // BZH_MODE_REFERENCE / BZH_MODE_FIXED (bzh_set_mode)
     char err[512] = {0};      // last failure (guarded by err_mu: the streaming worker writes it too)
