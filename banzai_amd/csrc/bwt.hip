@@ -771,6 +771,7 @@ struct RefineArgs {
     uint32_t bpass;      // refine_one<init>: pass id of the rank binning's status words (rows of cstat)
     uint32_t *err;       // bit 1: a look-back gave up
     const uint8_t *blk;  // [B][S] the text (init pass: low half of the 8-byte prefix is compared from it)
+    uint8_t *bwt;        // [B][S] the last column (init pass: the bytes of the rotations it resolves)
     uint32_t *rank;      // [B][S]
     uint32_t *sa;        // [B][S]
     uint32_t *headp;     // [B][S]
@@ -1430,6 +1431,9 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
                     atomicAdd(&bh[i >> 12], 1u); // every suffix gets a rank: binned by 4096-suffix window, then applied
                     isuf[k] = i;
                     ihead[k] = head;
+                    // (alone in its group: its byte of the last column leaves now, in sorted order -- as in chunk_finish, bwt_msd.h;
+                    // the rank word below says so and bwt_emit skips it)
+                    if (c == CLS_SINGLE) a.bwt[base + head] = a.blk[base + (i ? i - 1u : a.n[b] - 1u)];
                     if (c != CLS_SINGLE) { // heads rise with q: runs counted in registers, LDS touched once per run (as refine)
                         if (head != ph) {
                             if (pc) atomicAdd(&dh[ph & 127u], pc);
@@ -1539,7 +1543,7 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
     for (int k = 0; k < SORT_ITEMS; k++) {
         if ((outv[k] >> 60) & 1ull) {
             const uint32_t i = (uint32_t)(outv[k] & SUF_MASK), head = (uint32_t)(outv[k] >> 40) & 0xFFFFFu;
-            const uint32_t word = (uint32_t)(outv[k] >> 62) == CLS_SINGLE ? (head | RANK_RESOLVED) : head;
+            const uint32_t word = (uint32_t)(outv[k] >> 62) == CLS_SINGLE ? (head | RANK_RESOLVED | RANK_EMITTED) : head;
             lds[atomicAdd(&bcur[i >> 12], 1u)] = ((u64)word << 32) | i;
         }
     }
@@ -1794,6 +1798,8 @@ __global__ void __launch_bounds__(TR_THREADS) tail_round(TailArgs a)
 // Every suffix is resolved, so rank[i] is the position of rotation i in the sorted order: the last column is
 // a scatter of the text, bwt[rank[i]] = S[i-1] -- coalesced reads of the ranks and the text, one-byte stores
 // into the block's 0.9 MB output (resident in the XCD's L2); ptr = rank[0]; has_byte straight from the text.
+// The rotations the bucket-first initial sort resolved (over half of a text block's) have their bytes in place: chunk_finish
+// wrote them in sorted order, next to each other; their rank words say so and they are skipped here.
 __global__ void __launch_bounds__(256) bwt_emit(Batch bt, uint32_t T, uint32_t B)
 {
     uint32_t b, tile;
@@ -1826,7 +1832,8 @@ __global__ void __launch_bounds__(256) bwt_emit(Batch bt, uint32_t T, uint32_t B
         c[0] = s[i0 ? i0 - 1 : n - 1];
         for (uint32_t k = 1; k < m; k++) c[k] = s[i0 + k - 1];
         for (uint32_t k = 0; k < m; k++) {
-            out[rank_final(r[k])] = c[k];
+            // (a rotation chunk_finish resolved has its byte in place already: bwt_msd.h, RANK_EMITTED)
+            if ((r[k] >> 20) != ((RANK_RESOLVED | RANK_EMITTED) >> 20)) out[rank_final(r[k])] = c[k];
             seen[c[k]] = 1; // every byte of S appears exactly once in the last column
         }
         if (i0 == 0) bt.ptr[b] = rank_final(r[0]);
@@ -2553,6 +2560,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     r.tbase = bt.c_tail;
     r.mode = bt.st_mode;
     r.blk = bt.rle;
+    r.bwt = bt.bwt;
     r.rank = bt.rank;
     r.sa = bt.sa;
     r.headp = bt.headp;

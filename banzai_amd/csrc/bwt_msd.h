@@ -39,6 +39,7 @@ struct Msd {
     uint32_t *items, *cnt, *np, *act_old, *act_new, *bincur;
     u64 *bufX, *bufY;    // partition output of levels 0, 2, 4 / 1, 3, 5
     u64 *big, *tail, *binned;
+    uint8_t *bwt;        // [B][S] the last column (chunk_finish writes the bytes of the rotations it resolves)
     uint32_t *c_big, *c_small, *c_groups;
     uint32_t *err;
     uint32_t midcap;     // records a tile of mid_sort holds at most (mid_plan; a longer run is a tile of its own)
@@ -1212,7 +1213,14 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
             const uint32_t w = k * MS_THREADS + tq6;
             if (w < len) {
                 const uint32_t c = gi[k] >> 30, head = gi[k] & 0xFFFFFu;
-                const uint32_t word = c == CLS_SINGLE ? (head | RANK_RESOLVED) : head;
+                uint32_t word = head;
+                if (c == CLS_SINGLE) {
+                    // A rotation that is alone in its group has its final place: its byte of the last column leaves now (the
+                    // text is in this XCD's L2, neighbours in the order are neighbours in the column), and the rank word says
+                    // so -- tag 31, which no round writes with less = 0 -- for bwt_emit, which then scatters the rest only.
+                    word = head | RANK_RESOLVED | RANK_EMITTED;
+                    m.bwt[(size_t)b * m.S + head] = txt[sf[k] ? sf[k] - 1u : n - 1u];
+                }
                 stage[atomicAdd(&bcur[sf[k] >> 12], 1u)] = ((u64)word << 32) | sf[k];
             }
         }
@@ -1607,6 +1615,7 @@ static int msd_sort_begin(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntot
     m.big = big;
     m.tail = tail;
     m.binned = binned;
+    m.bwt = bt.bwt;
     m.c_big = bt.c_big;
     m.c_small = bt.c_small;
     m.c_groups = bt.c_groups;

@@ -53,6 +53,7 @@ constexpr int SORT_ITEMS = 16;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS; // 8192 elements per workgroup (512 x 16: halves the look-back /
                                                      // scan overhead per element against 256 x 16, -7 % on the bench)
 constexpr uint32_t RANK_RESOLVED = 0x80000000u;      // suffix is alone in its group
+constexpr uint32_t RANK_EMITTED = 31u << 26;         // (with RANK_RESOLVED, less = 0) its byte of the last column has been written (chunk_finish)
 constexpr int SUMMARY_WORDS = 24; // round summary: see round_begin (bwt.hip)
 constexpr uint32_t GID_MAX = 4096;  // large groups of a block a round can number densely (12 key bits)
 constexpr int RS_ROWS = 22;       // per-block rows of the suffix sort's round state (layout_batch, api.hip)
