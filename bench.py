@@ -553,7 +553,7 @@ def main():
                          "radix_scatter_all": {"achieved": round(achieved_rs, 1) if achieved_rs else None,
                                                "frac": round(achieved_rs / HBM_PEAK_GBS, 4) if achieved_rs else None,
                                                "launches": int(sort_launches),
-                                               "avg_launch_us": round(sort_ms * 1e3 / max(1, sort_launches), 2)},
+                                               "avg_launch_us": round(sort_ms * 1e3 / sort_launches, 2) if sort_launches else None},
                          "measured_in": "untimed pass of the same K steps with profiling on, before the warm-up and the timed region "
                                         f"({round(ms_profiled, 3)} ms per step there)",
                          # the whole path by SURVEY 8(d)'s fixed accounting, over the TIMED region (all ranks)

@@ -69,6 +69,7 @@ def test_rocprof_summary_agrees_with_the_line(rnd):
     mean_us = sum(int(r["TotalDurationNs"]) for r in rows) / calls / 1e3
     assert calls > 0 and abs(mean_us - d["roofline"]["avg_launch_us"]) / mean_us < 0.05
     t = json.load(open(os.path.join(PROF, f"{rnd}_pmc_traffic.json")))
-    assert t["radix_scatter_all"]["hbm_bytes_per_launch"] > 0
+    if rnd in ("r01", "r02", "r03", "r04"):  # (from round 5 on the headline launches no global radix pass at all: mid_sort)
+        assert t["radix_scatter_all"]["hbm_bytes_per_launch"] > 0
     if rnd not in ("r01", "r02", "r03"):
         assert any(k.startswith(key) and v["hbm_bytes_per_launch"] > 0 for k, v in t["kernels"].items())
