@@ -172,6 +172,8 @@ static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
     carve(p, bt.nsyms, NB);
     carve(p, bt.tfreq, NB * 3 * 258);
     carve(p, bt.lens, NB * 3 * 258);
+    carve(p, bt.lens2, 2 * NB * 3 * 258);
+    carve(p, bt.lfit, 2 * NB * 3);
     carve(p, bt.ntab, NB);
     carve(p, bt.codes, NB * 258);
     carve(p, bt.hdr, NB * HDR_BYTES);

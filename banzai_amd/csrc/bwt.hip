@@ -2871,6 +2871,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             tail_round<true><<<dim3(xcd_grid(ta.T, nQ)), TR_THREADS, 0, st>>>(ta);
         }
     };
+    uint64_t emitted = 0; // rotations whose last-column byte the initial sort wrote (statistics)
     auto account = [&](const uint32_t *sm) { // statistics of the round a summary describes
         if (!ctx->profiling) return;
         const uint64_t tot = (uint64_t)sm[8], eS = (uint64_t)sm[10], eAm = (uint64_t)sm[19], eA = (uint64_t)sm[12] - eAm; // (eAm: mid_sort's records, round 0)
@@ -2886,6 +2887,12 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         ctx->k_bytes[K_ACTIVE_GEN] += eA * 20;                      // record in, re-keyed record out, one rank gather
         ctx->k_bytes[K_REFINE_ROUNDS] += (eA + eAm) * 20;           // record in, rank word, list record out
         ctx->k_bytes[K_TAIL_ROUND] += (tot - eS - eA - eAm - sm[9]) * 24; // record in, key gather, rank word, survivor out (not the groups that sit the round out)
+        if (sm[0] == 0) {
+            // (+ the last-column bytes of the rotations the initial sort resolved -- everything that is in no list now: one
+            // byte gathered, one byte stored each; bwt_emit stores the rest)
+            emitted = ntotal > tot ? ntotal - tot : 0;
+            ctx->k_bytes[nOld == B ? K_REFINE_INIT : K_MSD_FINISH] += emitted * 2;
+        }
         if (sm[0] == 0) ctx->k_bytes[nOld == B ? K_REFINE_INIT : K_MSD_FINISH] += tot * 8 + (uint64_t)sm[13] * 8; // the list records the initial refinement wrote + the 8 text bytes each member of a small group was keyed on
     };
 
@@ -3055,7 +3062,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     if (gx > 256) gx = 256;
     if (gx == 0) gx = 1;
     if (few_blocks(B)) gx |= WG_SPREAD;
-    KSpan ks(ctx, K_BWT_EMIT, 6 * ntotal);
+    KSpan ks(ctx, K_BWT_EMIT, 6 * ntotal - emitted); // rank word and text byte in for every rotation, one byte out for those not yet written
     bwt_emit<<<dim3(xcd_grid(gx, B)), 256, 0, st>>>(bt, gx, B);
     HIP_TRY(ctx, hipGetLastError());
     return BZH_OK;

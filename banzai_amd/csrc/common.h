@@ -151,6 +151,8 @@ struct Batch {
     // Huffman
     uint32_t *tfreq;   // [B][3][258]
     uint8_t *lens;     // [B][3][258]
+    uint8_t *lens2;    // [2][B][3][258] huff_build: what each half of a block's attempts found (huff_header picks)
+    uint32_t *lfit;    // [2][B][3] the scaling exponent that half found to fit (0xFFFFFFFF: none)
     uint32_t *ntab;    // [B]
     uint32_t *codes;   // [B][258]  (len << 24 | word) for table 0
     uint8_t *hdr;      // [B][HDR_BYTES] per-block header bits (block header .. coding tables)

@@ -279,20 +279,30 @@ __device__ void build_lengths(HeapMem &h, uint32_t nsyms, uint8_t *out, uint32_t
     }
 }
 
-// One wavefront per (table, attempt): the attempts with scaling 1, 2, 4 and 8 are independent computations from the
-// same frequencies, so they run side by side and the first that fits is kept -- exactly the table the reference's
-// sequential loop ends with, in the time of one build instead of up to four (blocks with skewed 258-symbol
-// alphabets need two or three).  Should none fit, the loop carries on from scaling 16.  All lanes of a wavefront work
-// in lock step; the heaps live in LDS.
-constexpr int HB_TRIES = 4; // (measured on the headline: 1 try 991 us, 2 tries 805 us, 4 tries 424 us -- one build takes ~420 us)
-__global__ void __launch_bounds__(64 * 3 * HB_TRIES) huff_build(Batch bt)
+// One wavefront per (table, attempt): the attempts with scaling 1, 2, 4, ... are independent computations from the same
+// frequencies, so they run side by side and the first that fits is kept -- exactly the table the reference's sequential
+// loop ends with, in the time of ONE build instead of up to five.  Eight attempts a table for two tables, five for three,
+// in TWO workgroups a block (the lower and the upper exponents): a build is a chain of dependent LDS round trips whose
+// instructions the wavefronts of a SIMD issue in turn -- 12 wavefronts on a CU: 224 us a build, 16: 298 us, 8 or 9: below --
+// and a batch has fewer blocks than half the CUs.  Each half leaves what it found (bt.lens2, bt.lfit); huff_header takes
+// the lower half's table if it has one.
+// (Round 4 ran four attempts a table and noted "should none fit, the loop carries on from scaling 16 -- never seen".  It
+// was seen all along: every block of the headline but the first two needs scaling 16 -- a 161-symbol alphabet with byte
+// values that occur once in 300,000 symbols --, so the kernel took two builds, 424 us, whatever else was tried on it; its
+// time against the number of blocks in the batch showed the step.)
+// Should nothing fit in the upper half either, its first wavefront of the table carries on behind the last attempt.
+constexpr int HB_WAVES = 10; // (at most 2 tables x 4 or 3 tables x 3 attempts a half)
+constexpr uint32_t HB_NONE = 0xFFFFFFFFu;
+__global__ void __launch_bounds__(64 * HB_WAVES) huff_build(Batch bt)
 {
-    const uint32_t b = blockIdx.x;
+    const uint32_t half = blockIdx.x, b = blockIdx.y;
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t t = w / HB_TRIES, a = w % HB_TRIES;
     const uint32_t ntab = bt.ntab[b], nsyms = bt.nsyms[b];
-    __shared__ HeapMem hm[3 * HB_TRIES];
-    __shared__ int mx[3][HB_TRIES];
+    const uint32_t t0 = ntab <= 2u ? 4u : 3u, t1 = ntab <= 2u ? 8u : 5u; // (ntab is 2 or 3)
+    const uint32_t lo = half ? t0 : 0u, per = half ? t1 - t0 : t0;
+    const uint32_t t = w / per, a = lo + w % per;
+    __shared__ HeapMem hm[HB_WAVES];
+    __shared__ int mx[3][4];
     uint32_t dep[(HUF_SYMS + 63) / 64];
     int maxlen = 0;
     if (t < ntab) {
@@ -301,16 +311,21 @@ __global__ void __launch_bounds__(64 * 3 * HB_TRIES) huff_build(Batch bt)
         for (uint32_t s = lane; s < nsyms; s += 64) hm[w].fr[s] = tf[s] + (t == 0 ? 3u * F[s] : 0u);
         HEAP_ORDER();
         maxlen = build_attempt(hm[w], nsyms, a, lane, dep);
-        if (lane == 0) mx[t][a] = maxlen;
+        if (lane == 0) mx[t][a - lo] = maxlen;
     }
     __syncthreads();
     if (t >= ntab) return;
-    int first = HB_TRIES; // smallest scaling that fits
-    for (int k = HB_TRIES - 1; k >= 0; k--)
-        if (mx[t][k] <= HUF_MAXLEN) first = k;
-    uint8_t *out = bt.lens + ((size_t)b * 3 + t) * HUF_SYMS;
-    if (first == (int)a) store_lengths(out, nsyms, lane, dep);
-    if (first == HB_TRIES && a == 0) build_lengths(hm[w], nsyms, out, lane, HB_TRIES); // (never seen: weights < 2^22)
+    uint32_t first = HB_NONE; // smallest scaling of my half that fits
+    for (int k = (int)per - 1; k >= 0; k--)
+        if (mx[t][k] <= HUF_MAXLEN) first = lo + (uint32_t)k;
+    const size_t slot = ((size_t)half * bt.B + b) * 3 + t;
+    uint8_t *out = bt.lens2 + slot * HUF_SYMS;
+    if (first == a) store_lengths(out, nsyms, lane, dep);
+    if (first == HB_NONE && half && a == lo) { // (scaling 256 / 32 and beyond: the reference's loop, one attempt after the other)
+        build_lengths(hm[w], nsyms, out, lane, t1);
+        first = t1;
+    }
+    if (a == lo && lane == 0) bt.lfit[slot] = first;
 }
 
 // ---- header bit string + canonical codes + bit totals ----------------------------------------------------
@@ -350,6 +365,14 @@ __global__ void __launch_bounds__(192) huff_header(Batch bt)
 {
     const uint32_t b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t ntab = bt.ntab[b], nsyms = bt.nsyms[b], m = bt.m[b];
+    // the table of every attempt-half that found one (huff_build): the lower exponents' if there is one
+    for (uint32_t t = 0; t < ntab; t++) {
+        const uint32_t h = bt.lfit[((size_t)0 * bt.B + b) * 3 + t] != 0xFFFFFFFFu ? 0u : 1u;
+        const uint8_t *src = bt.lens2 + (((size_t)h * bt.B + b) * 3 + t) * HUF_SYMS;
+        uint8_t *dst = bt.lens + ((size_t)b * 3 + t) * HUF_SYMS;
+        for (uint32_t s2 = threadIdx.x; s2 < nsyms; s2 += blockDim.x) dst[s2] = src[s2];
+    }
+    __syncthreads();
     const uint8_t *lens = bt.lens + (size_t)b * 3 * HUF_SYMS;
     uint8_t *hdr = bt.hdr + (size_t)b * HDR_BYTES;
     __shared__ __align__(16) uint8_t tb[3][TB_BYTES];
@@ -894,7 +917,7 @@ int huff_prepare(bzh_ctx *ctx, uint32_t B, uint32_t mmax)
     }
     huff_init<<<dim3(B), 64, 0, st>>>(bt, ranges);
     huff_segments<<<dim3((nsegmax + 255) / 256, B), 256, 0, st>>>(bt, ranges);
-    huff_build<<<dim3(B), 64 * 3 * HB_TRIES, 0, st>>>(bt);
+    huff_build<<<dim3(2, B), 64 * HB_WAVES, 0, st>>>(bt);
     huff_header<<<dim3(B), 192, 0, st>>>(bt);
     block_scan<<<dim3(1), 1024, 0, st>>>(bt, B);
     pack_tilebits<false><<<dim3(ptiles, B), PACK_THREADS, 0, st>>>(bt, PT, selmax);
