@@ -365,15 +365,21 @@ __global__ void __launch_bounds__(192) huff_header(Batch bt)
 {
     const uint32_t b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t ntab = bt.ntab[b], nsyms = bt.nsyms[b], m = bt.m[b];
-    // the table of every attempt-half that found one (huff_build): the lower exponents' if there is one
+    // the table of every attempt-half that found one (huff_build): the lower exponents' if there is one -- to bt.lens for
+    // the kernels behind this one, and into LDS for the serial loops below (one lane per table walks its 258 lengths, one
+    // lane writes the symbol map: from global memory every step was a load of its own -- 50 us a launch, whatever the batch)
+    __shared__ uint8_t ll[3][HUF_SYMS + 6];
     for (uint32_t t = 0; t < ntab; t++) {
         const uint32_t h = bt.lfit[((size_t)0 * bt.B + b) * 3 + t] != 0xFFFFFFFFu ? 0u : 1u;
         const uint8_t *src = bt.lens2 + (((size_t)h * bt.B + b) * 3 + t) * HUF_SYMS;
         uint8_t *dst = bt.lens + ((size_t)b * 3 + t) * HUF_SYMS;
-        for (uint32_t s2 = threadIdx.x; s2 < nsyms; s2 += blockDim.x) dst[s2] = src[s2];
+        for (uint32_t s2 = threadIdx.x; s2 < nsyms; s2 += blockDim.x) {
+            const uint8_t v = src[s2];
+            dst[s2] = v;
+            ll[t][s2] = v;
+        }
     }
     __syncthreads();
-    const uint8_t *lens = bt.lens + (size_t)b * 3 * HUF_SYMS;
     uint8_t *hdr = bt.hdr + (size_t)b * HDR_BYTES;
     __shared__ __align__(16) uint8_t tb[3][TB_BYTES];
     __shared__ uint32_t tbits[3], abits, paybits;
@@ -383,7 +389,7 @@ __global__ void __launch_bounds__(192) huff_header(Batch bt)
         uint32_t *pb = reinterpret_cast<uint32_t *>(hdr + HDR_A);
         for (uint32_t k = lane; k < (HDR_BYTES - HDR_A) / 4; k += 64) pb[k] = 0;
         if (lane < ntab) { // delta-coded table (:509-545)
-            const uint8_t *tl = lens + (size_t)lane * HUF_SYMS;
+            const uint8_t *tl = ll[lane];
             BitW c{tb[lane], 0, 0, 0};
             c.put(tl[0], 5);
             uint32_t acc = tl[0];
@@ -406,8 +412,13 @@ __global__ void __launch_bounds__(192) huff_header(Batch bt)
         // payload bits = sum F[s] * len0[s]
         const uint32_t *F = bt.freqs + (size_t)b * HUF_SYMS;
         uint32_t pay = 0;
-        for (uint32_t s2 = lane; s2 < nsyms; s2 += 64) pay += F[s2] * lens[s2];
+        for (uint32_t s2 = lane; s2 < nsyms; s2 += 64) pay += F[s2] * ll[0][s2];
         pay = wave_reduce_add(pay);
+        // the symbol map's sixteen 16-bit sectors, most significant bit first (:39-64): four ballots over has_byte
+        const uint8_t *hb = bt.hasbyte + (size_t)b * 256;
+        uint64_t hm4[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) hm4[q] = __ballot(hb[q * 64 + lane] != 0);
         if (lane == 0) {
             paybits = pay;
             // part A: block header (lib/lib.rs:24-36), symbol map (:39-64), table count, selector count
@@ -419,11 +430,10 @@ __global__ void __launch_bounds__(192) huff_header(Batch bt)
             a.put(crc & 0xFFFF, 16);
             a.put(0, 1);
             a.put(bt.ptr[b], 24);
-            const uint8_t *hb = bt.hasbyte + (size_t)b * 256;
             uint32_t sector_map = 0, sectors[16], ns = 0;
             for (uint32_t x = 0; x < 16; x++) {
-                uint32_t sec = 0;
-                for (uint32_t y = 0; y < 16; y++) sec = (sec << 1) | (hb[(x << 4) | y] ? 1u : 0u);
+                const uint32_t field = (uint32_t)(hm4[x >> 2] >> (16u * (x & 3u))) & 0xFFFFu; // bit y: byte 16 x + y occurs
+                const uint32_t sec = __brev(field) >> 16;
                 sector_map <<= 1;
                 if (sec) {
                     sector_map |= 1;
@@ -445,7 +455,7 @@ __global__ void __launch_bounds__(192) huff_header(Batch bt)
 #pragma unroll
         for (int q = 0; q < (HUF_SYMS + 63) / 64; q++) {
             const uint32_t s2 = q * 64 + lane;
-            l5[q] = s2 < nsyms ? lens[s2] : 0xFFu;
+            l5[q] = s2 < nsyms ? ll[0][s2] : 0xFFu;
             if (s2 < nsyms) {
                 minl = min(minl, l5[q]);
                 maxl = max(maxl, l5[q]);
