@@ -9,6 +9,8 @@ read once per process.  Exit code 1 on any mismatch."""
 import os
 import sys
 
+if len(sys.argv) > 2 and sys.argv[2] == "nomid":  # the large groups of the bucket-first blocks through the global passes as well (BZH_MID=0)
+    os.environ["BZH_MID"] = "0"
 os.environ["BZH_INIT"] = sys.argv[1] if len(sys.argv) > 1 else "msd"  # "msd": bucket-first where the plan allows it (the default); "lsd": 8 passes everywhere
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

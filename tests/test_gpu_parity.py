@@ -143,6 +143,26 @@ def test_huffman_three_tables_and_rescale(oracle, ctx9):
     assert oracle.build_table_from_freqs(40, freqs).max() <= 17
 
 
+def test_huffman_scaling_attempts_of_both_halves(oracle, ctx9):
+    """huff_build runs the scaling attempts 1, 2, 4, ... of a table side by side, the lower and the upper exponents in two
+    workgroups a block, and huff_header takes the lower half's table if it has one: symbol streams whose counts double from
+    symbol to symbol (codes up to 19 bits at scaling 1) need scaling 8 .. 64 -- tables decided by the lower half, by the
+    upper half, with 2 tables and with 3 (>= 200 symbols)"""
+    rng = np.random.default_rng(17)
+    for top, extra in ((13, 0), (15, 0), (17, 0), (18, 0), (18, 100), (18, 230)):
+        counts = np.array([1 << i for i in range(top + 1)] + [1] * extra, dtype=np.int64)
+        ns = len(counts) + 1
+        s = np.repeat(np.arange(len(counts), dtype=np.uint16), counts)
+        rng.shuffle(s)
+        s = np.concatenate([s, np.array([ns - 1], np.uint16)])
+        f = np.zeros(258, np.uint32)
+        f[:ns] = np.bincount(s, minlength=ns)
+        gbits, gn, glens = ctx9.huffman(s, ns, f)
+        obits, on, olens = oracle.huffman_block(s, ns, f)
+        assert gn == on and gbits == obits and np.array_equal(glens[:, :ns], olens[:, :ns]), (top, extra)
+        assert glens[0, :ns].max() <= 17
+
+
 @pytest.mark.parametrize("level,ctxname", [(1, "ctx1"), (9, "ctx9")])
 def test_rle1_split_and_crc_seam(oracle, request, level, ctxname):
     ctx = request.getfixturevalue(ctxname)
@@ -927,15 +947,17 @@ def test_full_size_other_workloads_bit_exact_vs_oracle(oracle, native):
                 del d_in, d_out
 
 
-@pytest.mark.parametrize("init", ["msd", "lsd"])
+@pytest.mark.parametrize("init", ["msd", "lsd", "msd nomid"])
 def test_both_initial_sorts(native, init):
     """the bucket-first initial sort of bwt_msd.h (the default for text-like blocks) and the 8-pass sort forced on every
     block (BZH_INIT=lsd) are both bit-exact against the oracle on blocks and streams that reach every part of them
-    (scripts/gpu_msd_check.py, a process of its own: the switch is read once per process)"""
+    (scripts/gpu_msd_check.py, a process of its own: the switch is read once per process); "msd nomid": the bucket-first sort
+    with the large groups on the global radix passes (BZH_MID=0) instead of mid_sort -- the path blocks with a group that
+    spans several units always take"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_msd_check.py"), init], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_msd_check.py")] + init.split(), capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "mismatches: 0" in r.stdout
