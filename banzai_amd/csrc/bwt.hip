@@ -2773,7 +2773,11 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         const uint32_t gt = (maxA + SORT_TILE - 1) / SORT_TILE;
         if (!nA || !gt) return;
         hipStream_t sa = st;
-        if (side) {
+        // (round 0 with mid_sort alone -- no block for the global passes, no small-group kernel beside it: it stays on the main
+        // stream, a fork and a join between streams are 20 us)
+        const bool alone = round == 0 && mid_on && have_mid && !have_glob && r0_fused && nOld == 0;
+        const bool forked = side && !alone;
+        if (forked) {
             hipEventRecord(ctx->side_ev[0], st);
             hipStreamWaitEvent(side, ctx->side_ev[0], 0);
             sa = side;
@@ -2802,10 +2806,10 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         a.mid_np = mid_on ? bt.ms_np : nullptr;
         a.mid_spans = mid_on ? msc_row(bt.ms_cnt, B, MSR_SPANS) : nullptr;
         bool on_side2 = false;
-        if (mid && side && round == 0) {
+        if (mid && forked && round == 0) {
             sa = st;
             ctx->stream = st;
-        } else if (mid && side2 && global_path) { // (from round 1 on the main stream is tail_round's: a third stream)
+        } else if (mid && forked && side2 && global_path) { // (from round 1 on the main stream is tail_round's: a third stream)
             hipStreamWaitEvent(side2, ctx->side_ev[0], 0);
             sa = side2;
             ctx->stream = side2;
@@ -2847,7 +2851,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         span_end(ctx, e0);
         } // (global_path)
         a.mid_np = a.mid_spans = nullptr;
-        if (side) {
+        if (forked) {
             ctx->stream = st;
             hipEventRecord(ctx->side_ev[1], side);
             side_busy = true;
