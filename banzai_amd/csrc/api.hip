@@ -180,6 +180,7 @@ static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
     carve(p, bt.hdrbits, NB * 4);
     carve(p, bt.bits, NB);
     carve(p, bt.bitoff, NB + 1);
+    carve(p, bt.packgate, 4);
     carve(p, bt.symbits, NB * PT);
     carve(p, bt.desc, NB);
     { // "fixed" Huffman mode (optional)
@@ -782,7 +783,7 @@ struct RangeJob {
 };
 
 // Everything of a batch up to its bit total, on the lane's stream and arena.
-static int prepare_batch(bzh_ctx *lane, RangeJob &j)
+static int prepare_batch(bzh_ctx *lane, RangeJob &j, bool wait_total = true)
 {
     hipStream_t st = lane->stream;
     auto mark = [&](int i) {
@@ -801,6 +802,7 @@ static int prepare_batch(bzh_ctx *lane, RangeJob &j)
     mark(3);
     BZH_TRY(huff_prepare(lane, j.B, j.mmax));
     mark(4);
+    if (!wait_total) return BZH_OK; // (a call of one batch: the device carries on by itself, encode_range reads the total at the end)
     HIP_TRY(lane, hipMemcpyAsync(&j.T, lane->bt.bitoff + j.B, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(lane, bzh_stream_wait(st));
     return BZH_OK;
@@ -895,11 +897,16 @@ static int encode_range(bzh_ctx *ctx, size_t b0, size_t b1, uint8_t *d_out, size
     uint64_t zeroed_upto = bit_base / 32; // first word not yet known to be zero
     uint64_t cur = 0;
     int status = BZH_OK;
+    // A call of ONE batch (the usual case: up to max_batch blocks) needs the host for nothing between the Huffman tables and
+    // the packed bits: the output words are zeroed, the capacity checked and the pack kernels gated on the device
+    // (huff_pack_gate), and the bit total is read once, at the end -- instead of a copy, a wait, a memset and a launch in the
+    // middle of the step (35-40 us of idle device).
+    const bool one_batch = NL == 1 && jobs.size() == 1;
     for (size_t j = 0; j < jobs.size(); j++) {
         RangeJob &job = *jobs[j];
         bzh_ctx *lane = lanes[j % NL];
         if (NL == 1) { // no worker thread: prepare here
-            job.status = status == BZH_OK ? prepare_batch(lane, job) : BZH_E_STATE;
+            job.status = status == BZH_OK ? prepare_batch(lane, job, !one_batch) : BZH_E_STATE;
             job.ready.set_value();
         }
         job.ready.get_future().wait();
@@ -907,6 +914,37 @@ static int encode_range(bzh_ctx *ctx, size_t b0, size_t b1, uint8_t *d_out, size
             status = job.status;
             if (lane != ctx) bzh_set_error(ctx, "%s", lane->err);
         }
+        if (status == BZH_OK && one_batch) {
+            hipStream_t st = lane->stream;
+            uint64_t *rec = reinterpret_cast<uint64_t *>(lane->h_pinned); // (the first 64 words of the pinned block are free)
+            status = huff_pack_gate(lane, job.B, d_out, bit_base, cap_words, seed_word ? *seed_word : 0u, seed_word != nullptr, rec);
+            if (status == BZH_OK) status = huff_pack(lane, job.B, job.mmax, d_out, bit_base, true);
+            hipError_t he = hipSuccess;
+            std::vector<uint32_t> hm;
+            if (lane->profiling && status == BZH_OK) {
+                job.ev[5] = bzh_event(lane);
+                hipEventRecord(job.ev[5], st);
+                hm.resize(job.B);
+                he = hipMemcpyAsync(hm.data(), lane->bt.m, job.B * 4, hipMemcpyDeviceToHost, st);
+            }
+            if (status == BZH_OK) {
+                if (he == hipSuccess) he = bzh_stream_wait(st);
+                if (he != hipSuccess) {
+                    bzh_set_error(ctx, "pack: %s", hipGetErrorString(he));
+                    status = BZH_E_HIP;
+                } else {
+                    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                    job.T = reinterpret_cast<volatile uint64_t *>(rec)[0];
+                    if (reinterpret_cast<volatile uint64_t *>(rec)[1] == 0) {
+                        bzh_set_error(ctx, "output needs more than %zu bytes", cap);
+                        status = BZH_E_CAP;
+                    } else {
+                        for (uint32_t b = 0; b < (uint32_t)hm.size(); b++) ctx->stats.mtf_syms += hm[b];
+                        cur += job.T;
+                    }
+                }
+            }
+        } else
         if (status == BZH_OK) {
             hipStream_t st = lane->stream;
             const uint64_t need_upto = (bit_base + cur + job.T + 31) / 32 + 1;

@@ -159,6 +159,7 @@ struct Batch {
     uint32_t *hdrbits; // [B][4] bits of part A, selector count, bits of part B, payload bits
     uint64_t *bits;    // [B]   total bits of the block
     uint64_t *bitoff;  // [B+1] exclusive scan of bits
+    uint32_t *packgate; // [1] pack_gate: 1 = the batch's bits fit the output (the pack kernels of a gated call write nothing otherwise)
     uint32_t *symbits; // [B][PT] per pack tile bit counts
     BlockDesc *desc;   // [B]
     // "fixed" Huffman mode only (bzh_set_mode) -- the default path never touches these
@@ -496,7 +497,11 @@ int unbwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax);               // bwt.hip
 int unbwt_compare(bzh_ctx *ctx, uint32_t B, uint32_t nmax, unsigned long long *d_acc); // bwt.hip: bt.rle vs bt.mtfpos
 int mtf_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal = 0); // mtf.hip (ntotal: statistics only)
 int huff_prepare(bzh_ctx *ctx, uint32_t B, uint32_t mmax);            // huffman.hip: tables, header bits, bit totals
-int huff_pack(bzh_ctx *ctx, uint32_t B, uint32_t mmax, uint8_t *d_out, uint64_t bit_base); // huffman.hip
+int huff_pack(bzh_ctx *ctx, uint32_t B, uint32_t mmax, uint8_t *d_out, uint64_t bit_base, bool gated = false); // huffman.hip
+// (one batch, no host in between: zeroes the output words the batch's bits will occupy -- the first one may carry bits owed to
+// it --, checks the capacity on the device and opens or shuts the gate of the pack kernels; hostrec[0] = bits, [1] = fits)
+int huff_pack_gate(bzh_ctx *ctx, uint32_t B, uint8_t *d_out, uint64_t bit_base, uint64_t cap_words, uint32_t seed, bool has_seed,
+                   uint64_t *hostrec);
 int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n, bool with_crc = true); // rle1.hip: tables + split from 0
 int rle1_plan_tables(bzh_ctx *ctx, const uint8_t *d_in, size_t n);                 // rle1.hip
 int rle1_plan_split(bzh_ctx *ctx, size_t start, bool with_crc, size_t stop);      // rle1.hip

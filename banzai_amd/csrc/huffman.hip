@@ -573,8 +573,9 @@ __device__ __forceinline__ void or_be32(uint32_t *out, uint64_t word_idx, uint32
 }
 
 template <bool FX>
-__global__ void __launch_bounds__(PACK_THREADS) pack_symbols(Batch bt, uint32_t PT, uint32_t *out, uint64_t bit_base, uint32_t selmax)
+__global__ void __launch_bounds__(PACK_THREADS) pack_symbols(Batch bt, uint32_t PT, uint32_t *out, uint64_t bit_base, uint32_t selmax, const uint32_t *gate)
 {
+    if (gate && *gate == 0u) return; // (pack_gate: the batch's bits do not fit the output)
     const uint32_t b = blockIdx.y, tile = blockIdx.x;
     const uint32_t m = bt.m[b];
     if (tile * PACK_TILE >= m) return;
@@ -659,8 +660,9 @@ __device__ void or_bits(uint32_t *out, uint64_t pos, const uint8_t *src, uint32_
     }
 }
 
-__global__ void __launch_bounds__(64) pack_headers(Batch bt, uint32_t *out, uint64_t bit_base)
+__global__ void __launch_bounds__(64) pack_headers(Batch bt, uint32_t *out, uint64_t bit_base, const uint32_t *gate)
 {
+    if (gate && *gate == 0u) return;
     const uint32_t b = blockIdx.x, lane = threadIdx.x;
     const uint32_t *hb = bt.hdrbits + (size_t)b * 4;
     const uint8_t *hdr = bt.hdr + (size_t)b * HDR_BYTES;
@@ -669,8 +671,9 @@ __global__ void __launch_bounds__(64) pack_headers(Batch bt, uint32_t *out, uint
     or_bits(out, pos + hb[0] + hb[1], hdr + HDR_A, hb[2], lane);
 }
 
-__global__ void __launch_bounds__(64) fx_pack_headers(Batch bt, uint32_t *out, uint64_t bit_base, uint32_t selbytes)
+__global__ void __launch_bounds__(64) fx_pack_headers(Batch bt, uint32_t *out, uint64_t bit_base, uint32_t selbytes, const uint32_t *gate)
 {
+    if (gate && *gate == 0u) return;
     const uint32_t b = blockIdx.x, lane = threadIdx.x;
     const uint32_t *hb = bt.hdrbits + (size_t)b * 4;
     const uint8_t *hdr = bt.fx_hdr + (size_t)b * FX_HDR_BYTES;
@@ -937,7 +940,34 @@ int huff_prepare(bzh_ctx *ctx, uint32_t B, uint32_t mmax)
 }
 
 // Writes blocks 0..B-1 at bit_base + bitoff[b] of d_out (zero-initialised, 4-byte aligned).
-int huff_pack(bzh_ctx *ctx, uint32_t B, uint32_t mmax, uint8_t *d_out, uint64_t bit_base)
+// What encode_range does on the host between two batches -- read the batch's bit total, check the capacity, zero the words
+// the bits will be ORed into, seed the first word -- for a call of one batch, on the device: T = bitoff[B].
+__global__ void __launch_bounds__(256) pack_gate(uint32_t *out, uint64_t bit_base, const uint64_t *T, uint64_t cap_words, uint32_t seed,
+                                                 uint32_t has_seed, uint32_t *gate, uint64_t *hostrec)
+{
+    const uint64_t t = *T, w0 = bit_base / 32, need = (bit_base + t + 31) / 32 + 1;
+    const bool ok = need <= cap_words;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *gate = ok ? 1u : 0u;
+        hostrec[0] = t;
+        hostrec[1] = ok ? 1ull : 0ull;
+    }
+    if (!ok) return;
+    for (uint64_t w = w0 + (uint64_t)blockIdx.x * 256 + threadIdx.x; w < need; w += (uint64_t)gridDim.x * 256)
+        out[w] = (w == w0 && has_seed) ? seed : 0u;
+}
+
+int huff_pack_gate(bzh_ctx *ctx, uint32_t B, uint8_t *d_out, uint64_t bit_base, uint64_t cap_words, uint32_t seed, bool has_seed,
+                   uint64_t *hostrec)
+{
+    Batch &bt = ctx->bt;
+    pack_gate<<<dim3(2048), 256, 0, ctx->stream>>>(reinterpret_cast<uint32_t *>(d_out), bit_base, bt.bitoff + B, cap_words, seed, has_seed ? 1u : 0u,
+                                                   bt.packgate, hostrec);
+    HIP_TRY(ctx, hipGetLastError());
+    return BZH_OK;
+}
+
+int huff_pack(bzh_ctx *ctx, uint32_t B, uint32_t mmax, uint8_t *d_out, uint64_t bit_base, bool gated)
 {
     KSpan ks(ctx, K_PACK, 3 * (uint64_t)ctx->k_cur_ntotal, 2); // symbols in, about a third of a byte out per symbol
     Batch &bt = ctx->bt;
@@ -947,13 +977,14 @@ int huff_pack(bzh_ctx *ctx, uint32_t B, uint32_t mmax, uint8_t *d_out, uint64_t 
     const uint32_t ptiles = (mmax + PACK_TILE - 1) / PACK_TILE;
     uint32_t *out = reinterpret_cast<uint32_t *>(d_out);
     const uint32_t selmax = (bt.S + 64 + 49) / 50 + 2;
+    const uint32_t *gate = gated ? bt.packgate : nullptr;
     if (ctx->mode == BZH_MODE_FIXED) {
         const uint32_t selbytes = (uint32_t)((((size_t)selmax * 6 + 7) / 8 + 8 + 63) / 64 * 64);
-        pack_symbols<true><<<dim3(ptiles, B), PACK_THREADS, 0, st>>>(bt, PT, out, bit_base, selmax);
-        fx_pack_headers<<<dim3(B), 64, 0, st>>>(bt, out, bit_base, selbytes);
+        pack_symbols<true><<<dim3(ptiles, B), PACK_THREADS, 0, st>>>(bt, PT, out, bit_base, selmax, gate);
+        fx_pack_headers<<<dim3(B), 64, 0, st>>>(bt, out, bit_base, selbytes, gate);
     } else {
-        pack_symbols<false><<<dim3(ptiles, B), PACK_THREADS, 0, st>>>(bt, PT, out, bit_base, selmax);
-        pack_headers<<<dim3(B), 64, 0, st>>>(bt, out, bit_base);
+        pack_symbols<false><<<dim3(ptiles, B), PACK_THREADS, 0, st>>>(bt, PT, out, bit_base, selmax, gate);
+        pack_headers<<<dim3(B), 64, 0, st>>>(bt, out, bit_base, gate);
     }
     HIP_TRY(ctx, hipGetLastError());
     return BZH_OK;
