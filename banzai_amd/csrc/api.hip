@@ -824,7 +824,7 @@ static int encode_range(bzh_ctx *ctx, size_t b0, size_t b1, uint8_t *d_out, size
         lanes = ctx->lanes;
     }
     const size_t NL = lanes.size();
-    HIP_TRY(ctx, bzh_stream_wait(ctx->stream)); // the plan and whatever produced the input
+    if (NL > 1) HIP_TRY(ctx, bzh_stream_wait(ctx->stream)); // the plan and whatever produced the input: the lanes' streams start behind it (one lane = this stream: in order anyway)
     const bzh_stats stats_in = ctx->stats;
     const size_t nb = b1 - b0;
     const uint32_t lane_mb = lanes[0]->max_batch;
