@@ -83,7 +83,7 @@ enum { BZH_MODE_REFERENCE = 0, BZH_MODE_FIXED = 1 };
 BZH_API int bzh_set_mode(bzh_ctx *ctx, int mode);
 /* 1 (default): batches run one after the other on the context's stream.  2: two half-batch lanes on
  * internal streams and host threads.  Measured on the 100 MB headline (one batch split in two): 2 lanes are 3-5 % SLOWER
- * than 1 (round 5: 9.09-9.32 against 8.41-8.49 ms; the per-batch latency chains -- huff_build, the late doubling rounds -- are paid
+ * than 1 (round 5: 8.73-8.93 against 8.34-8.41 ms; the per-batch latency chains -- huff_build, the late doubling rounds -- are paid
  * twice and overlap less than they cost); kept for experiments only. */
 BZH_API int bzh_set_lanes(bzh_ctx *ctx, int lanes);
 BZH_API int bzh_get_stats(const bzh_ctx *ctx, bzh_stats *out);
