@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5 baseline / quick look at the working copy on one box: stream check, kernel table + timeline of the headline,
-# per-round trace of the headline and of real text.   scripts/r5_base.sh [tag]
+# per-round trace of the headline and of real text.   scripts/r5/r5_base.sh [tag]
 cd $GRAFT_REPO_ROOT
 TAG=${1:-base}
 python scripts/gpu_encode_check.py 2>&1 | tail -2

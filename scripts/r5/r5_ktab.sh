@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel table of one workload (default enwik) under rocprofv3: scripts/r5_ktab.sh [workload] [rows]
+# kernel table of one workload (default enwik) under rocprofv3: scripts/r5/r5_ktab.sh [workload] [rows]
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 W=${1:-enwik}
 rm -rf gpurun_out/prof_k
