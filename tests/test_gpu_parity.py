@@ -963,6 +963,19 @@ def test_both_initial_sorts(native, init):
     assert "mismatches: 0" in r.stdout
 
 
+@pytest.mark.parametrize("init", ["msd", "lsd", "default"])
+def test_exactly_periodic_text_blocks(native, init):
+    """a stretch of text repeated k times (2 .. 113), shorter than a block: groups of k identical rotations that only the tie
+    rule orders, on both initial sorts and through both paths of the large groups (scripts/gpu_exact_period.py, a process of
+    its own: the switch is read once per process)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_exact_period.py"), init], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "bad: 0" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 @pytest.mark.gpu
 def test_coverage_guided_corpus(oracle, native):
     """the corpus a coverage-guided fuzzing session of the CPU oracle left (tests/golden/fuzz_corpus.zip, oracle/covfuzz.c)
