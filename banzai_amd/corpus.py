@@ -161,7 +161,7 @@ V2_PHRASE_PROB = 0.15     # calibrated so that bzip2 -9 of the 100,000,000-byte 
 V2_REPEAT_FRACTION = 0.03
 
 
-def enwik_synthetic_v2(n, seed=20061):
+def enwik_synthetic_v2(n, seed=20061, repeat_fraction=None):
     """"enwik8-synthetic-v2": the stand-in for enwik8 the bench quotes its headline on.
 
     Stated model: tokens are drawn i.i.d. -- with probability V2_PHRASE_PROB a reusable phrase (2..9 words, phrase
@@ -192,7 +192,9 @@ def enwik_synthetic_v2(n, seed=20061):
         take = min(total, n - pos)
         out[pos:pos + take] = vflat[src[:take]]
         pos += take
-    budget = int(n * V2_REPEAT_FRACTION)
+    # (repeat_fraction: the bench's sensitivity rows -- how the throughput depends on the share of copied bytes, which sets
+    # the depth of the suffix sort; the headline uses the calibrated V2_REPEAT_FRACTION)
+    budget = int(n * (V2_REPEAT_FRACTION if repeat_fraction is None else repeat_fraction))
     while budget > 0 and n > 200_000:
         ln = int(np.exp(rng.uniform(np.log(200), np.log(60000))))
         dist = int(np.exp(rng.uniform(np.log(ln + 1), np.log(600_000))))

@@ -94,6 +94,28 @@ extern "C" const char *bzh_last_error(const bzh_ctx *cctx)
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// The context's second stream with its events (the suffix sort's big-list path, the plan's CRCs), created on first use.
+hipStream_t bzh_side_stream(bzh_ctx *ctx)
+{
+    if (ctx->side_stream) return ctx->side_stream;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int k = 0; k < 4; k++) {
+        if (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) {
+            for (int j = 0; j < k; j++) hipEventDestroy(ev[j]);
+            hipStreamDestroy(s);
+            return nullptr;
+        }
+    }
+    ctx->side_ev[0] = ev[0];
+    ctx->side_ev[1] = ev[1];
+    ctx->plan_ev[0] = ev[2];
+    ctx->plan_ev[1] = ev[3];
+    ctx->side_stream = s;
+    return s;
+}
+
 template <typename T>
 static void carve(uint8_t *&p, T *&dst, size_t count)
 {
@@ -183,6 +205,7 @@ static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
     carve(p, bt.packgate, 4);
     carve(p, bt.symbits, NB * PT);
     carve(p, bt.desc, NB);
+    bt.pdesc = bt.desc; // (rle1_emit points it at the plan's descriptors of the batch)
     { // "fixed" Huffman mode (optional)
         const size_t selmax = (S + 64 + 49) / 50 + 2;
         carve(p, bt.fx_tfreq, NB * FX_TABLES * 258);
@@ -237,8 +260,12 @@ extern "C" int bzh_create(bzh_ctx **out, int device, int level, int max_batch)
     ctx->device = device;
     ctx->level = level;
     ctx->M = 100000u * (uint32_t)level - 1u; // lib/rle.rs:121
-    // default: a batch covers about 115 MB of RLE1 output at every level (128 level-9 blocks)
-    ctx->max_batch = max_batch ? (uint32_t)max_batch : std::min<uint32_t>(1024u, 128u * 9u / (uint32_t)level);
+    // default: a batch covers about 520 MB of RLE1 output at level 9 (576 blocks; 1,024 blocks from level 5 down).  A pass
+    // costs about half a millisecond of latency chains whatever its size (the plan, the late doubling rounds, the Huffman
+    // heaps), so a long stream is cheaper in few, large batches -- 1 GB on one MI355X: 87.8 ms in batches of 128 blocks,
+    // 81.6 ms in 256s, 78.2 ms in 576s (profiles/r06_multibatch.txt).  The arena is sized for the batch actually planned
+    // (ensure_arena: 45 MB a block), so only an input that fills such a batch pays for it: 26 GB of 288 GB.
+    ctx->max_batch = max_batch ? (uint32_t)max_batch : std::min<uint32_t>(1024u, 576u * 9u / (uint32_t)level);
     // a streaming pass is worth launching once a full batch of input is pending
     ctx->strm.min_feed = std::min<size_t>((size_t)128 << 20, (size_t)ctx->max_batch * (ctx->M + 1));
     Batch probe{};
@@ -247,7 +274,7 @@ extern "C" int bzh_create(bzh_ctx **out, int device, int level, int max_batch)
         delete ctx;
         return BZH_E_ARG;
     }
-    // The workspace arena (about 45 MB per block of a batch, 5.8 GB for 128 level-9 blocks) is NOT allocated here:
+    // The workspace arena (about 45 MB per block of a batch, 5.8 GB for the 112 blocks of a 100 MB input) is NOT allocated here:
     // ensure_arena sizes it for the batches actually planned, so a 1 MB file does not pay for a 128-block arena.
     ctx->S = probe.S;
     ctx->bt.S = probe.S;
@@ -284,6 +311,8 @@ extern "C" void bzh_destroy(bzh_ctx *ctx)
         hipStreamSynchronize(c->side_stream);
         hipEventDestroy(c->side_ev[0]);
         hipEventDestroy(c->side_ev[1]);
+        hipEventDestroy(c->plan_ev[0]);
+        hipEventDestroy(c->plan_ev[1]);
         hipStreamDestroy(c->side_stream);
         c->side_stream = nullptr;
         if (c->side2_stream) {
@@ -646,6 +675,7 @@ extern "C" int bzh_huffman(bzh_ctx *ctx, const uint16_t *syms, size_t m, uint32_
     HIP_TRY(ctx, hipMemcpyAsync(bt.freqs, freqs, 258 * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(bt.hasbyte, hb, 256, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(bt.desc, &d, sizeof d, hipMemcpyHostToDevice, st));
+    bt.pdesc = bt.desc;
     HIP_TRY(ctx, hipMemcpyAsync(bt.ptr, &zero, 4, hipMemcpyHostToDevice, st));
     BZH_TRY(huff_prepare(ctx, 1, m32));
     uint64_t total = 0;
@@ -800,6 +830,10 @@ static int prepare_batch(bzh_ctx *lane, RangeJob &j, bool wait_total = true)
     mark(2);
     BZH_TRY(mtf_run(lane, j.B, j.nmax, j.ntotal));
     mark(3);
+    {   // the block headers carry the block CRCs: a whole-path plan left them to the owner's second stream (rle1_plan_split)
+        bzh_ctx *pc = lane->parent ? lane->parent : lane;
+        if (pc->crc_pending) HIP_TRY(lane, hipStreamWaitEvent(st, pc->plan_ev[1], 0));
+    }
     BZH_TRY(huff_prepare(lane, j.B, j.mmax));
     mark(4);
     if (!wait_total) return BZH_OK; // (a call of one batch: the device carries on by itself, encode_range reads the total at the end)
@@ -918,7 +952,10 @@ static int encode_range(bzh_ctx *ctx, size_t b0, size_t b1, uint8_t *d_out, size
             hipStream_t st = lane->stream;
             uint64_t *rec = reinterpret_cast<uint64_t *>(lane->h_pinned); // (the first 64 words of the pinned block are free)
             status = huff_pack_gate(lane, job.B, d_out, bit_base, cap_words, seed_word ? *seed_word : 0u, seed_word != nullptr, rec);
-            if (status == BZH_OK) status = huff_pack(lane, job.B, job.mmax, d_out, bit_base, true);
+            if (status == BZH_OK) {
+                status = huff_pack(lane, job.B, job.mmax, d_out, bit_base, true);
+                if (status != BZH_OK) (void)bzh_stream_wait(st); // (pack_gate is queued: nothing of this call may still run when the error is reported)
+            }
             hipError_t he = hipSuccess;
             std::vector<uint32_t> hm;
             if (lane->profiling && status == BZH_OK) {
@@ -1213,7 +1250,7 @@ extern "C" int bzh_encode_device(bzh_ctx *ctx, const void *d_in, size_t n, void 
         hipEventRecord(t0, st);
     }
     BZH_TRY(check_in_ptr(ctx, d_in));
-    BZH_TRY(rle1_plan(ctx, (const uint8_t *)d_in, n));
+    BZH_TRY(rle1_plan(ctx, (const uint8_t *)d_in, n, true, true)); // (the block CRCs beside the main stream: joined below)
     if (ctx->profiling) {
         t1 = bzh_event(ctx);
         hipEventRecord(t1, st);
@@ -1235,6 +1272,7 @@ extern "C" int bzh_encode_device(bzh_ctx *ctx, const void *d_in, size_t n, void 
     if (zero_to * 4 > cap) return BZH_E_CAP;
     if (zero_to > zero_from && nb)
         HIP_TRY(ctx, hipMemsetAsync((uint8_t *)d_out + zero_from * 4, 0, (size_t)(zero_to - zero_from) * 4, st));
+    BZH_TRY(rle1_plan_crc_join(ctx));
     std::vector<uint32_t> crcs(nb);
     for (size_t k = 0; k < nb; k++) crcs[k] = ctx->plan_blocks[k].crc;
     stream_frame<<<1, 64, 0, st>>>((uint32_t *)d_out, ctx->level, body, fold_stream_crc(crcs.data(), nb));
@@ -1431,7 +1469,7 @@ static void stream_pass(bzh_ctx *ctx)
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         hipStream_t st = ctx->stream;
         const uint8_t *buf = s.d_buf[p.buf] + p.off;
-        BZH_TRY(rle1_plan(ctx, buf, p.total));
+        BZH_TRY(rle1_plan(ctx, buf, p.total, true, true));
         const size_t nb = ctx->plan_blocks.size();
         size_t F = nb; // blocks that are final
         if (!p.eof) {
@@ -1472,6 +1510,7 @@ static void stream_pass(bzh_ctx *ctx)
             const uint8_t *w = s.h_out;
             p.lastw = ((uint32_t)w[0] << 24) | ((uint32_t)w[1] << 16) | ((uint32_t)w[2] << 8) | w[3];
         }
+        BZH_TRY(rle1_plan_crc_join(ctx));
         for (size_t k = 0; k < F; k++) p.crcs.push_back(ctx->plan_blocks[k].crc);
         return BZH_OK;
     });

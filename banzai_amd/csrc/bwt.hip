@@ -67,6 +67,14 @@ enum GenMode : int {
     GEN_LCOL = 4    // inverse BWT: element e is position e of the last column, keyed by its byte
 };
 
+// Timing experiments that leave parts of a kernel out (wrong results on purpose) exist in builds made with
+// -DBZH_EXPERIMENTS only; the product build has neither the branches nor the environment variables.
+#ifdef BZH_EXPERIMENTS
+#define BZH_DBG(x) (x)
+#else
+#define BZH_DBG(x) 0u
+#endif
+
 constexpr u64 SUF_MASK = 0xFFFFFull;
 constexpr uint32_t H_DONE = 1u << 30; // depth that stands for "h >= n"
 
@@ -128,6 +136,7 @@ struct SortArgs {
     const uint32_t *chain; // [B][4] near-periodic blocks (period_probe): flags, period, tails that lead the order
     const uint32_t *clist; // [B][2S] those tails, then the other tails, ascending (the block's listD)
     uint32_t fault;        // test hook (bzh_debug_fault): 1 = tile 1 of block 0 never publishes its digit counts
+    uint32_t patient;      // 1: the pinned retry after a look-back gave up -- waits are bounded by LOOK_TICKS_PATIENT
     // big-list rounds with numbered groups: *gwide == 0 -> the keys are 32 bits, four passes, and the passes run over the
     // buffers named here instead (active_gen wrote in place; a null src_n: this pass is not needed)
     const uint32_t *gwide; // the word of THIS round (bt.gwide + (round & 1))
@@ -457,6 +466,11 @@ __global__ void __launch_bounds__(256) active_bases(uint32_t *dtot, uint32_t *db
 // 100 MHz clock (s_memrealtime) is read every 64th idle spin; LOOK_TICKS = 20 ms, then the caller raises bit 1 of the
 // error word and bwt_run starts over with every block pinned to one XCD.
 constexpr unsigned long long LOOK_TICKS = 2000000ull, LOOK_TICKS_FAULT = 100000ull; // (injected faults: 1 ms)
+// The clock keeps running while the queue is preempted (another process time-slicing the GPU, a profiler serialising
+// kernels), so a waiter and its also-preempted predecessor can both expire with no logic error.  In the pinned retry a
+// tile only ever waits for a workgroup that is resident already -- no deadlock is possible there -- so the retry waits
+// seconds, not milliseconds: a correct encode does not fail because of scheduling (SortArgs / RefineArgs::patient).
+constexpr unsigned long long LOOK_TICKS_PATIENT = 3000000000ull; // 30 s
 struct LookWait {
     unsigned long long t0 = 0;
     uint32_t spins = 0;
@@ -488,7 +502,7 @@ __device__ __forceinline__ u64 look2_word(uint32_t pass, uint32_t state, uint32_
 // flight at once a one-tile-at-a-time walk is a chain of hundreds of dependent loads).  Publishes the tile's own
 // status words on the way.  Status word: [pass:32][state:2][count:30].  Returns the prefix in every lane.
 __device__ __forceinline__ uint32_t lookback_wave(u64 *st, uint32_t tile, uint32_t pass, uint32_t own, uint32_t *err,
-                                                   bool published = false)
+                                                   bool published, unsigned long long budget)
 {
     const int lane = threadIdx.x & 63;
     uint32_t acc = 0;
@@ -511,7 +525,7 @@ __device__ __forceinline__ uint32_t lookback_wave(u64 *st, uint32_t tile, uint32
             if (gl) break;
             t -= first_nr;
             if (first_nr == 0) {
-                if (lw.expired()) { // 20 ms: only a logic error or a shared GPU gets here
+                if (lw.expired(budget)) { // 20 ms: only a logic error or a shared GPU gets here
                     if (lane == 0) atomicOr(err, 2u);
                     break;
                 }
@@ -712,7 +726,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
         }
     }
     if (MODE == GEN_GID && wave == NW - 1) { // (the digits keep the first NB threads busy)
-        const uint32_t pre = lookback_wave(a.gst + (size_t)b * a.TPB * 2, tile, a.pass, gid_total, a.err, true);
+        const uint32_t pre = lookback_wave(a.gst + (size_t)b * a.TPB * 2, tile, a.pass, gid_total, a.err, true, a.patient ? LOOK_TICKS_PATIENT : LOOK_TICKS);
         if (lane == 0) ls[NW + 1] = pre;
     }
     if (threadIdx.x < NB) { // look back for the counts of digit `bin` in tiles 0 .. tile-1
@@ -725,7 +739,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter(SortArgs a)
             const u64 w = __hip_atomic_load(col + (size_t)t * NBMAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t state = (uint32_t)(w >> 30) & 3u;
             if ((uint32_t)(w >> 32) != a.pass || state == 0) { // predecessor has not published yet
-                if (lw.expired(a.fault ? LOOK_TICKS_FAULT : LOOK_TICKS)) { // only a logic error or a shared GPU gets here
+                if (lw.expired(a.fault ? LOOK_TICKS_FAULT : a.patient ? LOOK_TICKS_PATIENT : LOOK_TICKS)) { // only a logic error or a shared GPU gets here
                     atomicOr(a.err, 2u);
                     break;
                 }
@@ -770,6 +784,7 @@ struct RefineArgs {
     u64 *carry;          // refine_one: [B][TPB][2] tile status words of the carry look-back (slot 1 of a pair)
     uint32_t bpass;      // refine_one<init>: pass id of the rank binning's status words (rows of cstat)
     uint32_t *err;       // bit 1: a look-back gave up
+    uint32_t patient;    // 1: the pinned retry (LOOK_TICKS_PATIENT)
     const uint8_t *blk;  // [B][S] the text (init pass: low half of the 8-byte prefix is compared from it)
     uint8_t *bwt;        // [B][S] the last column (init pass: the bytes of the rotations it resolves)
     uint32_t *rank;      // [B][S]
@@ -1034,7 +1049,7 @@ __global__ void __launch_bounds__(SORT_THREADS) refine(RefineArgs a)
                 const u64 w = __hip_atomic_load(cst + (size_t)t * NBMAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t state = (uint32_t)(w >> 42) & 3u;
                 if ((uint32_t)(w >> 44) != (a.cpass & 0xFFFFFu) || state == 0) {
-                    if (lw.expired()) {
+                    if (lw.expired(a.patient ? LOOK_TICKS_PATIENT : LOOK_TICKS)) {
                         atomicOr(a.err, 2u);
                         break;
                     }
@@ -1182,7 +1197,7 @@ constexpr int POS_FAR = INT32_MAX; // "no boundary within reach"
 // Carries of a tile: last group start / last boundary in any earlier tile of the block (-1: none).  Run by one
 // whole wavefront; lane j inspects tile t - j.  Status word: look2_word(pass, state, start + 1, boundary + 1).
 __device__ __forceinline__ void carry_lookback(u64 *st, uint32_t tile, uint32_t pass, int own_gs, int own_bd, bool need_gs,
-                                               int &cg, int &cd, uint32_t *err) // st: one word per tile, 2 words apart
+                                               int &cg, int &cd, uint32_t *err, unsigned long long budget) // st: one word per tile, 2 words apart
 {
     const int lane = threadIdx.x & 63;
     const uint32_t egs = (uint32_t)(own_gs + 1), ebd = (uint32_t)(own_bd + 1);
@@ -1220,7 +1235,7 @@ __device__ __forceinline__ void carry_lookback(u64 *st, uint32_t tile, uint32_t 
             if (hb && hg) break;
             t -= first_nr;
             if (first_nr == 0) {
-                if (lw.expired()) {
+                if (lw.expired(budget)) {
                     if (lane == 0) atomicOr(err, 2u);
                     break;
                 }
@@ -1330,7 +1345,7 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
         int cgi = -1, cdi = -1;
         if (!midb)
             carry_lookback(a.carry + (size_t)b * a.TPB * 2 + 1, tile, a.cpass, ex0[SORT_THREADS - 1], ex1[SORT_THREADS - 1], !INIT,
-                           cgi, cdi, a.err);
+                           cgi, cdi, a.err, a.patient ? LOOK_TICKS_PATIENT : LOOK_TICKS);
         if (lane == 0) {
             s_cg = cgi;
             s_cd = cdi;
@@ -1557,7 +1572,7 @@ __global__ void __launch_bounds__(SORT_THREADS) refine_one(RefineArgs a, uint32_
             const u64 w = __hip_atomic_load(col + (size_t)t * NBMAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t state = (uint32_t)(w >> 30) & 3u;
             if ((uint32_t)(w >> 32) != a.bpass || state == 0) { // predecessor has not published yet
-                if (lw.expired()) {
+                if (lw.expired(a.patient ? LOOK_TICKS_PATIENT : LOOK_TICKS)) {
                     atomicOr(a.err, 2u);
                     break;
                 }
@@ -1614,7 +1629,7 @@ struct TailArgs {
     uint32_t *c_tail;    // [B] survivors of the round
     uint32_t *c_prog;    // [B] "a group was refined"
     uint32_t tag;        // this round's id in the rank words
-    uint32_t dbg;        // timing experiments only (BZH_TAIL_DBG: 1 = no ranking loop, 2 = no rank stores, 4 = no key gather; wrong results)
+    uint32_t dbg;        // builds with -DBZH_EXPERIMENTS only (BZH_TAIL_DBG: 1 = no ranking loop, 2 = no rank stores, 4 = no key gather; wrong results)
     uint32_t *err;       // [1] precondition violations
     const uint32_t *hb;  // [B] depth h of each block
     uint32_t S, T;
@@ -1674,7 +1689,7 @@ __global__ void __launch_bounds__(TR_THREADS) tail_round(TailArgs a)
                 if (h < n) {
                     uint32_t i2 = i + h;
                     if (i2 >= n) i2 -= n;
-                    const uint32_t k2 = (a.dbg & 4u) ? i2 * 2654435761u >> 12 : rank_at(rank[rslot(i2)], tag);
+                    const uint32_t k2 = BZH_DBG(a.dbg & 4u) ? i2 * 2654435761u >> 12 : rank_at(rank[rslot(i2)], tag);
                     key = (key_t)k2;
                     if (QUAD) { // two more h-blocks of the (cyclic) rotation
                         uint32_t i3 = i2 + h;
@@ -1733,7 +1748,7 @@ __global__ void __launch_bounds__(TR_THREADS) tail_round(TailArgs a)
             }
             const key_t my = K[w];
             uint32_t less = 0, eq = 0, eqb = 0;
-            if (a.dbg & 1u) ge = g;
+            if (BZH_DBG(a.dbg & 1u)) ge = g;
 #pragma unroll 4
             for (uint32_t f = g; f < ge; f++) { // bounds known up front: the LDS reads pipeline
                 const key_t kf = K[f];
@@ -1748,7 +1763,7 @@ __global__ void __launch_bounds__(TR_THREADS) tail_round(TailArgs a)
                 // only if the rank moved: nobody reads the "resolved" bit of a block in SPLIT mode (the SA-order
                 // enumeration of SWEEP mode is its one reader), and a random 4-byte store is the most expensive
                 // thing this kernel does (it leaves the XCD as a partial 64-byte write).
-                if (less && !(a.dbg & 2u)) rank[rslot(ci[k])] = rank_word(cr[k], less, tag, single);
+                if (less && !BZH_DBG(a.dbg & 2u)) rank[rslot(ci[k])] = rank_word(cr[k], less, tag, single);
                 nsurv += single ? 0u : 1u;
             }
             res[k] = (owned ? 0x80000000u : 0u) | (single ? 0x40000000u : 0u) | (less << 24) | (g + less + eqb);
@@ -2210,9 +2225,11 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
 
 // ---- one launch clears everything a sort starts from ---------------------------------------------------------------
 // (a hipMemsetAsync is a kernel of its own, about 5 us each back to back: eight of them were 45 us of every step)
+constexpr int CLEAR_MAX = 16;
 struct ClearArgs {
-    uint4 *p[12];         // 16-byte aligned regions (carved at 256-byte boundaries)
-    unsigned long long q[12]; // their lengths in 16-byte words, as a running total (region k = [q[k-1], q[k]))
+    uint4 *p[CLEAR_MAX];         // 16-byte aligned regions (carved at 256-byte boundaries: layout_batch, api.hip -- a length
+                                 // rounded up to 16 bytes stays inside the region's own carve)
+    unsigned long long q[CLEAR_MAX]; // their lengths in 16-byte words, as a running total (region k = [q[k-1], q[k]))
     int n;
 };
 __global__ void __launch_bounds__(256) bwt_clear(ClearArgs c)
@@ -2226,9 +2243,14 @@ __global__ void __launch_bounds__(256) bwt_clear(ClearArgs c)
 }
 struct ClearList {
     ClearArgs a{};
+    bool overflow = false; // a region that found no room: the caller must not launch (state would stay uncleared)
     void add(void *p, size_t bytes)
     {
-        if (!bytes || a.n >= 12) return;
+        if (!bytes) return;
+        if (a.n >= CLEAR_MAX) {
+            overflow = true;
+            return;
+        }
         a.p[a.n] = reinterpret_cast<uint4 *>(p);
         a.q[a.n] = (a.n ? a.q[a.n - 1] : 0ull) + (bytes + 15) / 16; // (regions end at 256-byte boundaries of the arena: rounding up stays inside)
         a.n++;
@@ -2421,6 +2443,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     a.gst = reinterpret_cast<u64 *>(bt.tagg); // (flag_tiles / flag_carry use it after the initial sort only)
     a.chain = bt.chain;
     a.fault = ctx->debug_fault; // (one batch only)
+    a.patient = ctx->no_spread ? 1u : 0u;
     const bool had_fault = a.fault == 1u; // (kind 2: the fault of a shared GPU -- the sort is expected to recover by itself)
     ctx->debug_fault = 0;
     a.clist = reinterpret_cast<const uint32_t *>(bt.listD); // (a block in SWEEP mode has no small-group lists)
@@ -2447,15 +2470,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     static const bool no_overlap = getenv("BZH_NO_OVERLAP") != nullptr;
     hipStream_t side = nullptr;
     if (!ctx->profiling && !no_overlap) {
-        if (!ctx->side_stream) {
-            if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) ctx->side_stream = nullptr;
-            if (ctx->side_stream && (hipEventCreateWithFlags(&ctx->side_ev[0], hipEventDisableTiming) != hipSuccess ||
-                                     hipEventCreateWithFlags(&ctx->side_ev[1], hipEventDisableTiming) != hipSuccess)) {
-                hipStreamDestroy(ctx->side_stream);
-                ctx->side_stream = nullptr;
-            }
-        }
-        side = ctx->side_stream;
+        side = bzh_side_stream(ctx);
         if (side && !ctx->side2_stream) { // (optional: without it the global passes follow mid_sort on the second stream)
             if (hipStreamCreateWithFlags(&ctx->side2_stream, hipStreamNonBlocking) != hipSuccess) ctx->side2_stream = nullptr;
             if (ctx->side2_stream && hipEventCreateWithFlags(&ctx->side_ev[2], hipEventDisableTiming) != hipSuccess) {
@@ -2499,6 +2514,10 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         clr.add(bt.ms_bgcur, (size_t)B * MS_BG * sizeof(uint32_t));
     } else {
         clr.add(bt.ms_np, (size_t)B * sizeof(uint32_t));
+    }
+    if (clr.overflow) { // (more regions than the clearing kernel takes: sort state would stay dirty -- loud, not wrong bytes)
+        bzh_set_error(ctx, "BWT: the clearing list is full (internal error)");
+        return BZH_E_HIP;
     }
     clr.launch(st);
     if (use_msd) {
@@ -2582,6 +2601,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     r.carry = reinterpret_cast<u64 *>(bt.tagg);
     r.cpass = ++a.pass;
     r.err = bt.errflag;
+    r.patient = a.patient;
     r.lst = oldl;
     // lists of every block + (rank word, suffix) pairs in list order; the blocks that start in SWEEP mode get their
     // SA order and digit bases in round 0 (below)
@@ -2649,7 +2669,9 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     ta.err = bt.errflag;
     ta.hb = bt.st_h;
     ta.S = bt.S;
+#ifdef BZH_EXPERIMENTS
     ta.dbg = getenv("BZH_TAIL_DBG") ? (uint32_t)atoi(getenv("BZH_TAIL_DBG")) : 0u;
+#endif
 
     // ---- doubling rounds, queued one ahead of the summaries ---------------------------------------------
     // round_begin writes its summary straight into pinned host memory and sets the record's last word to
@@ -2768,6 +2790,10 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             sp = side;
         }
         mid_plan<<<dim3(B), 256, 0, sp>>>(mp, 0u);
+        if (side) { // (the plan is part of what the second stream was given: join_side, fail_wait and the end of the sort wait for it)
+            hipEventRecord(ctx->side_ev[1], side);
+            side_busy = true;
+        }
     };
     auto run_A = [&](uint32_t round) {
         const uint32_t gt = (maxA + SORT_TILE - 1) / SORT_TILE;
@@ -2799,7 +2825,10 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         if (mid) {
             KSpan ks(ctx, K_MID_SORT, 0); // (the tiles were planned behind the refinement that wrote the lists: plan_ahead)
             MidArgs ma{cur, bt.rank, bt.st_h, bt.gateA, a.tag, msc_tiles(bt.ms_cnt, B), msc_row(bt.ms_cnt, B, MSR_MTILES), msc_row(bt.ms_cnt, B, MSR_SPANS),
-                       bt.ms_np, bt.n, msc_row(bt.ms_cnt, B, MSR_MTICKET), bt.errflag, bt.S, B, getenv("BZH_MID_DBG") ? (uint32_t)atoi(getenv("BZH_MID_DBG")) : 0u};
+                       bt.ms_np, bt.n, msc_row(bt.ms_cnt, B, MSR_MTICKET), bt.errflag, bt.S, B, 0u};
+#ifdef BZH_EXPERIMENTS
+            ma.dbg = getenv("BZH_MID_DBG") ? (uint32_t)atoi(getenv("BZH_MID_DBG")) : 0u;
+#endif
             mid_sort<<<dim3(round ? 256 : 512), MS_THREADS, 0, sa>>>(ma);
         }
         const bool global_path = !mid_on || have_glob;

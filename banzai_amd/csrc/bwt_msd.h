@@ -1116,7 +1116,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
         for (int k = 0; k < KH; k++) {
             const uint32_t w = k * MS_THREADS + tq3;
             kk[k] = 0ull;
-            if (fuse && w < len && (gi[k] >> 30) == CLS_SMALL) kk[k] = (m.dbg & 32u) ? (u64)sf[k] * 0x9E3779B97F4A7C15ull : ms_key8(txt, sf[k], n);
+            if (fuse && w < len && (gi[k] >> 30) == CLS_SMALL) kk[k] = BZH_DBG(m.dbg & 32u) ? (u64)sf[k] * 0x9E3779B97F4A7C15ull : ms_key8(txt, sf[k], n);
         }
         // rank binning: local starts of the bins -- one wavefront, four bins a lane, while the keys are on their way (no
         // workgroup scan: three barriers less per unit); their room in the block's windows is claimed behind the next
@@ -1134,7 +1134,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
 #pragma unroll
             for (int k = KH; k < MS_ITEMS; k++) {
                 const uint32_t w = k * MS_THREADS + tid;
-                if (w < len && (gi[k] >> 30) == CLS_SMALL) stage[w] = (m.dbg & 32u) ? (u64)sf[k] * 0x9E3779B97F4A7C15ull : ms_key8(txt, sf[k], n);
+                if (w < len && (gi[k] >> 30) == CLS_SMALL) stage[w] = BZH_DBG(m.dbg & 32u) ? (u64)sf[k] * 0x9E3779B97F4A7C15ull : ms_key8(txt, sf[k], n);
             }
             const uint32_t tq4 = (uint32_t)ms_opaque((int)tid);
             #pragma unroll
@@ -1159,7 +1159,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) chunk_finish(Msd m)
                     uint32_t c = gi[k] >> 30;
                     const uint32_t g = gi[k] & 8191u;
                     uint32_t hp = s + g, dest = w;
-                    if (fuse && c == CLS_SMALL && !(m.dbg & 64u)) {
+                    if (fuse && c == CLS_SMALL && !BZH_DBG(m.dbg & 64u)) {
                         nin++; // (a member of a small group ENTERS the first doubling step: counted in A, bwt.hip round_begin)
                         const uint32_t ge = g + ((gi[k] >> 24) & 63u) + 1u;
                         const u64 my = stage[w];
@@ -1472,7 +1472,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) mid_sort(MidArgs a)
                 if (h < n) {
                     uint32_t i2 = i + h;
                     if (i2 >= n) i2 -= n;
-                    k2[k] = (a.dbg & 2u) ? i2 * 2654435761u >> 12 : rank[rslot(i2)];
+                    k2[k] = BZH_DBG(a.dbg & 2u) ? i2 * 2654435761u >> 12 : rank[rslot(i2)];
                 } else {
                     k2[k] = n - 1u - i; // identical rotations: larger index first -- a plain rank, no tag
                 }
@@ -1547,7 +1547,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) mid_sort(MidArgs a)
 #pragma unroll 1
             for (int pass = 0; pass < 4; pass++) {
                 const int sh = 20 + 7 * pass; // key2: bits 20..39 (+ bit 40, always 0); group index: bits 41..47
-                if (((vary >> sh) & 127ull) == 0ull || (a.dbg & 1u)) continue;
+                if (((vary >> sh) & 127ull) == 0ull || BZH_DBG(a.dbg & 1u)) continue;
                 tile_rank<7>(x, sh, actmask, R, cur[par], cur[par ^ 1], ls, pos, tid);
                 par ^= 1;
 #pragma unroll
@@ -1570,7 +1570,7 @@ __global__ void __launch_bounds__(MS_THREADS, 4) mid_sort(MidArgs a)
             }
         }
         // ---- out, in place: [rank : 20 @40][key2 : 20 @20][suffix : 20] (refine_one reads a block of this kind that way whatever the round's other lists carry)
-        for (uint32_t q = tid; q < len && !(a.dbg & 4u); q += MS_THREADS) {
+        for (uint32_t q = tid; q < len && !BZH_DBG(a.dbg & 4u); q += MS_THREADS) {
             const u64 y = stage[ms_slot(q)];
             recs[q] = ((u64)G[(uint32_t)(y >> 41) & 127u] << 40) | (y & 0xFFFFFFFFFFull);
         }
@@ -1588,6 +1588,8 @@ __global__ void __launch_bounds__(MS_THREADS, 4) mid_sort(MidArgs a)
 // reported (the blocks that keep the 8 passes are then queued on the second stream, beside all this); msd_sort_finish
 // waits for level 1's report -- which arrives while its scatter runs -- queues the deeper levels only if a bucket is
 // still oversized (text: mostly none; twelve empty launches were 68 us of every step), then the finishing kernel.
+// (seg_plan: one oversized bucket a workgroup -- a bucket is a serial chain of ~20 us, the headline has 922 at level 1)
+constexpr uint32_t SEG_PLAN_WGS = 1024;
 static int msd_sort_begin(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal, u64 *X, u64 *Y, u64 *big, u64 *tail, u64 *binned,
                           bool force_old, uint32_t fuse, volatile uint32_t *hrec, uint32_t seq, uint32_t *n_old, hipEvent_t ev_plan, Msd *keep)
 {
@@ -1626,7 +1628,10 @@ static int msd_sort_begin(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntot
     m.tiles = msc_tiles(bt.ms_cnt, B);
     m.ntiles = msc_row(bt.ms_cnt, B, MSR_MTILES);
     m.mticket = msc_row(bt.ms_cnt, B, MSR_MTICKET);
-    m.midcap = getenv("BZH_MID_CAP") ? std::min<uint32_t>(MS_TILE, std::max(1, atoi(getenv("BZH_MID_CAP")))) : (uint32_t)MS_TILE;
+    m.midcap = (uint32_t)MS_TILE;
+#ifdef BZH_EXPERIMENTS // (a cap below 8192 also breaks the 2 L / SORT_TILE + 1 tile bound refine_one's launch is sized with)
+    if (getenv("BZH_MID_CAP")) m.midcap = std::min<uint32_t>(MS_TILE, std::max(1, atoi(getenv("BZH_MID_CAP"))));
+#endif
     m.force_old = force_old ? 1u : 0u;
     m.fuse = fuse;
     {
@@ -1636,7 +1641,14 @@ static int msd_sort_begin(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntot
         }();
         m.force_new = init_msd ? 1u : 0u;
     }
-    m.dbg = getenv("BZH_MSD_DBG") ? (uint32_t)atoi(getenv("BZH_MSD_DBG")) : 0u;
+    {   // (16 = cycles per phase of chunk_finish, bit-exact; the bits that leave work out exist with -DBZH_EXPERIMENTS only)
+        static const uint32_t msd_dbg = getenv("BZH_MSD_DBG") ? (uint32_t)atoi(getenv("BZH_MSD_DBG")) : 0u;
+#ifdef BZH_EXPERIMENTS
+        m.dbg = msd_dbg;
+#else
+        m.dbg = msd_dbg & 16u;
+#endif
+    }
     // (bt.ms_cnt, bt.ms_bincur and bt.ms_bgcur arrive cleared: bwt_run's one clearing launch)
     {
         KSpan ks(ctx, K_MSD_PLAN, force_old ? 0 : ntotal, 2);
@@ -1657,7 +1669,7 @@ static int msd_sort_begin(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntot
         {
             KSpan ks(ctx, K_MSD_LEVELS, 0, 3 * MS_LEVELS);
             seg_count<<<dim3(1024), MS_THREADS, 0, st>>>(m, 1);
-            seg_plan<<<dim3(256), 256, 0, st>>>(m, 1, const_cast<uint32_t *>(hrec), seq);
+            seg_plan<<<dim3(SEG_PLAN_WGS), 256, 0, st>>>(m, 1, const_cast<uint32_t *>(hrec), seq);
             seg_scatter<<<dim3(1024), MS_THREADS, 0, st>>>(m, 1);
         }
     }
@@ -1702,7 +1714,7 @@ static int msd_sort_finish(bzh_ctx *ctx, hipStream_t st, const Msd &m, uint64_t 
         *deeper_out = deeper != 0u; // (only level 5 makes units out of a group that spans several: without the deeper levels no block has one)
         for (uint32_t L = 2; L <= MS_LEVELS && deeper; L++) {
             seg_count<<<dim3(1024), MS_THREADS, 0, st>>>(m, L);
-            seg_plan<<<dim3(256), 256, 0, st>>>(m, L);
+            seg_plan<<<dim3(SEG_PLAN_WGS), 256, 0, st>>>(m, L);
             seg_scatter<<<dim3(1024), MS_THREADS, 0, st>>>(m, L);
         }
     }

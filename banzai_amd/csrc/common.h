@@ -162,6 +162,8 @@ struct Batch {
     uint32_t *packgate; // [1] pack_gate: 1 = the batch's bits fit the output (the pack kernels of a gated call write nothing otherwise)
     uint32_t *symbits; // [B][PT] per pack tile bit counts
     BlockDesc *desc;   // [B]
+    const BlockDesc *pdesc; // [B] where the block CRCs are read from: the plan's descriptors of this batch (rle1_emit; the CRCs may
+                            //     arrive there on a side stream while the batch is already being sorted) or `desc` itself (stage seams)
     // "fixed" Huffman mode only (bzh_set_mode) -- the default path never touches these
     uint32_t *fx_tfreq;  // [B][6][258]
     uint8_t *fx_lens;    // [B][6][258]
@@ -171,7 +173,7 @@ struct Batch {
     uint8_t *fx_hdr;     // [B][FX_HDR_BYTES] block header .. selector count, then the delta-coded tables
 };
 
-constexpr uint32_t MTF_TILE = 2048;  // BWT bytes walked by one wavefront
+constexpr uint32_t MTF_TILE = 2048;  // BWT bytes walked by one wavefront (twice that in batches of 64 blocks and more: mtf_run)
 constexpr uint32_t HDR_BYTES = 4160; // 64 B block header/symbol map/counts + up to 3 delta-coded tables (< 25.6 kbit)
 constexpr uint32_t PACK_TILE = 4096; // MTF symbols packed by one workgroup
 constexpr uint32_t FX_TABLES = 6;         // lib/huffman.rs:319-326 allows 2..6 tables
@@ -212,6 +214,11 @@ struct bzh_ctx {
     hipStream_t side_stream = nullptr;   // second stream of the suffix sort (big-list path beside the small groups)
     hipStream_t side2_stream = nullptr;  // third stream: the global passes of the blocks mid_sort does not take, beside it (rounds >= 1)
     hipEvent_t side_ev[3] = {nullptr, nullptr, nullptr};
+    // the plan's work beside the main stream (rle1.hip): the block CRCs -- nothing needs them before the block headers are
+    // written -- and the table prefetch of the split run on the second stream between these events
+    hipEvent_t plan_ev[2] = {nullptr, nullptr};
+    bool crc_pending = false;           // the CRCs of the current plan are on their way (rle1_plan_crc_join collects them)
+    std::vector<uint8_t> crc_host;      // their landing place
     int profiling = 0;
     int mode = 0;                     // BZH_MODE_REFERENCE / BZH_MODE_FIXED (bzh_set_mode)
     char err[512] = {0};      // last failure (guarded by err_mu: the streaming worker writes it too)
@@ -502,9 +509,11 @@ int huff_pack(bzh_ctx *ctx, uint32_t B, uint32_t mmax, uint8_t *d_out, uint64_t 
 // it --, checks the capacity on the device and opens or shuts the gate of the pack kernels; hostrec[0] = bits, [1] = fits)
 int huff_pack_gate(bzh_ctx *ctx, uint32_t B, uint8_t *d_out, uint64_t bit_base, uint64_t cap_words, uint32_t seed, bool has_seed,
                    uint64_t *hostrec);
-int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n, bool with_crc = true); // rle1.hip: tables + split from 0
+int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n, bool with_crc = true, bool crc_async = false); // rle1.hip: tables + split from 0
 int rle1_plan_tables(bzh_ctx *ctx, const uint8_t *d_in, size_t n);                 // rle1.hip
-int rle1_plan_split(bzh_ctx *ctx, size_t start, bool with_crc, size_t stop);      // rle1.hip
+int rle1_plan_split(bzh_ctx *ctx, size_t start, bool with_crc, size_t stop, bool crc_async = false); // rle1.hip
+int rle1_plan_crc_join(bzh_ctx *ctx);                                             // rle1.hip: CRCs queued on the side stream -> plan_blocks
+hipStream_t bzh_side_stream(bzh_ctx *ctx);                                        // api.hip: the context's second stream (created once; null: none to be had)
 int rle1_plan_crc(bzh_ctx *ctx, size_t b0, size_t b1);               // rle1.hip: CRCs of plan blocks [b0, b1)
 int rle1_emit(bzh_ctx *ctx, size_t b0, uint32_t B);                   // rle1.hip: fill bt.rle / bt.n / bt.desc
 int crc_device(bzh_ctx *ctx, const uint8_t *d_in, size_t n, uint32_t *crc_out); // rle1.hip

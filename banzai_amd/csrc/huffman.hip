@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(192) huff_header(Batch bt)
             BitW a{hdr, 0, 0, 0};
             a.put(0x314159, 24);
             a.put(0x265359, 24);
-            const uint32_t crc = bt.desc[b].crc;
+            const uint32_t crc = bt.pdesc[b].crc;
             a.put(crc >> 16, 16);
             a.put(crc & 0xFFFF, 16);
             a.put(0, 1);
@@ -850,7 +850,7 @@ __global__ void __launch_bounds__(64) fx_header(Batch bt, uint32_t selmax, uint3
     BitW a{hdr, 0, 0, 0};
     a.put(0x314159, 24);
     a.put(0x265359, 24);
-    const uint32_t crc = bt.desc[b].crc;
+    const uint32_t crc = bt.pdesc[b].crc;
     a.put(crc >> 16, 16);
     a.put(crc & 0xFFFF, 16);
     a.put(0, 1);

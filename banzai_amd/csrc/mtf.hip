@@ -49,11 +49,11 @@ __device__ __forceinline__ uint32_t build_names(const uint8_t *hasbyte, uint8_t 
 }
 
 // ---- per-tile last occurrence (indexed by name) -----------------------------------------------------
-__global__ void __launch_bounds__(256) mtf_tile_last(Batch bt, int32_t *tlast, uint32_t MT)
+__global__ void __launch_bounds__(256) mtf_tile_last(Batch bt, int32_t *tlast, uint32_t MT, uint32_t TL)
 {
     const uint32_t b = blockIdx.y, tile = blockIdx.x;
     const uint32_t n = bt.n[b];
-    if (tile * MTF_TILE >= n) return;
+    if (tile * TL >= n) return;
     __shared__ int last[256];
     __shared__ uint8_t names[256];
     __shared__ uint32_t ls[8];
@@ -62,8 +62,8 @@ __global__ void __launch_bounds__(256) mtf_tile_last(Batch bt, int32_t *tlast, u
     const uint8_t *s = bt.bwt + (size_t)b * bt.S;
     static_assert(MTF_TILE % 2048 == 0, "256 threads x 8 bytes per sweep");
 #pragma unroll 1
-    for (uint32_t sub = 0; sub < MTF_TILE; sub += 2048) {
-    const uint32_t p0 = tile * MTF_TILE + sub + threadIdx.x * 8;
+    for (uint32_t sub = 0; sub < TL; sub += 2048) {
+    const uint32_t p0 = tile * TL + sub + threadIdx.x * 8;
     if (p0 < n) {
         uint2 w = *reinterpret_cast<const uint2 *>(s + p0);
         // only the last byte of a run inside my 8 bytes can be its symbol's last occurrence among them (after a
@@ -86,11 +86,11 @@ __global__ void __launch_bounds__(256) mtf_tile_last(Batch bt, int32_t *tlast, u
 
 // One workgroup per block: turn per-tile last occurrences into keys at tile entry (exclusive
 // running "latest occurrence"), seeded with the initial order; also num_syms.
-__global__ void __launch_bounds__(256) mtf_prefix(Batch bt, int32_t *tlast, uint32_t MT)
+__global__ void __launch_bounds__(256) mtf_prefix(Batch bt, int32_t *tlast, uint32_t MT, uint32_t TL)
 {
     const uint32_t b = blockIdx.x;
     const uint32_t n = bt.n[b];
-    const uint32_t ntile = (n + MTF_TILE - 1) / MTF_TILE;
+    const uint32_t ntile = (n + TL - 1) / TL;
     const uint32_t c = threadIdx.x;
     const bool present = bt.hasbyte[(size_t)b * 256 + c] != 0;
     uint32_t cnt = __popcll(__ballot(present));
@@ -243,11 +243,11 @@ __device__ __forceinline__ void walk_tile(const uint8_t *s, uint8_t *o, const in
     }
 }
 
-__global__ void __launch_bounds__(64) mtf_walk(Batch bt, const int32_t *tlast, uint32_t MT)
+__global__ void __launch_bounds__(64) mtf_walk(Batch bt, const int32_t *tlast, uint32_t MT, uint32_t TL)
 {
     const uint32_t b = blockIdx.y, tile = blockIdx.x;
     const uint32_t n = bt.n[b];
-    const uint32_t base_p = tile * MTF_TILE;
+    const uint32_t base_p = tile * TL;
     if (base_p >= n) return;
     const int lane = threadIdx.x;
     __shared__ uint8_t names[256];
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(64) mtf_walk(Batch bt, const int32_t *tlast, u
     const uint8_t *s = bt.bwt + (size_t)b * bt.S + base_p;
     uint8_t *o = bt.mtfpos + (size_t)b * bt.S + base_p;
     const uint32_t remain = n - base_p;
-    const uint32_t tile_len = remain < MTF_TILE ? remain : MTF_TILE;
+    const uint32_t tile_len = remain < TL ? remain : TL;
     if (num_names <= 64)
         walk_tile<1>(s, o, keys, names, lkeys, base_p, tile_len, lane);
     else if (num_names <= 128)
@@ -281,11 +281,11 @@ __global__ void __launch_bounds__(64) mtf_walk(Batch bt, const int32_t *tlast, u
 //   * the list for the next chunk: a seen symbol's position = the distinct symbols whose last occurrence in the chunk
 //     is later; an unseen symbol moves back by the seen symbols that were behind it.
 // The list at tile entry is the rank of mtf_prefix's keys (lib/mtf.rs:39-43 for the first tile).
-__global__ void __launch_bounds__(64) mtf_walk_par(Batch bt, const int32_t *tlast, uint32_t MT)
+__global__ void __launch_bounds__(64) mtf_walk_par(Batch bt, const int32_t *tlast, uint32_t MT, uint32_t TL)
 {
     const uint32_t b = blockIdx.y, tile = blockIdx.x;
     const uint32_t n = bt.n[b];
-    const uint32_t base_p = tile * MTF_TILE;
+    const uint32_t base_p = tile * TL;
     if (base_p >= n) return;
     const int lane = threadIdx.x;
     __shared__ uint8_t names[256];
@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(64) mtf_walk_par(Batch bt, const int32_t *tlas
     const uint8_t *s = bt.bwt + (size_t)b * bt.S + base_p;
     uint8_t *o = bt.mtfpos + (size_t)b * bt.S + base_p;
     const uint32_t remain = n - base_p;
-    const uint32_t tile_len = remain < MTF_TILE ? remain : MTF_TILE;
+    const uint32_t tile_len = remain < TL ? remain : TL;
     // ---- list at tile entry: E[name] = names with a larger key
     int k[4] = {keys[lane], keys[64 + lane], keys[128 + lane], keys[192 + lane]};
     int front;
@@ -669,15 +669,20 @@ int mtf_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     Batch &bt = ctx->bt;
     if (B == 0) return BZH_OK;
     hipStream_t st = ctx->stream;
-    const uint32_t MT = (bt.S + MTF_TILE - 1) / MTF_TILE;
+    // A wavefront walks TL bytes from the recency list at their start, which it first builds from the tile's keys (one step per
+    // name: a fifth of the walk of a 2,048-byte tile of text).  Tiles of 4,096 bytes halve that share and still leave a large
+    // batch three rounds of wavefronts (100 MB: 8.40 -> 8.34 ms); a small batch needs the wavefronts more (28 MB: 3.39 ->
+    // 3.49 ms with 4,096) and keeps 2,048.  8,192: no gain anywhere.
+    const uint32_t TL = B >= 64u ? 2u * MTF_TILE : MTF_TILE;
+    const uint32_t MT = (bt.S + TL - 1) / TL;
     int32_t *tlast = reinterpret_cast<int32_t *>(bt.listA);  // B*MT*256*4 <= B*S*8
     RleTile *rt = reinterpret_cast<RleTile *>(bt.listB);     // B*(S/RLE_TILE)*16 bytes
-    const uint32_t mt = (nmax + MTF_TILE - 1) / MTF_TILE;
+    const uint32_t mt = (nmax + TL - 1) / TL;
     const uint32_t rtiles = (nmax + RLE_TILE - 1) / RLE_TILE;
     {
         KSpan ks(ctx, K_MTF_LAST, ntotal, 2);
-        mtf_tile_last<<<dim3(mt, B), 256, 0, st>>>(bt, tlast, MT);
-        mtf_prefix<<<dim3(B), 256, 0, st>>>(bt, tlast, MT);
+        mtf_tile_last<<<dim3(mt, B), 256, 0, st>>>(bt, tlast, MT, TL);
+        mtf_prefix<<<dim3(B), 256, 0, st>>>(bt, tlast, MT, TL);
     }
     {
         KSpan ks(ctx, K_MTF_WALK, 2 * ntotal);
@@ -686,9 +691,9 @@ int mtf_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
             return e && !strcmp(e, "serial");
         }();
         if (serial_walk)
-            mtf_walk<<<dim3(mt, B), 64, 0, st>>>(bt, tlast, MT);
+            mtf_walk<<<dim3(mt, B), 64, 0, st>>>(bt, tlast, MT, TL);
         else
-            mtf_walk_par<<<dim3(mt, B), 64, 0, st>>>(bt, tlast, MT);
+            mtf_walk_par<<<dim3(mt, B), 64, 0, st>>>(bt, tlast, MT, TL);
     }
     KSpan ks(ctx, K_RLE2, 4 * ntotal, 3); // positions in twice, symbols (<= n, 2 bytes) out
     rle_tiles<<<dim3(rtiles, B), RLE_THREADS, 0, st>>>(bt, rt);

@@ -586,15 +586,16 @@ __device__ __forceinline__ uint32_t cut_block(const PlanArrays &pa, uint32_t lan
 // everything else is cut again in the next window, from the last good end -- a window per irregular cut instead of a
 // chain link per block.  The result is the sequential split's, block for block: a wavefront's cuts depend on its start
 // only, and a start is used only if it is the true one.
-constexpr uint32_t SP_W = 15, SP_K = 8; // (+ 1 wavefront that runs ahead and touches the tables: 1024 threads)
+constexpr uint32_t SP_W = 15, SP_K = 8;
 
-__global__ void __launch_bounds__(64 * (SP_W + 1)) plan_split(PlanArrays pa)
+// One wavefront that runs ahead of the split and touches the table lines it is about to read -- a launch of its own on the
+// context's second stream, beside plan_split (as a sixteenth wavefront of plan_split it left the workgroup before the
+// barriers of the others: a barrier not reached by every thread).
+__global__ void __launch_bounds__(64) plan_prefetch_kernel(PlanArrays pa) { plan_prefetch(pa, threadIdx.x); }
+
+__global__ void __launch_bounds__(64 * SP_W) plan_split(PlanArrays pa)
 {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    if (wave == SP_W) {
-        plan_prefetch(pa, lane);
-        return;
-    }
     const uint32_t N = (uint32_t)pa.n, M = pa.M, NT = pa.ntiles;
     const uint64_t total = pa.tc[NT];
     __shared__ CutRec rec[SP_W][SP_K];
@@ -1108,6 +1109,10 @@ static PlanWs plan_layout(uint8_t *base, uint64_t n, uint32_t M)
 int rle1_plan_tables(bzh_ctx *ctx, const uint8_t *d_in, size_t n)
 {
     hipStream_t st = ctx->stream;
+    if (ctx->crc_pending) { // (a call that failed before it collected its CRCs: the second stream must be done with the workspace)
+        (void)hipEventSynchronize(ctx->plan_ev[1]);
+        ctx->crc_pending = false;
+    }
     ctx->plan_blocks.clear();
     ctx->plan_open.clear();
     ctx->plan_crc_ok.clear();
@@ -1148,16 +1153,16 @@ int rle1_plan_tables(bzh_ctx *ctx, const uint8_t *d_in, size_t n)
     return BZH_OK;
 }
 
-int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n, bool with_crc)
+int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n, bool with_crc, bool crc_async)
 {
     BZH_TRY(rle1_plan_tables(ctx, d_in, n));
-    return rle1_plan_split(ctx, 0, with_crc, SIZE_MAX);
+    return rle1_plan_split(ctx, 0, with_crc, SIZE_MAX, crc_async);
 }
 
 // The sequential split over the tables of rle1_plan_tables, from input offset `start` (a block start) to the end of
 // the buffer -- or until a block starts at or after `stop` (that block is the last one listed); block offsets are
 // relative to the buffer.
-int rle1_plan_split(bzh_ctx *ctx, size_t start, bool with_crc, size_t stop)
+int rle1_plan_split(bzh_ctx *ctx, size_t start, bool with_crc, size_t stop, bool crc_async)
 {
     hipStream_t st = ctx->stream;
     const size_t n = ctx->plan_n;
@@ -1172,27 +1177,54 @@ int rle1_plan_split(bzh_ctx *ctx, size_t start, bool with_crc, size_t stop)
     pa.in = d_in;
     pa.start = (uint32_t)start;
     pa.stop = stop >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)stop;
+    // The second stream takes what nothing on the main stream waits for: the prefetching wavefront and -- crc_async, a
+    // whole-path call -- the block CRCs, which nobody reads before the block headers are written (prepare_batch makes the
+    // main stream wait for plan_ev[1] there; the host collects them with rle1_plan_crc_join).  64 us of CRC kernels
+    // and two fills leave the step's critical path.  (Profiling keeps everything on one stream: spans must not overlap.)
+    hipStream_t side = ctx->profiling ? nullptr : bzh_side_stream(ctx);
+    ctx->crc_pending = false;
     {
         KSpan ks(ctx, K_PLAN, 0, 1);
-        plan_split<<<dim3(1), 64 * (SP_W + 1), 0, st>>>(pa);
+        if (side) {
+            hipEventRecord(ctx->plan_ev[0], st); // (the tables are complete)
+            hipStreamWaitEvent(side, ctx->plan_ev[0], 0);
+            plan_prefetch_kernel<<<dim3(1), 64, 0, side>>>(pa);
+        }
+        plan_split<<<dim3(1), 64 * SP_W, 0, st>>>(pa);
     }
+    const size_t span = (size_t)((const uint8_t *)pa.nblocks - (const uint8_t *)pa.blocks) + 4;
+    const bool beside = with_crc && crc_async && side != nullptr;
     // The block CRCs are queued right behind the split, over as many blocks as there could be (the kernels read the
     // count on the device), and everything the host needs -- count, descriptors with their CRCs, cut status -- comes
     // back in ONE copy: the plan costs the host one wait.
     const CrcTables *ct = nullptr;
+    // blocks | aux | nblocks are consecutive in the workspace (plan_layout)
+    ctx->plan_host.resize(span);
     if (with_crc) {
         BZH_TRY(crc_tables(ctx, &ct));
+        hipStream_t sc = st;
+        if (beside) {
+            // (the descriptors come back first: the copy on the main stream must not see a CRC field half written -- it reads
+            // them before the side stream may write, and the CRCs come back in a copy of their own)
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->plan_host.data(), pa.blocks, span, hipMemcpyDeviceToHost, st));
+            hipEventRecord(ctx->plan_ev[0], st);
+            hipStreamWaitEvent(side, ctx->plan_ev[0], 0);
+            sc = side;
+        }
         KSpan ks(ctx, K_CRC, n, 2);
-        HIP_TRY(ctx, hipMemsetAsync(w.crcacc, 0, (size_t)pa.maxblocks * 4, st));
+        HIP_TRY(ctx, hipMemsetAsync(w.crcacc, 0, (size_t)pa.maxblocks * 4, sc));
         // (ranges of 64 KiB counted over all blocks: at most n / 64 KiB + one ragged range a block)
         const uint64_t ranges = n / ((uint64_t)CRC_TILE * CRC_WG_TILES) + pa.maxblocks + 1;
-        crc_tiles_flat<<<dim3((uint32_t)ranges), RL_THREADS, 0, st>>>(d_in, pa.blocks, w.crcacc, ct, pa.nblocks);
-        crc_finish<<<dim3(pa.maxblocks), 64, 0, st>>>(pa.blocks, w.crcacc, 0, ct, pa.nblocks);
+        crc_tiles_flat<<<dim3((uint32_t)ranges), RL_THREADS, 0, sc>>>(d_in, pa.blocks, w.crcacc, ct, pa.nblocks);
+        crc_finish<<<dim3(pa.maxblocks), 64, 0, sc>>>(pa.blocks, w.crcacc, 0, ct, pa.nblocks);
+        if (beside) {
+            ctx->crc_host.resize((size_t)pa.maxblocks * sizeof(BlockDesc));
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->crc_host.data(), pa.blocks, ctx->crc_host.size(), hipMemcpyDeviceToHost, side));
+            hipEventRecord(ctx->plan_ev[1], side);
+            ctx->crc_pending = true;
+        }
     }
-    // blocks | aux | nblocks are consecutive in the workspace (plan_layout)
-    const size_t span = (size_t)((const uint8_t *)pa.nblocks - (const uint8_t *)pa.blocks) + 4;
-    ctx->plan_host.resize(span);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->plan_host.data(), pa.blocks, span, hipMemcpyDeviceToHost, st));
+    if (!beside) HIP_TRY(ctx, hipMemcpyAsync(ctx->plan_host.data(), pa.blocks, span, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, bzh_stream_wait(st));
     HIP_TRY(ctx, hipGetLastError());
     uint32_t nb = 0;
@@ -1210,9 +1242,25 @@ int rle1_plan_split(bzh_ctx *ctx, size_t start, bool with_crc, size_t stop)
         ctx->plan_blocks[b].in_off = hb[b].in_off;
         ctx->plan_blocks[b].in_len = hb[b].in_len;
         ctx->plan_blocks[b].rle_len = hb[b].rle_len;
-        ctx->plan_blocks[b].crc = with_crc ? hb[b].crc : 0;
+        ctx->plan_blocks[b].crc = (with_crc && !beside) ? hb[b].crc : 0;
     }
-    ctx->plan_crc_ok.assign(nb, with_crc ? 1 : 0);
+    ctx->plan_crc_ok.assign(nb, (with_crc && !beside) ? 1 : 0);
+    return BZH_OK;
+}
+
+// The CRCs a whole-path plan left to the second stream: waits for them (they are long there: the call is at its end) and
+// fills them into plan_blocks.  No-op when none are pending.
+int rle1_plan_crc_join(bzh_ctx *ctx)
+{
+    if (!ctx->crc_pending) return BZH_OK;
+    ctx->crc_pending = false;
+    HIP_TRY(ctx, hipEventSynchronize(ctx->plan_ev[1]));
+    const BlockDesc *hb = reinterpret_cast<const BlockDesc *>(ctx->crc_host.data());
+    const size_t nb = std::min(ctx->plan_blocks.size(), ctx->crc_host.size() / sizeof(BlockDesc));
+    for (size_t b = 0; b < nb; b++) {
+        ctx->plan_blocks[b].crc = hb[b].crc;
+        ctx->plan_crc_ok[b] = 1;
+    }
     return BZH_OK;
 }
 
@@ -1220,6 +1268,7 @@ int rle1_plan_split(bzh_ctx *ctx, size_t start, bool with_crc, size_t stop)
 // the device descriptors (the block headers read them there) and into ctx->plan_blocks.
 int rle1_plan_crc(bzh_ctx *ctx, size_t b0, size_t b1)
 {
+    BZH_TRY(rle1_plan_crc_join(ctx));
     if (b1 > ctx->plan_blocks.size() || b0 > b1) return BZH_E_STATE;
     while (b0 < b1 && ctx->plan_crc_ok[b0]) b0++;
     while (b1 > b0 && ctx->plan_crc_ok[b1 - 1]) b1--;
@@ -1269,6 +1318,7 @@ int rle1_emit(bzh_ctx *ctx, size_t b0, uint32_t B)
         const uint64_t t0 = pb.in_off / RL_TILE, t1 = (pb.in_off + pb.in_len - 1) / RL_TILE;
         maxspan = std::max<uint64_t>(maxspan, t1 - t0 + 1);
     }
+    ctx->bt.pdesc = w.pa.blocks + b0; // (the block headers read the CRCs where crc_finish writes them)
     KSpan ks(ctx, K_RLE1_EMIT, 2 * (uint64_t)ctx->k_cur_ntotal);
     rle1_emit_kernel<<<dim3((uint32_t)maxspan, B), RL_THREADS, 0, ctx->stream>>>(ea, ctx->bt);
     HIP_TRY(ctx, hipGetLastError());

@@ -2,8 +2,10 @@
 // banzai's public surface over libbzhip.so (MI355X).  Signatures are those of the reference
 // crate (lib/lib.rs:84-88 and :141-153); every byte is produced by the HIP library.
 // NOTE: the build image has no Rust toolchain, so this crate has never been compiled or run; the same
-// calling pattern is exercised through the C ABI by banzai_amd/__init__.py and bnzhip.
+// calling pattern -- the context pool included -- is executed in C by tests/abi_facade.c (test_rust_facade_twin) and through
+// the C ABI by banzai_amd/__init__.py and bnzhip.
 
+use std::collections::HashMap;
 use std::convert;
 use std::ffi::CStr;
 use std::fs;
@@ -11,6 +13,7 @@ use std::io;
 use std::io::Write;
 use std::os::raw::{c_char, c_int};
 use std::path;
+use std::sync::{Mutex, OnceLock};
 
 #[repr(C)]
 struct BzhCtx {
@@ -44,6 +47,39 @@ impl Drop for Ctx {
     }
 }
 
+// A context is used by one thread at a time, and may move between threads between calls (include/bzhip.h).
+unsafe impl Send for Ctx {}
+
+// Process-wide pool of contexts, keyed by (device, level) -- what banzai_amd/__init__.py keeps in `_contexts`.
+// A context owns its workspace arena (45 MB per bzip2 block of a batch: 5.8 GB for a 100 MB input), allocated and
+// first-touched on the first encode that needs it; a caller that loops over files through `encode` must not pay that --
+// nor `bzh_create` -- per call.  `encode` checks a context OUT of the pool (two threads never share one), and back
+// IN when its stream ended cleanly; a context whose stream failed is dropped.  At most POOL_KEEP idle contexts a key.
+const POOL_KEEP: usize = 2;
+static POOL: OnceLock<Mutex<HashMap<(c_int, usize), Vec<Ctx>>>> = OnceLock::new();
+
+fn checkout(device: c_int, level: usize) -> io::Result<Ctx> {
+    let pool = POOL.get_or_init(|| Mutex::new(HashMap::new()));
+    if let Some(ctx) = pool.lock().unwrap().get_mut(&(device, level)).and_then(|v| v.pop()) {
+        return Ok(ctx);
+    }
+    let mut handle: *mut BzhCtx = std::ptr::null_mut();
+    let status = unsafe { bzh_create(&mut handle, device, level as c_int, 0) };
+    if status != 0 {
+        return Err(to_io_error(std::ptr::null(), status));
+    }
+    Ok(Ctx(handle))
+}
+
+fn checkin(device: c_int, level: usize, ctx: Ctx) {
+    let pool = POOL.get_or_init(|| Mutex::new(HashMap::new()));
+    let mut map = pool.lock().unwrap();
+    let idle = map.entry((device, level)).or_default();
+    if idle.len() < POOL_KEEP {
+        idle.push(ctx);
+    } // (else: dropped here, bzh_destroy)
+}
+
 fn to_io_error(ctx: *const BzhCtx, status: c_int) -> io::Error {
     let text = unsafe {
         let head = CStr::from_ptr(bzh_strerror(status)).to_string_lossy().into_owned();
@@ -69,15 +105,11 @@ where
     assert!(1 <= level && level <= 9);
 
     let device: c_int = std::env::var("BZHIP_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
-    let mut handle: *mut BzhCtx = std::ptr::null_mut();
-    let status = unsafe { bzh_create(&mut handle, device, level as c_int, 0) };
+    let ctx = checkout(device, level)?; // (an error below drops it: only a context whose stream ended cleanly goes back)
+    let handle = ctx.0; // (a copy of the raw pointer: the closure below must not hold a borrow of `ctx` when it is checked in)
+    let status = unsafe { bzh_stream_begin(handle) };
     if status != 0 {
-        return Err(to_io_error(std::ptr::null(), status));
-    }
-    let ctx = Ctx(handle);
-    let status = unsafe { bzh_stream_begin(ctx.0) };
-    if status != 0 {
-        return Err(to_io_error(ctx.0, status));
+        return Err(to_io_error(handle, status));
     }
 
     // Pull from the reader as the reference does (fill_buf / consume, lib/rle.rs:43-91).  A BufReader hands
@@ -89,16 +121,16 @@ where
     let mut stage: Vec<u8> = Vec::with_capacity(STAGE);
     let mut out: Vec<u8> = Vec::new();
     let mut feed = |chunk: &[u8], eof: bool, writer: &mut io::BufWriter<W>| -> io::Result<()> {
-        let cap = unsafe { bzh_stream_bound(ctx.0, chunk.len()) };
+        let cap = unsafe { bzh_stream_bound(handle, chunk.len()) };
         if out.len() < cap {
             out.resize(cap, 0);
         }
         let mut out_len = 0usize;
         let status = unsafe {
-            bzh_stream_feed(ctx.0, chunk.as_ptr(), chunk.len(), eof as c_int, out.as_mut_ptr(), out.len(), &mut out_len)
+            bzh_stream_feed(handle, chunk.as_ptr(), chunk.len(), eof as c_int, out.as_mut_ptr(), out.len(), &mut out_len)
         };
         if status != 0 {
-            return Err(to_io_error(ctx.0, status));
+            return Err(to_io_error(handle, status));
         }
         writer.write_all(&out[..out_len])
     };
@@ -123,7 +155,9 @@ where
         reader.consume(len);
     }
     writer.flush()?;
-    Ok(unsafe { bzh_stream_consumed(ctx.0) })
+    let consumed = unsafe { bzh_stream_consumed(handle) };
+    checkin(device, level, ctx);
+    Ok(consumed)
 }
 
 /// bzip2 encode a file and write the output to another file (level 9)

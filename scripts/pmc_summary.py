@@ -27,8 +27,11 @@ for k in sorted(set(fe) | set(wr)):
     kern[k] = {"launches": n, "fetch_kb": f, "write_kb": w, "hbm_bytes_per_launch": (2 * f + w) * 1024 / max(1, n)}
 rs = [v for k, v in kern.items() if k.startswith("radix_scatter")]
 nrs = sum(v["launches"] for v in rs)
-doc = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 1 --no-cpu "
-               "--no-extra` (3 passes of the hot path: warm-up, timed, profiled); values in KB as reported; hbm_bytes = "
+# passes of the hot path in the run = launches of a kernel every pass launches exactly once
+steps_in_run = max((v["launches"] for k, v in kern.items() if k.startswith("plan_split")), default=0)
+doc = {"steps_in_run": steps_in_run,
+       "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 1 --no-cpu "
+               "--no-extra` (`steps_in_run` passes of the hot path: first touch, profiled, warm-up, timed); values in KB as reported; hbm_bytes = "
                "(2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reads half of wide streaming reads, MI355X_MICROARCH.md "
                "HBM section; 8-byte-per-lane and narrower accesses are uncalibrated)",
        "tag": tag,

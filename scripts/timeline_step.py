@@ -6,7 +6,8 @@ f = max(glob.glob(os.path.join(d, '*', '*kernel_trace.csv')), key=os.path.getmti
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('plan_granules')]
-start, end = idx[-back], idx[-back + 1]
+start = idx[-back]
+end = idx[-back + 1] if back > 1 else len(rows)
 t0 = int(rows[start]['Start_Timestamp'])
 pe = t0
 for r in rows[start:end]:

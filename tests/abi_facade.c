@@ -7,13 +7,19 @@
  * empty --, bzh_stream_bound() asked before every feed and the output vector grown to it, every status checked.
  * Reference surface: lib/lib.rs:84-153.
  *
- *   abi_facade <level> <slice bytes> <input file> <output file>     exit 0 and prints "consumed <n>"
+ *   abi_facade <level> <slice bytes> <input file> <output file> [calls]    exit 0 and prints "consumed <n>"
+ *
+ * encode() takes its context from a process-wide pool keyed by (device, level) -- rust/src/lib.rs `POOL` / `checkout` /
+ * `checkin` -- so a caller that loops over files pays bzh_create and the arena (allocated and first-touched by the first
+ * encode that needs it) once: with [calls] > 1 the same input is encoded that many times and every call's wall clock is
+ * printed ("call <k>: <ms> ms"), the first against the steady state.
  * Built by tests/test_gpu_parity.py::test_rust_facade_twin (gcc, links banzai_amd/libbzhip.so); test infrastructure.
  */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "../include/bzhip.h"
 
@@ -44,27 +50,59 @@ static int feed(bzh_ctx *ctx, const uint8_t *chunk, size_t n, int eof, struct ou
     return fwrite(out->p, 1, out_len, writer) == out_len ? 0 : -101;
 }
 
-int main(int argc, char **argv)
+/* ---- the context pool (rust/src/lib.rs: POOL, checkout, checkin): idle contexts by (device, level) ------------------- */
+#define POOL_SLOTS 16
+static struct { int device, level; bzh_ctx *ctx; } pool[POOL_SLOTS];
+
+static bzh_ctx *checkout(int device, int level, int *status)
 {
-    if (argc != 5) {
-        fprintf(stderr, "usage: abi_facade <level> <slice bytes> <input> <output>\n");
-        return 2;
-    }
-    const int level = atoi(argv[1]);
-    const size_t slice = (size_t)strtoull(argv[2], NULL, 10);
-    if (level < 1 || level > 9 || slice == 0) return 2; /* assert!(1 <= level && level <= 9) */
-    FILE *reader = fopen(argv[3], "rb");
-    FILE *writer = fopen(argv[4], "wb");
-    if (!reader || !writer) return 3;
+    *status = BZH_OK;
+    for (int k = 0; k < POOL_SLOTS; k++)
+        if (pool[k].ctx && pool[k].device == device && pool[k].level == level) {
+            bzh_ctx *c = pool[k].ctx;
+            pool[k].ctx = NULL;
+            return c;
+        }
+    bzh_ctx *c = NULL;
+    *status = bzh_create(&c, device, level, 0);
+    return *status == BZH_OK ? c : NULL;
+}
+
+static void checkin(int device, int level, bzh_ctx *ctx)
+{
+    for (int k = 0; k < POOL_SLOTS; k++)
+        if (!pool[k].ctx) {
+            pool[k].device = device;
+            pool[k].level = level;
+            pool[k].ctx = ctx;
+            return;
+        }
+    bzh_destroy(ctx); /* (the pool keeps a bounded number of idle contexts) */
+}
+
+static double now_ms(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
+
+/* banzai::encode(reader, writer, level) */
+static int encode(FILE *reader, FILE *writer, int level, size_t slice, size_t *consumed)
+{
     const char *dev = getenv("BZHIP_DEVICE");
-    bzh_ctx *ctx = NULL;
-    int status = bzh_create(&ctx, dev ? atoi(dev) : 0, level, 0);
-    if (status != BZH_OK) {
+    const int device = dev ? atoi(dev) : 0;
+    int status;
+    bzh_ctx *ctx = checkout(device, level, &status);
+    if (!ctx) {
         fprintf(stderr, "abi_facade: bzh_create: %s\n", bzh_strerror(status));
         return 4;
     }
     status = bzh_stream_begin(ctx);
-    if (status != BZH_OK) return 4;
+    if (status != BZH_OK) {
+        bzh_destroy(ctx); /* (a context whose stream failed does not go back) */
+        return 4;
+    }
     uint8_t *buf = (uint8_t *)malloc(slice);   /* the BufReader's buffer */
     uint8_t *stage = (uint8_t *)malloc(STAGE + slice); /* Vec::with_capacity(STAGE), extend_from_slice may grow it */
     size_t staged = 0;
@@ -91,12 +129,43 @@ int main(int argc, char **argv)
         /* reader.consume(len) */
     }
     if (rc == 0 && fflush(writer) != 0) rc = -102;
-    if (rc == 0) printf("consumed %zu\n", bzh_stream_consumed(ctx));
-    bzh_destroy(ctx);
-    fclose(reader);
-    fclose(writer);
+    if (rc == 0) {
+        *consumed = bzh_stream_consumed(ctx);
+        checkin(device, level, ctx);
+    } else {
+        bzh_destroy(ctx);
+    }
     free(buf);
     free(stage);
     free(out.p);
     return rc ? 6 : 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc != 5 && argc != 6) {
+        fprintf(stderr, "usage: abi_facade <level> <slice bytes> <input> <output> [calls]\n");
+        return 2;
+    }
+    const int level = atoi(argv[1]);
+    const size_t slice = (size_t)strtoull(argv[2], NULL, 10);
+    const int calls = argc == 6 ? atoi(argv[5]) : 1;
+    if (level < 1 || level > 9 || slice == 0 || calls < 1) return 2; /* assert!(1 <= level && level <= 9) */
+    size_t consumed = 0;
+    for (int k = 0; k < calls; k++) {
+        FILE *reader = fopen(argv[3], "rb");
+        FILE *writer = fopen(argv[4], "wb");
+        if (!reader || !writer) return 3;
+        const double t0 = now_ms();
+        const int rc = encode(reader, writer, level, slice, &consumed);
+        const double t1 = now_ms();
+        fclose(reader);
+        fclose(writer);
+        if (rc) return rc;
+        if (calls > 1) printf("call %d: %.2f ms\n", k + 1, t1 - t0);
+    }
+    printf("consumed %zu\n", consumed);
+    for (int k = 0; k < POOL_SLOTS; k++)
+        if (pool[k].ctx) bzh_destroy(pool[k].ctx);
+    return 0;
 }
