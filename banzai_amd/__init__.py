@@ -13,12 +13,14 @@ import io
 
 from . import _native
 
-__all__ = ["encode", "encode_file", "Context", "BzhError"]
+__all__ = ["encode", "encode_file", "Context", "MultiContext", "BzhError"]
 
 Context = _native.Context
+MultiContext = _native.MultiContext
 BzhError = _native.BzhError
 
 _ctx_cache = {}
+_multi_cache = {}
 READ_CHUNK = 16 << 20
 
 
@@ -36,14 +38,43 @@ def _copying_sink(writer):
     return isinstance(writer, (io.BytesIO, io.BufferedWriter, io.BufferedRandom, io.FileIO))
 
 
-def encode(reader, writer, level, device=0):
+def _device_list(devices):
+    """`devices=` of encode, or $BZHIP_DEVICES ("0,1,2,3"): the GPUs of one node an encode is spread over."""
+    if devices is None:
+        import os
+        env = os.environ.get("BZHIP_DEVICES", "").strip()
+        devices = [int(x) for x in env.split(",") if x.strip() != ""] if env else None
+    return [int(d) for d in devices] if devices else None
+
+
+def encode(reader, writer, level, device=0, devices=None):
     """bzip2-encode everything `reader` yields and write the stream to `writer`.
 
     Same contract as banzai::encode: `level` in 1..=9 is the block size in 100 kB units
     (anything else raises, the reference asserts at lib/lib.rs:89); returns the number of input
-    bytes encoded; I/O errors of reader/writer propagate."""
+    bytes encoded; I/O errors of reader/writer propagate.
+
+    `devices` (or $BZHIP_DEVICES): a list of HIP devices of this node -- the blocks are then cut and encoded on all of
+    them (bzh_create_multi: one host thread and context per device inside the library, the stream assembled on the
+    first) and the stream is the one a single device writes, bit for bit.  That path reads the whole input first."""
     if isinstance(level, bool) or not isinstance(level, int) or not 1 <= level <= 9:
         raise ValueError("level must be in 1..=9")
+    devs = _device_list(devices)
+    if devs and len(devs) > 1:
+        data = reader.getvalue()[reader.tell():] if isinstance(reader, io.BytesIO) else reader.read()
+        if not isinstance(data, (bytes, bytearray, memoryview)):
+            raise TypeError("reader.read() must return bytes")
+        key = (tuple(devs), level)
+        if key not in _multi_cache:
+            _multi_cache[key] = _native.MultiContext(devs, level)
+        writer.write(_multi_cache[key].encode(data))
+        if isinstance(reader, io.BytesIO):
+            reader.seek(0, io.SEEK_END)
+        if hasattr(writer, "flush"):
+            writer.flush()
+        return len(data)
+    if devs:
+        device = devs[0]
     ctx = _ctx(level, device)
     put = writer.write if _copying_sink(writer) else (lambda view: writer.write(bytes(view)))
     # incremental ingestion (the reference pulls from fill_buf as it goes, lib/rle.rs:30-92): input is
@@ -97,7 +128,7 @@ def encode(reader, writer, level, device=0):
     return ctx.stream_consumed()
 
 
-def encode_file(in_path, out_path, device=0):
+def encode_file(in_path, out_path, device=0, devices=None):
     """bzip2-encode a file into another file at level 9 (banzai::encode_file)."""
     with open(in_path, "rb") as inf, open(out_path, "wb") as outf:
-        return encode(inf, outf, 9, device)
+        return encode(inf, outf, 9, device, devices)

@@ -82,6 +82,16 @@ SIGNATURES = {
                                                ctypes.c_size_t, u64p]),
     "bzh_assemble_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), u64p, ctypes.c_size_t,
                                            u32p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, szp]),
+    "bzh_create_multi": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int]),
+    "bzh_destroy_multi": (None, [ctypes.c_void_p]),
+    "bzh_multi_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "bzh_multi_device_count": (ctypes.c_int, [ctypes.c_void_p]),
+    "bzh_multi_encode": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_size_t, u8p, ctypes.c_size_t, szp, szp]),
+    "bzh_multi_load": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_size_t]),
+    "bzh_multi_run": (ctypes.c_int, [ctypes.c_void_p, szp]),
+    "bzh_multi_fetch": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_size_t]),
+    "bzh_multi_output_device": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "bzh_multi_times": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_size_t]),
     "bzh_rle1_split": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_size_t, ctypes.POINTER(Block), ctypes.c_size_t,
                                       szp, u8p, ctypes.c_size_t]),
     "bzh_crc32": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_size_t, u32p]),
@@ -434,3 +444,68 @@ class Context:
 
     def stream_consumed(self):
         return int(lib().bzh_stream_consumed(self._h))
+
+
+class MultiContext:
+    """Several GPUs behind one handle (bzh_create_multi): one host thread and one context per listed device inside the
+    library, block ranges chained by start offset, the bit strings assembled on devices[0].  A device may be listed more
+    than once (one context per entry)."""
+
+    def __init__(self, devices, level=9):
+        self.devices = [int(d) for d in devices]
+        self.level = level
+        self._h = ctypes.c_void_p()
+        arr = (ctypes.c_int * len(self.devices))(*self.devices)
+        st = lib().bzh_create_multi(ctypes.byref(self._h), arr, len(self.devices), level)
+        if st != 0:
+            raise BzhError(st, lib().bzh_strerror(st).decode())
+
+    def close(self):
+        if self._h:
+            lib().bzh_destroy_multi(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def check(self, st):
+        if st != 0:
+            raise BzhError(st, lib().bzh_strerror(st).decode() + ": " + lib().bzh_multi_last_error(self._h).decode())
+
+    @staticmethod
+    def _in(data):
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        return a if a.size else np.zeros(1, dtype=np.uint8), int(a.size)
+
+    def encode(self, data):
+        """bytes-like -> the whole .bz2 stream (bytes)"""
+        a, n = self._in(data)
+        cap = n + n // 4 + (n // 70000 + 4) * 4096 + 65536
+        out = np.empty(cap, dtype=np.uint8)
+        got, used = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        self.check(lib().bzh_multi_encode(self._h, ptr(a), n, ptr(out), cap, ctypes.byref(got), ctypes.byref(used)))
+        return out[:got.value].tobytes()
+
+    def load(self, data):
+        a, n = self._in(data)
+        self.check(lib().bzh_multi_load(self._h, ptr(a), n))
+
+    def run(self):
+        got = ctypes.c_size_t(0)
+        self.check(lib().bzh_multi_run(self._h, ctypes.byref(got)))
+        return got.value
+
+    def fetch(self, n):
+        out = np.empty(max(1, n), dtype=np.uint8)
+        self.check(lib().bzh_multi_fetch(self._h, ptr(out), out.size))
+        return out[:n].tobytes()
+
+    def times(self):
+        w = len(self.devices)
+        buf = (ctypes.c_double * (5 * w))()
+        self.check(lib().bzh_multi_times(self._h, buf, w))
+        keys = ("ms_load", "ms_wait", "ms_plan", "ms_encode", "ms_copy")
+        return [dict(zip(keys, (round(buf[5 * r + k], 3) for k in range(5)))) for r in range(w)]

@@ -336,6 +336,7 @@ extern "C" void bzh_destroy(bzh_ctx *ctx)
     if (ctx->d_stage_in) hipFree(ctx->d_stage_in);
     if (ctx->d_stage_out) hipFree(ctx->d_stage_out);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+    if (ctx->crc_host) hipHostFree(ctx->crc_host);
     if (ctx->d_crctab) hipFree(ctx->d_crctab);
     for (int k = 0; k < 2; k++)
         if (ctx->strm.d_buf[k]) hipFree(ctx->strm.d_buf[k]);
@@ -1655,11 +1656,8 @@ extern "C" int bzh_stream_feed(bzh_ctx *ctx, const uint8_t *in, size_t n, int eo
         opos += nbytes;
         s.bitpos += 80;
         s.active = false;
-        for (int k = 0; k < 2; k++) {
-            if (s.d_buf[k]) hipFree(s.d_buf[k]);
-            s.d_buf[k] = nullptr;
-            s.cap[k] = 0;
-        }
+        // (the two input buffers stay with the context for its next stream -- bzh_destroy frees them: a hipMalloc of 150 MB at
+        // the first feed and two synchronizing hipFree at the end were 0.3-0.5 ms of every stream of the API path)
         s.head = 0;
     }
     *out_len = opos;

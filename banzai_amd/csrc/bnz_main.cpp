@@ -51,7 +51,8 @@ const char *VERSION = "version alpha 0.3.1-hip";
             "  notes:\n"
             "     '-' as input path reads standard in.  Without --output / --stdout the file\n"
             "     '<input_path>.bz2' is written and the input removed; with an explicit output the\n"
-            "     input is kept unless --remove is given.  GPU: $BZHIP_DEVICE (default 0);\n"
+            "     input is kept unless --remove is given.  GPU: $BZHIP_DEVICE (default 0), or\n"
+            "     $BZHIP_DEVICES=0,1,2,... to spread the blocks over several GPUs of this node;\n"
             "     BZHIP_HUFFMAN=fixed: 2-6 Huffman tables with refinement (smaller, not banzai's exact bytes).\n\n%s\n",
             VERSION);
     exit(SUCCESS);
@@ -134,6 +135,55 @@ int main(int argc, char **argv)
         if (!outf) die(ERR_FILESYSTEM, "[filesystem error] cannot create " + p + ": " + strerror(errno));
     }
 
+    // $BZHIP_DEVICES = "0,1,2,3": the GPUs of this node the blocks are spread over (bzh_create_multi: one host thread and
+    // context per device inside the library; the stream is the one a single device writes).  That path holds the whole
+    // input in memory; with one device (the default) the input is streamed as below.
+    if (const char *dl = getenv("BZHIP_DEVICES")) {
+        std::vector<int> devices;
+        for (const char *q = dl; *q;) {
+            char *e = nullptr;
+            const long v = strtol(q, &e, 10);
+            if (e == q) break;
+            devices.push_back((int)v);
+            q = *e == ',' ? e + 1 : e;
+            if (*e && *e != ',') break;
+        }
+        const char *hm = getenv("BZHIP_HUFFMAN");
+        if (devices.size() > 1 && !(hm && std::string(hm) == "fixed")) {
+            std::vector<uint8_t> data;
+            std::unique_ptr<uint8_t[]> buf(new uint8_t[(size_t)16 << 20]);
+            for (;;) {
+                const size_t k = fread(buf.get(), 1, (size_t)16 << 20, inf);
+                data.insert(data.end(), buf.get(), buf.get() + k);
+                if (k < ((size_t)16 << 20)) {
+                    if (ferror(inf)) die(ERR_OUTPUT, "error during compression: read failed");
+                    break;
+                }
+            }
+            bzh_multi *m = nullptr;
+            int ms = bzh_create_multi(&m, devices.data(), (int)devices.size(), level);
+            if (ms != BZH_OK) die(ERR_OUTPUT, std::string("error during compression: ") + bzh_strerror(ms));
+            const size_t n = data.size(), cap = n + n / 4 + (n / 70000 + 4) * 4096 + 65536;
+            std::unique_ptr<uint8_t[]> out(new (std::nothrow) uint8_t[cap]);
+            size_t got = 0;
+            static const uint8_t none = 0;
+            ms = out ? bzh_multi_encode(m, n ? data.data() : &none, n, out.get(), cap, &got, nullptr) : BZH_E_NOMEM;
+            if (ms != BZH_OK) {
+                const std::string msg = std::string("error during compression: ") + bzh_strerror(ms) + ": " + bzh_multi_last_error(m);
+                bzh_destroy_multi(m);
+                die(ERR_OUTPUT, msg);
+            }
+            bzh_destroy_multi(m);
+            if (got && fwrite(out.get(), 1, got, outf) != got) die(ERR_OUTPUT, "error during compression: write failed");
+            if (!in_stdin) fclose(inf);
+            if (fflush(outf) != 0) die(ERR_OUTPUT, "error during compression: write failed");
+            if (outf != stdout) fclose(outf);
+            const bool keep_in = keep >= 0 ? keep == 1 : have_out; // bnz/src/main.rs:292-300
+            if (!keep_in && !in_stdin && remove(in_path.c_str()) != 0)
+                die(ERR_OUTPUT, "error deleting input file: " + std::string(strerror(errno)));
+            return SUCCESS;
+        }
+    }
     const char *devs = getenv("BZHIP_DEVICE");
     bzh_ctx *ctx = nullptr;
     int st = bzh_create(&ctx, devs ? atoi(devs) : 0, level, 0);

@@ -218,7 +218,8 @@ struct bzh_ctx {
     // written -- and the table prefetch of the split run on the second stream between these events
     hipEvent_t plan_ev[2] = {nullptr, nullptr};
     bool crc_pending = false;           // the CRCs of the current plan are on their way (rle1_plan_crc_join collects them)
-    std::vector<uint8_t> crc_host;      // their landing place
+    uint8_t *crc_host = nullptr;        // their landing place: PINNED (a copy to pageable memory holds the host until it is done)
+    size_t crc_host_cap = 0, crc_host_len = 0;
     int profiling = 0;
     int mode = 0;                     // BZH_MODE_REFERENCE / BZH_MODE_FIXED (bzh_set_mode)
     char err[512] = {0};      // last failure (guarded by err_mu: the streaming worker writes it too)

@@ -1218,8 +1218,19 @@ int rle1_plan_split(bzh_ctx *ctx, size_t start, bool with_crc, size_t stop, bool
         crc_tiles_flat<<<dim3((uint32_t)ranges), RL_THREADS, 0, sc>>>(d_in, pa.blocks, w.crcacc, ct, pa.nblocks);
         crc_finish<<<dim3(pa.maxblocks), 64, 0, sc>>>(pa.blocks, w.crcacc, 0, ct, pa.nblocks);
         if (beside) {
-            ctx->crc_host.resize((size_t)pa.maxblocks * sizeof(BlockDesc));
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->crc_host.data(), pa.blocks, ctx->crc_host.size(), hipMemcpyDeviceToHost, side));
+            const size_t need = (size_t)pa.maxblocks * sizeof(BlockDesc);
+            if (need > ctx->crc_host_cap) {
+                if (ctx->crc_host) hipHostFree(ctx->crc_host);
+                ctx->crc_host = nullptr;
+                ctx->crc_host_cap = 0;
+                if (hipHostMalloc((void **)&ctx->crc_host, need * 2, hipHostMallocDefault) != hipSuccess) {
+                    bzh_set_error(ctx, "hipHostMalloc(%zu) for the block CRCs failed", need * 2);
+                    return BZH_E_NOMEM;
+                }
+                ctx->crc_host_cap = need * 2;
+            }
+            ctx->crc_host_len = need;
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->crc_host, pa.blocks, need, hipMemcpyDeviceToHost, side));
             hipEventRecord(ctx->plan_ev[1], side);
             ctx->crc_pending = true;
         }
@@ -1255,8 +1266,8 @@ int rle1_plan_crc_join(bzh_ctx *ctx)
     if (!ctx->crc_pending) return BZH_OK;
     ctx->crc_pending = false;
     HIP_TRY(ctx, hipEventSynchronize(ctx->plan_ev[1]));
-    const BlockDesc *hb = reinterpret_cast<const BlockDesc *>(ctx->crc_host.data());
-    const size_t nb = std::min(ctx->plan_blocks.size(), ctx->crc_host.size() / sizeof(BlockDesc));
+    const BlockDesc *hb = reinterpret_cast<const BlockDesc *>(ctx->crc_host);
+    const size_t nb = std::min(ctx->plan_blocks.size(), ctx->crc_host_len / sizeof(BlockDesc));
     for (size_t b = 0; b < nb; b++) {
         ctx->plan_blocks[b].crc = hb[b].crc;
         ctx->plan_crc_ok[b] = 1;

@@ -56,6 +56,10 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="bytes of the workload timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true", help="skip the oracle (no cpu_baseline, no bit-exactness checks)")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_workloads and value_host_inclusive")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N inside ONE process: bzh_create_multi (one host thread and context per device inside the "
+                         "library) instead of one rank per GPU over torch.distributed")
+    ap.add_argument("--devices", default="", help="--single-process: the device list, e.g. 0,0,0 (default 0..N-1)")
     return ap.parse_args()
 
 
@@ -81,8 +85,71 @@ def path_alg_bytes(st):
             + 3 * ((st["out_bits"] + 7) // 8))
 
 
+def single_process(args):
+    """--gpus N --single-process: the N devices behind ONE handle (bzh_create_multi, include/bzhip.h) -- what a caller of
+    banzai_amd.encode(..., devices=[...]) / bnzhip with $BZHIP_DEVICES runs.  Same line shape as the launcher flow; a step
+    is bzh_multi_run: every worker's byte range resident on its device when it starts, the stream resident on the first
+    device when it ends."""
+    import bz2
+    import numpy as np
+    import torch
+    from banzai_amd import _native as nv
+    from banzai_amd import corpus
+    world = args.gpus
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(world))
+    if len(devices) != world:
+        raise SystemExit(f"--devices lists {len(devices)} devices, --gpus says {world}")
+    total = args.total_bytes or args.bytes * world
+    seg_bytes = -(-total // world)
+    segs, wname = [], None
+    for k in range(world):
+        sl = max(0, min(seg_bytes, total - k * seg_bytes))
+        sk, wname = corpus.workload(max(1, sl), segment=k)
+        segs.append(sk[:sl])
+    data = np.concatenate(segs)
+    with nv.MultiContext(devices, LEVEL) as m:
+        m.load(data)
+        out_len = m.run()
+        for _ in range(args.warmup):
+            out_len = m.run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out_len = m.run()
+        dt = time.perf_counter() - t0
+        per_worker = m.times()
+        stream = m.fetch(out_len)
+    checks = {}
+    if total <= 200_000_000:
+        checks["libbz2_roundtrip"] = bool(bz2.decompress(stream) == data.tobytes())
+    dev = torch.device("cuda", devices[0])
+    with nv.Context(devices[0], LEVEL) as ctx:
+        d_in = torch.zeros(total + 16, dtype=torch.uint8, device=dev)
+        d_in[:total] = torch.from_numpy(data).to(dev)
+        cap = (total // 3 + total // 8 + (1 << 20)) & ~3
+        d_out = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        ln = ctx.encode_device(d_in.data_ptr(), total, d_out.data_ptr(), cap)
+        checks["sharded_equals_single_gpu"] = bool(d_out[:ln].cpu().numpy().tobytes() == stream)
+    ms = dt * 1e3 / args.steps
+    result = {"metric": "encode MB/s (input) at level 9, enwik8, 1/2/4/8 MI355X; bit-exact vs CPU",
+              "value": round(total * args.steps / dt / 1e6, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
+              "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+              "scaling": "strong" if args.total_bytes else "weak", "vs_baseline": None, "dtype": "u8",
+              "data": "synthetic" if wname != "enwik8" else "enwik8",
+              "config": {"workload": f"level {LEVEL} {wname}, {seg_bytes} bytes per GPU, {total} bytes in one stream, "
+                                     "full RLE1->BWT->MTF->Huffman pipeline",
+                         "parallelism": f"block-sharded x{world}, single process (bzh_create_multi), devices {devices}"},
+              "per_worker_ms": per_worker, "collective_backend": "none: chain by host variables, strings by hipMemcpyPeer",
+              "compressed_bytes": out_len, "checks": checks}
+    print(json.dumps(result), flush=True)
+    if not all(checks.values()):
+        raise SystemExit("bench: correctness check failed")
+
+
 def main():
     args = parse_args()
+    if args.single_process:
+        return single_process(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 

@@ -192,6 +192,30 @@ BZH_API int bzh_encode_range_device(bzh_ctx *ctx, size_t b0, size_t b1, void *d_
 BZH_API int bzh_assemble_device(bzh_ctx *ctx, const void *const *d_segs, const uint64_t *seg_bits, size_t nseg,
                         const uint32_t *block_crcs, size_t nblocks, void *d_out, size_t cap, size_t *out_len);
 
+/* ---- several GPUs behind one handle: banzai::encode for a caller that holds a node (lib/lib.rs:84-88, the loop at
+ * :101-126 sharded by start offset as above) -- one host thread and one context per listed device INSIDE the library,
+ * the chain hand-off a host variable, the encoded bit strings copied to devices[0] (hipMemcpyPeer: xGMI) and
+ * funnel-shifted into the stream there.  A device may be listed more than once (one context per entry: the whole
+ * flow runs on a box with one GPU that way).  The handle is single-threaded like a context.  The launcher flow (one
+ * process per GPU over torch.distributed, banzai_amd/sharded.py) remains for multi-process jobs. */
+typedef struct bzh_multi bzh_multi;
+BZH_API int bzh_create_multi(bzh_multi **out, const int *devices, int ndev, int level);
+BZH_API void bzh_destroy_multi(bzh_multi *m);
+BZH_API const char *bzh_multi_last_error(const bzh_multi *m);
+BZH_API int bzh_multi_device_count(const bzh_multi *m);
+/* Host buffers in and out: the complete .bz2 stream of in[0..n), bit-identical to bzh_encode's on one device. */
+BZH_API int bzh_multi_encode(bzh_multi *m, const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len,
+                             size_t *consumed);
+/* The same in three steps (bench.py --single-process times the middle one: input resident in HBM when it starts,
+ * the stream resident on devices[0] when it ends): every worker's byte range (+ look-ahead) to its device; tables,
+ * chained split, encode, strings to devices[0], assembly; the stream back to host memory. */
+BZH_API int bzh_multi_load(bzh_multi *m, const uint8_t *in, size_t n);
+BZH_API int bzh_multi_run(bzh_multi *m, size_t *out_len);
+BZH_API int bzh_multi_fetch(bzh_multi *m, uint8_t *out, size_t cap);
+BZH_API const void *bzh_multi_output_device(const bzh_multi *m); /* the assembled stream on devices[0] (device pointer) */
+/* Wall clocks of the last call per worker, 5 doubles each (ms): load, wait for the chain, tables + split, encode, copy. */
+BZH_API int bzh_multi_times(const bzh_multi *m, double *out, size_t max_workers);
+
 /* ---- stage seams (host pointers; computed on the GPU; used by the parity tests) ------------ */
 
 /* rle_one() applied repeatedly (lib/rle.rs:102-253): block table for in[0..n) and, if rle_out

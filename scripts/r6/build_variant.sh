@@ -8,10 +8,10 @@ BD=/tmp/bzh_build_$NAME
 mkdir -p $BD
 cd $ROOT/banzai_amd/csrc
 pids=()
-for f in api bwt mtf huffman rle1; do
+for f in api bwt mtf huffman rle1 multi; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-value -fvisibility=hidden -fno-gpu-rdc -DBZH_BUILD $FLAGS -c $f.hip -o $BD/$f.o &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/banzai_amd/libbzhip_$NAME.so $BD/api.o $BD/bwt.o $BD/mtf.o $BD/huffman.o $BD/rle1.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/banzai_amd/libbzhip_$NAME.so $BD/api.o $BD/bwt.o $BD/mtf.o $BD/huffman.o $BD/rle1.o $BD/multi.o
 ls -la $ROOT/banzai_amd/libbzhip_$NAME.so

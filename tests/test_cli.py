@@ -67,3 +67,10 @@ def test_cli_end_to_end(cli, oracle, tmp_path):
     env = dict(os.environ, BZHIP_HUFFMAN="fixed")
     r2 = subprocess.run([cli, "-c", "-"], input=big, capture_output=True, env=env)
     assert r2.returncode == 0 and len(r2.stdout) < len(r.stdout) and bz2.decompress(r2.stdout) == big
+    # BZHIP_DEVICES: the blocks spread over several GPUs of the node (here: the one GPU, listed three times) -- the same bytes
+    env = dict(os.environ, BZHIP_DEVICES="0,0,0")
+    r3 = subprocess.run([cli, "-c", "-"], input=big, capture_output=True, env=env)
+    assert r3.returncode == 0 and r3.stdout == r.stdout
+    f.write_bytes(d)
+    r4 = subprocess.run([cli, "-5", "--output", str(out), str(f)], capture_output=True, env=env)
+    assert r4.returncode == 0 and f.exists() and out.read_bytes() == oracle.encode(d, 5)

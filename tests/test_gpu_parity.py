@@ -1072,3 +1072,69 @@ def test_bench_world_eight_on_one_gpu():
     assert 0 < cal["split_ms_per_block"] < cal["encode_ms_per_block"] and 0 <= cal["plan_cost"] <= 0.05
     waits = [r["model"]["wait"] for r in line["per_rank"]]
     assert waits[0] == 0 and all(a < b for a, b in zip(waits, waits[1:]))
+
+
+def test_multi_device_handle_bit_exact(oracle, native):
+    """bzh_create_multi with ONE GPU listed several times (one context and host thread per entry: what an 8-GPU node runs with
+    eight different devices): the chained split over host variables, the strings copied to the first entry's device and
+    assembled there.  Streams equal the oracle's -- text, runs that make a block span several workers' ranges, inputs shorter
+    than the number of workers, the empty input; the three-step form (load / run / fetch) gives the same bytes."""
+    from banzai_amd import corpus
+    text = corpus.enwik_synthetic(30_000_000, seed=77).tobytes()
+    runs = cases.gen(3_000_000, "text", 9) + b"\0" * 60_000_000 + cases.gen(2_000_000, "shortruns", 9) + b"ab" * 1_500_000
+    with native.MultiContext([0, 0, 0], 9) as m:
+        for data in (text, runs, b"", b"x", b"xy" * 3, text[:2_500_000]):
+            want = oracle.encode(data, 9)
+            assert m.encode(data) == want, len(data)
+        m.load(text)
+        n1 = m.run()
+        n2 = m.run()  # (a loaded input can be encoded again: bench.py --single-process times this call)
+        assert n1 == n2 and m.fetch(n1) == oracle.encode(text, 9)
+        assert len(m.times()) == 3
+    with native.MultiContext([0, 0], 1) as m:  # level 1: a hundred blocks a worker
+        data = cases.gen(9_000_000, "text", 3) + cases.repeats(1_000_000, 3)
+        assert m.encode(data) == oracle.encode(data, 1)
+    with native.MultiContext([0] * 8, 9) as m:  # eight workers, fewer blocks than workers in some ranges
+        data = text[:5_000_000]
+        assert m.encode(data) == oracle.encode(data, 9)
+
+
+def test_multi_device_handle_400mb(oracle, native):
+    """the same at 400 MB over three workers: equal to the one-device stream AND to the oracle's"""
+    import numpy as np
+    import torch
+    from banzai_amd import corpus
+    data = np.concatenate([corpus.workload(100_000_000, segment=k)[0] for k in range(4)])
+    n = int(data.size)
+    with native.MultiContext([0, 0, 0], 9) as m:
+        got = m.encode(data)
+    with native.Context(0, 9) as ctx:
+        d_in = torch.zeros(n + 16, dtype=torch.uint8, device="cuda")
+        d_in[:n] = torch.from_numpy(data).cuda()
+        cap = (n // 2 + (1 << 20)) & ~3
+        d_out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+        ln = ctx.encode_device(d_in.data_ptr(), n, d_out.data_ptr(), cap)
+        single = d_out[:ln].cpu().numpy().tobytes()
+    assert got == single
+    assert got == oracle.encode(data.tobytes(), 9)
+
+
+def test_multi_device_public_api_and_errors(oracle, native):
+    """banzai_amd.encode(reader, writer, level, devices=[...]) and $BZHIP_DEVICES; a device that does not exist fails the
+    creation with a status, not a crash"""
+    import io
+    import banzai_amd
+    data = cases.gen(4_000_000, "text", 12) + b"\0" * 300_000
+    want = oracle.encode(data, 9)
+    out = io.BytesIO()
+    assert banzai_amd.encode(io.BytesIO(data), out, 9, devices=[0, 0]) == len(data) and out.getvalue() == want
+    os.environ["BZHIP_DEVICES"] = "0,0,0"
+    try:
+        out = io.BytesIO()
+        assert banzai_amd.encode(io.BytesIO(data), out, 9) == len(data) and out.getvalue() == want
+    finally:
+        del os.environ["BZHIP_DEVICES"]
+    with pytest.raises(native.BzhError):
+        native.MultiContext([0, 63], 9)
+    with pytest.raises(native.BzhError):
+        native.MultiContext([], 9)
