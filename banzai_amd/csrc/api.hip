@@ -166,6 +166,7 @@ static size_t layout_batch(Batch &bt, uint8_t *base, uint32_t B, uint32_t M)
         bt.stat_A = rs ? reinterpret_cast<unsigned long long *>(rs + oA) : nullptr;
     }
     carve(p, bt.chain, NB * 4);
+    carve(p, bt.pshrink, NB * 4);
     carve(p, bt.errflag, 64);
     carve(p, bt.gidof, NB * S);
     carve(p, bt.grank, 2 * NB * GID_MAX);

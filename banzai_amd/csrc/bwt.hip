@@ -2056,6 +2056,189 @@ __global__ void __launch_bounds__(1024) period_probe(ProbeArgs a)
     }
 }
 
+// ---- near-periodic blocks, from the start: sort eight periods, expand -------------------------------------------------
+// period_probe above finishes a block S = w^k w' (|w| = p, 0 < |w'| = r < p) in one round -- AFTER the 8-pass sort of all its
+// n rotations and a SWEEP round over all of them: 3.5 of the 4.3 ms a batch of such blocks takes.  But the order of the
+// rotations of S follows from the order of the rotations of the short block S' = w^m w' (its first n' = m p + r bytes: the
+// text needs no copy), m = 8:
+//   * rotation i' of S' and rotation i' + D of S (D = n - n' = (k - m) p) are the same distance from the end of the block,
+//     where the phase jumps from r to 0 -- the one place a rotation of S differs from w repeated for ever; every comparison
+//     between two rotations is decided within fewer than 3 p characters behind the seam of the one that reaches it first, so
+//     rotations that are both within n' of the end compare in S as they do in S';
+//   * the k - m rotations c, c + p, .. of phase c that S has and S' has not are further from the end than any of them: they
+//     read w from phase c for more than n' characters, as rotation c of S' does, and sort next to it -- before it in ascending
+//     index order if a rotation that keeps reading (phase r) sorts before one that has wrapped (phase 0), else behind it in
+//     descending order -- with nothing in between (a rotation that compares equal to w^inf from phase c for that long is a
+//     rotation of phase c, or a tail that reads like one after its wrap and lies beyond all of them).
+// (Checked against a naive sort of all rotations for 36,000 random (w, k, r) over alphabets of 2-4 letters, periods up to 30
+// and m = 3, 4, 8: no mismatch from m = 3 on -- /tests/test_period_model.py keeps a smaller run of that model; on the GPU
+// test_near_periodic_from_the_start compares whole streams with the oracle.)
+// period_detect (one workgroup a block, before anything else reads bt.n): the smallest p <= PD_PMAX with S[u] = S[u + p] for
+// all u < n - p -- candidates are the places where the block's first 16 bytes recur, verified in ascending order --; if the
+// block is at least PD_M + 2 periods long and r != 0 it leaves (flags, p, n, m) in bt.pshrink and SHRINKS bt.n[b] to n': every
+// kernel of the sort then sees a block of a few periods.  period_expand (behind bwt_emit) writes the last column and the
+// origin pointer of S from the ranks of S' and restores bt.n[b].  Exactly periodic blocks (r = 0) are left to round_begin's
+// "nothing was refined" rule, as before.
+constexpr uint32_t PD_PMAX = 8192, PD_M = 8, PD_MINLEN = 64;
+
+__global__ void __launch_bounds__(1024) period_detect(const uint8_t *blk, uint32_t *nn, uint32_t *pshrink, uint32_t S)
+{
+    const uint32_t b = blockIdx.x, tid = threadIdx.x, n = nn[b];
+    const uint8_t *s = blk + (size_t)b * S;
+    __shared__ uint32_t s_cand, s_d;
+    uint32_t *rec = pshrink + (size_t)b * 4;
+    if (tid < 4) rec[tid] = 0u;
+    if (n < 20u * 16u) return; // (too short to be worth it; also keeps the 16-byte probes inside the block)
+    const uint32_t pmax = min(PD_PMAX, n / (PD_M + 2u));
+    u64 f0, f1;
+    __builtin_memcpy(&f0, s, 8);
+    __builtin_memcpy(&f1, s + 8, 8);
+    uint32_t lower = 1;
+    for (int attempt = 0; attempt < 4; attempt++) {
+        if (tid == 0) s_cand = 0xFFFFFFFFu;
+        __syncthreads();
+        uint32_t mine = 0xFFFFFFFFu;
+        for (uint32_t p = lower + tid; p <= pmax && mine == 0xFFFFFFFFu; p += 1024) {
+            u64 g0, g1;
+            __builtin_memcpy(&g0, s + p, 8);
+            __builtin_memcpy(&g1, s + p + 8, 8);
+            if (g0 == f0 && g1 == f1) mine = p;
+        }
+        if (mine != 0xFFFFFFFFu) atomicMin(&s_cand, mine);
+        __syncthreads();
+        const uint32_t p = s_cand;
+        if (p == 0xFFFFFFFFu) return; // the first 16 bytes do not recur: no period up to pmax
+        // every u < n - p: 16 bytes a thread and step, four steps between two looks at the verdict
+        const uint32_t lim = n - p;
+        bool failed = false;
+        for (uint32_t u0 = 0; u0 < lim; u0 += 4u * 16384u) {
+            bool bad = false;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) {
+                const uint32_t u = u0 + q * 16384u + tid * 16u;
+                if (u + 16u <= lim) {
+                    u64 a0, a1, c0, c1;
+                    __builtin_memcpy(&a0, s + u, 8);
+                    __builtin_memcpy(&a1, s + u + 8, 8);
+                    __builtin_memcpy(&c0, s + u + p, 8);
+                    __builtin_memcpy(&c1, s + u + p + 8, 8);
+                    bad |= a0 != c0 || a1 != c1;
+                } else {
+                    for (uint32_t v = u; v < lim; v++) bad |= s[v] != s[v + p];
+                }
+            }
+            if (__syncthreads_or(bad ? 1 : 0)) { // (the same verdict in every thread: the loop is left by all of them together)
+                failed = true;
+                break;
+            }
+        }
+        if (!failed) {
+            const uint32_t k = n / p, r = n - k * p;
+            const uint32_t m = max(PD_M, (PD_MINLEN + p - 1u) / p);
+            if (r == 0u || k < m + 2u) return;
+            // which way a phase's rotations run: does a rotation that keeps reading (w from phase r) sort before one that has
+            // wrapped (w from phase 0)?  First difference of the two, within p characters (w is primitive, r != 0)
+            if (tid == 0) s_d = 0xFFFFFFFFu;
+            __syncthreads();
+            uint32_t dmin = 0xFFFFFFFFu;
+            for (uint32_t d = tid; d < p && dmin == 0xFFFFFFFFu; d += 1024) {
+                uint32_t x = r + d;
+                if (x >= p) x -= p;
+                if (s[x] != s[d]) dmin = d;
+            }
+            if (dmin != 0xFFFFFFFFu) atomicMin(&s_d, dmin);
+            __syncthreads();
+            const uint32_t d = s_d;
+            if (d == 0xFFFFFFFFu) return; // (cannot happen for a minimal period; the block is then left to the general sort)
+            if (tid == 0) {
+                uint32_t x = r + d;
+                if (x >= p) x -= p;
+                const bool asc = s[x] < s[d];
+                rec[1] = p;
+                rec[2] = n;
+                rec[3] = m;
+                rec[0] = 1u | (asc ? 2u : 0u);
+                nn[b] = m * p + r;
+            }
+            return;
+        }
+        lower = p + 1u; // that recurrence was no period: the next one
+        __syncthreads();
+    }
+}
+
+constexpr uint32_t PX_WGS = 8; // workgroups that share the expansion of one block
+__global__ void __launch_bounds__(1024) period_expand(Batch bt, const uint32_t *pshrink)
+{
+    const uint32_t b = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
+    const uint32_t *rec = pshrink + (size_t)b * 4;
+    if (!(rec[0] & 1u)) return;
+    const bool asc = (rec[0] & 2u) != 0u;
+    const uint32_t p = rec[1], n = rec[2], m = rec[3];
+    const uint32_t k = n / p, r = n - k * p, np = m * p + r, X = k - m; // X: rotations of every phase that S has and S' has not
+    const size_t base = (size_t)b * bt.S;
+    const uint8_t *s = bt.rle + base;
+    const uint32_t *rank = bt.rank + base;
+    uint8_t *out = bt.bwt + base;
+    constexpr uint32_t MW = (PD_M * PD_PMAX + 2u * PD_PMAX + PD_MINLEN) / 32u + 8u; // words of a bit per position of S' (n' < (m + 1) p)
+    __shared__ uint32_t mask[MW], pre[MW];
+    __shared__ uint32_t ls[20];
+    const uint32_t words = (np + 1u + 31u) / 32u;
+    for (uint32_t w = tid; w < words; w += 1024) mask[w] = 0u;
+    __syncthreads();
+    // where the extra rotations of every phase go: in front of rotation c of S' (ascending) or behind it (descending)
+    for (uint32_t c = tid; c < p; c += 1024) {
+        const uint32_t q = rank_final(rank[rslot(c)]) + (asc ? 0u : 1u);
+        atomicOr(&mask[q >> 5], 1u << (q & 31u));
+    }
+    __syncthreads();
+    // pre[w] = insertion points in the words before w
+    uint32_t carry = 0;
+    for (uint32_t w0 = 0; w0 < words; w0 += 1024) {
+        const uint32_t w = w0 + tid;
+        const uint32_t c = w < words ? (uint32_t)__popc(mask[w]) : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_add(c, ls, &tot);
+        if (w < words) pre[w] = carry + ex;
+        carry += tot;
+    }
+    __syncthreads();
+    auto upto = [&](uint32_t q) { return pre[q >> 5] + (uint32_t)__popc(mask[q >> 5] & (0xFFFFFFFFu >> (31u - (q & 31u)))); }; // points at positions <= q
+    // the rotations S' has: rotation i' of S' is rotation i' + D of S, behind every run of extras whose point is at or before it
+    for (uint32_t i = part * 1024u + tid; i < np; i += PX_WGS * 1024u) {
+        const uint32_t q = rank_final(rank[rslot(i)]);
+        out[q + X * upto(q)] = i ? s[i - 1u] : s[p - 1u]; // (rotation D of S is preceded by the end of a period, not by S'[n' - 1])
+    }
+    // the extras of every phase: X copies of the phase's predecessor byte -- rotation 0 of S, the furthest of phase 0, is
+    // preceded by the block's last byte and is where the origin pointer points.  Short periods: the workgroups share every
+    // phase's run; long ones: a wavefront a phase.
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    if (X >= 4096u) {
+        for (uint32_t c = 0; c < p; c++) {
+            const uint32_t q = rank_final(rank[rslot(c)]) + (asc ? 0u : 1u);
+            const uint32_t at = q + X * (upto(q) - 1u);
+            const uint8_t ch = c ? s[c - 1u] : s[p - 1u];
+            for (uint32_t j = part * 1024u + tid; j < X; j += PX_WGS * 1024u)
+                if (!(c == 0u && j == (asc ? 0u : X - 1u))) out[at + j] = ch; // (phase 0's one exception is written below)
+        }
+    } else {
+        for (uint32_t c = part * 16u + wave; c < p; c += PX_WGS * 16u) {
+            const uint32_t q = rank_final(rank[rslot(c)]) + (asc ? 0u : 1u);
+            const uint32_t at = q + X * (upto(q) - 1u);
+            const uint8_t ch = c ? s[c - 1u] : s[p - 1u];
+            for (uint32_t j = lane; j < X; j += 64)
+                if (!(c == 0u && j == (asc ? 0u : X - 1u))) out[at + j] = ch;
+        }
+    }
+    if (part == 0 && tid == 0) {
+        const uint32_t q = rank_final(rank[rslot(0)]) + (asc ? 0u : 1u);
+        const uint32_t at = q + X * (upto(q) - 1u) + (asc ? 0u : X - 1u);
+        out[at] = s[n - 1u];
+        bt.ptr[b] = at;
+        bt.n[b] = n;
+    }
+}
+
 // ---- round bookkeeping on the device ---------------------------------------------------------------
 // One workgroup, one thread per block.  Consumes the counters the previous round left (c_big, c_small,
 // c_tail, c_prog; after the initial refine: `first`), decides every block's mode and depth, builds this
@@ -2400,7 +2583,7 @@ static void launch_refine_one(bzh_ctx *ctx, RefineArgs &r, uint32_t NB, uint32_t
 
 // Suffix-sort and emit the last column for blocks 0..B-1 of the batch (bt.rle / bt.n filled).
 // nmax = largest block length in the batch, ntotal = sum of block lengths (statistics only).
-int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
+int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal, bool is_retry)
 {
     Batch &bt = ctx->bt;
     if (B == 0) return BZH_OK;
@@ -2520,6 +2703,10 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         return BZH_E_HIP;
     }
     clr.launch(st);
+    // near-periodic blocks are sorted as eight of their periods (period_detect shrinks bt.n[b] before anything reads it,
+    // period_expand behind bwt_emit writes the whole block's last column); a retry after a look-back gave up finds the blocks
+    // shrunk already
+    if (!is_retry) period_detect<<<dim3(B), 1024, 0, st>>>(bt.rle, bt.n, bt.pshrink, bt.S);
     if (use_msd) {
         BZH_TRY(msd_sort_begin(ctx, B, nmax, ntotal, bufB, bufD, bufA, bufC, binned, false, r0_fused,
                                hrec0 + (size_t)MAX_ROUNDS * SUMMARY_WORDS, epoch + 63u, &nOld, side ? ctx->side_ev[0] : nullptr, &msd_keep));
@@ -3078,7 +3265,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
         memcpy(ctx->k_launch, kl_in, sizeof kl_in);
         static const bool say = getenv("BZH_TRACE_ROUNDS") != nullptr;
         if (say) fprintf(stderr, "[bzhip] a look-back gave up: the suffix sort runs again with every block on one XCD\n");
-        return bwt_run(ctx, B, nmax, ntotal);
+        return bwt_run(ctx, B, nmax, ntotal, true);
     }
     // (the last summary read is the one of a round that found nothing to do: every kernel before it has run, so
     // its error word and its sum of unresolved suffixes are final)
@@ -3097,6 +3284,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     if (few_blocks(B)) gx |= WG_SPREAD;
     KSpan ks(ctx, K_BWT_EMIT, 6 * ntotal - emitted); // rank word and text byte in for every rotation, one byte out for those not yet written
     bwt_emit<<<dim3(xcd_grid(gx, B)), 256, 0, st>>>(bt, gx, B);
+    period_expand<<<dim3(PX_WGS, B), 1024, 0, st>>>(bt, bt.pshrink);
     HIP_TRY(ctx, hipGetLastError());
     return BZH_OK;
 }

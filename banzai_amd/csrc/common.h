@@ -109,6 +109,7 @@ struct Batch {
     uint32_t *c_groups; // groups of the block after the initial sort (refine_one<init>; round_begin picks the first mode)
     uint32_t *scratch;  // a row nobody reads
     uint32_t *chain;    // [B][4] near-periodic blocks: flags, period, leading tails (period_probe, bwt.hip)
+    uint32_t *pshrink;  // [B][4] blocks sorted as eight of their periods: flags, period, the block's real length, periods kept (period_detect / period_expand)
     uint32_t *gateS, *gateA, *gateR, *gateT;     // this round: sorted-list length per path (0 = not on that path)
     uint32_t *actS, *actA, *actR, *actT, *actQ;  // this round: ids of the blocks on each path (Q: TAIL at depth x4)
     uint32_t *nlist;    // [8] lengths of those lists (S, A, R, T, Q)
@@ -500,7 +501,7 @@ __device__ __forceinline__ int block_excl_min_rev(int v, int *lds)
 }
 
 // ---- stage entry points (host side, defined in the stage files) ---------------------------------
-int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal); // bwt.hip
+int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal, bool is_retry = false); // bwt.hip
 int unbwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax);               // bwt.hip: inverse transform, bt.bwt/ptr -> bt.mtfpos
 int unbwt_compare(bzh_ctx *ctx, uint32_t B, uint32_t nmax, unsigned long long *d_acc); // bwt.hip: bt.rle vs bt.mtfpos
 int mtf_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal = 0); // mtf.hip (ntotal: statistics only)

@@ -1138,3 +1138,33 @@ def test_multi_device_public_api_and_errors(oracle, native):
         native.MultiContext([0, 63], 9)
     with pytest.raises(native.BzhError):
         native.MultiContext([], 9)
+
+
+def test_near_periodic_from_the_start(oracle, native):
+    """period_detect / period_expand (bwt.hip): a block that is a word repeated, cut off inside a repetition, is sorted as eight
+    of its periods and expanded.  Whole streams against the oracle: periods from 2 to the limit of 8,192 and just beyond it,
+    small alphabets (partial matches between phases: the tails that read like another phase after their wrap), what RLE1
+    leaves of one enormous run (period 5), blocks with barely enough repetitions and one too few, level 1 and level 9, periodic
+    stretches between text (blocks that are periodic only in part must take the general sort)."""
+    rng = np.random.default_rng(606)
+    inputs = []
+    for p, sigma, reps in ((2, 2, 700_000), (3, 2, 400_000), (7, 3, 200_000), (31, 2, 40_000), (1024, 256, 1_500), (1000, 4, 1_200),
+                           (8191, 2, 160), (8192, 256, 130), (8193, 256, 130), (4096, 3, 9), (4096, 3, 11), (60_000, 256, 14)):
+        w = rng.integers(0, sigma, p, dtype=np.uint8)
+        # (no run of four equal bytes: RLE1 must leave the repetition alone, or the block's period is another one)
+        for q in range(3, p):
+            if w[q] == w[q - 1] == w[q - 2] == w[q - 3]:
+                w[q] = (int(w[q]) + 1) % max(2, sigma)
+        data = np.tile(w, reps).tobytes()
+        inputs.append(data[: len(data) - int(rng.integers(1, p))] if p > 1 else data)
+    inputs.append(b"\0" * 30_000_000)                                  # RLE1 output: 00 00 00 00 FB repeated
+    inputs.append(b"A" * 255 + b"z" * 256 + b"A" * 257 + b"zzz" + b"AAAA" + b"z" * 5)
+    inputs[-1] = inputs[-1] * 12_000
+    text = cases.gen(1_200_000, "text", 4)
+    inputs.append(text + b"ab" * 900_000 + text[:500_000] + b"xyz" * 400_000)
+    for level in (9, 1):
+        with native.Context(0, level, 32) as ctx:
+            for data in inputs:
+                if level == 1 and len(data) > 3_000_000:
+                    data = data[:3_000_000]
+                assert ctx.encode(data) == oracle.encode(data, level), (level, len(data), data[:16])
