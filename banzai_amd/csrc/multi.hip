@@ -330,17 +330,19 @@ extern "C" void bzh_destroy_multi(bzh_multi *m)
 {
     if (!m) return;
     for (Worker &k : m->w) {
-        if (k.ctx) bzh_destroy(k.ctx); // (waits for the context's own streams)
-        if (hipSetDevice(k.device) == hipSuccess) {
+        if (!k.ctx) continue; // (a handle whose creation failed half way: nothing was ever done on that device)
+        bzh_destroy(k.ctx);   // (waits for the context's own streams)
+        if ((k.d_in || k.d_part) && hipSetDevice(k.device) == hipSuccess) {
             if (k.d_in) hipFree(k.d_in);
             if (k.d_part) hipFree(k.d_part);
         }
     }
-    if (!m->w.empty() && hipSetDevice(m->w[0].device) == hipSuccess) {
+    if (!m->w.empty() && m->w[0].ctx && hipSetDevice(m->w[0].device) == hipSuccess) {
         for (size_t r = 1; r < m->w.size(); r++)
             if (m->w[r].d_seg) hipFree(m->w[r].d_seg);
         if (m->d_out) hipFree(m->d_out);
     }
+    (void)hipGetLastError(); // (no sticky status of this teardown is left for the thread's next HIP call to trip over)
     delete m;
 }
 

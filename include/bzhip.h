@@ -51,7 +51,9 @@ typedef struct {
  * the last bzh_encode* / bzh_encode_range_device call; filled when profiling is enabled. */
 typedef struct {
     double ms_plan, ms_rle1, ms_bwt, ms_mtf, ms_huff, ms_pack, ms_total;
-    double ms_bwt_sort;           /* radix scatter+histogram kernels only (dominant kernel class) */
+    double ms_bwt_sort;           /* the global radix passes only (radix_scatter: the 8 passes of blocks that keep them and
+                                   * the big-list passes of the rounds; text batches launch none since round 5 -- the
+                                   * dominant kernel class is chunk_finish, see bzh_get_kernel_stats)               */
     uint64_t bwt_sort_launches;   /* radix scatter launches issued in ms_bwt_sort (incl. ones that find no work) */
     uint64_t bwt_sort_elems;      /* elements moved by those launches                           */
     uint64_t raw_bytes, rle_bytes, mtf_syms, out_bits;

@@ -1,9 +1,9 @@
 #!/bin/bash
 # builds banzai_amd/libbzhip_<name>.so from the working tree with extra compiler flags (A/B runs on one box: BZH_LIB=...)
-#   scripts/r6/build_variant.sh NAME "-DFOO=1 ..."
+#   scripts/build_variant.sh NAME "-DFOO=1 ..."
 set -e
 NAME=$1; FLAGS=${2:-}
-ROOT=$(cd "$(dirname "$0")/../.." && pwd)
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
 BD=/tmp/bzh_build_$NAME
 mkdir -p $BD
 cd $ROOT/banzai_amd/csrc

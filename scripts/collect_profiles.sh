@@ -43,5 +43,19 @@ python3 scripts/msd_ablation.py "$OUT" "$TAG" > "$OUT/${TAG}_msd_ablation.json"
 python3 scripts/cli_wallclock.py "$OUT/${TAG}_cli_wallclock.json" > /dev/null 2>&1
 python3 scripts/gpu_stream_sweep.py > "$OUT/${TAG}_stream_api_sweep.txt" 2>&1
 python3 scripts/gpu_lanes.py > "$OUT/${TAG}_lanes.txt" 2>&1
+# ---- round 6: what the host<->device copies of the API paths cost on this box (the floor of value_stream_api /
+# value_host_inclusive: DESIGN section 6); the Rust facade's calling pattern with its context pool, first call against
+# steady state (tests/abi_facade.c, 16 MiB slices = encode_file, 100 MB, output to /dev/null); the devices-behind-one-handle
+# flow on this box's one GPU (three contexts, 3 x 30 MB)
+if [ ! -x scripts/micro/copy_rates ]; then (cd scripts/micro && hipcc -O2 --offload-arch=gfx950 -o copy_rates copy_rates.hip -lpthread > /dev/null 2>&1); fi
+./scripts/micro/copy_rates > "$OUT/${TAG}_copy_rates.txt" 2>&1
+gcc -O2 -Wall -o /tmp/abi_facade tests/abi_facade.c -Lbanzai_amd -lbzhip -Wl,-rpath,$PWD/banzai_amd
+python3 -c "
+import sys; sys.path.insert(0, '.')
+from banzai_amd import corpus
+corpus.workload(100_000_000)[0].tofile('/tmp/facade_in.bin')"
+/tmp/abi_facade 9 16777216 /tmp/facade_in.bin /dev/null 5 > "$OUT/${TAG}_facade_calls.txt" 2>&1
+rm -f /tmp/facade_in.bin
+python3 bench.py --gpus 3 --single-process --devices 0,0,0 --bytes 30000000 --steps 5 > "$OUT/${TAG}_single_process_3x30MB.json" 2>/dev/null
 rm -f "$OUT"/pmc_*.log "$OUT"/*.err
 ls -la "$OUT"

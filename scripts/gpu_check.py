@@ -1,6 +1,6 @@
 """bit-exactness of the library in use against the oracle: a mixed 16-block batch (text + runs + periodic) and a small one"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from banzai_amd import _native, corpus
 from oracle import pyoracle
 ok = True

@@ -1,6 +1,6 @@
 """Multi-batch streams on one GPU: 1 GB (config 4, ten 100 MB segments of the generator) and a C4 rank's 125 MB, lanes 1 vs 2."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from banzai_amd import _native as nv, corpus
 nseg = int(sys.argv[1]) if len(sys.argv) > 1 else 10

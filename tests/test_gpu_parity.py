@@ -816,7 +816,7 @@ def test_lookback_give_up_is_an_error_not_a_hang(oracle, native):
     """a tile that never publishes its look-back status (injected): the tiles behind it give up after a bounded wait,
     the call returns an error status, and the context encodes correctly afterwards"""
     import time
-    d = cases.gen(400_000, "text", 3)
+    d = cases.repeats(400_000, 3)  # (not a repeated sentence: a near-periodic block is sorted as eight of its periods, one tile)
     with native.Context(0, 9, 8) as ctx:
         ctx.debug_fault(1)
         t0 = time.perf_counter()
@@ -831,7 +831,7 @@ def test_lookback_give_up_of_a_shared_gpu_is_recovered(oracle, native):
     """what several processes computing on one GPU do to a small batch (a look-back gives up: its predecessor is queued on
     an XCD whose slots another process holds), injected: the suffix sort runs again with every block on one XCD, the call
     succeeds with the oracle's bytes, and the context keeps that mapping"""
-    d = cases.gen(400_000, "text", 5) + cases.gen(2_000_000, "text", 6)
+    d = cases.repeats(400_000, 5) + cases.repeats(2_000_000, 6)  # (see above: blocks that take the general sort)
     with native.Context(0, 9, 8) as ctx:
         ctx.debug_fault(2)
         assert ctx.encode(d) == oracle.encode(d, 9)
