@@ -2812,7 +2812,8 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal, bool is_re
         }
         if (use_msd) { // the rest of the bucket-first sort: deeper levels if level 1 left any, the finishing kernel
             BZH_TRY(msd_sort_finish(ctx, st, msd_keep, ntotal, hrec0 + (size_t)MAX_ROUNDS * SUMMARY_WORDS, epoch + 63u, &msd_deeper));
-        if (getenv("BZH_TRACE_ROUNDS")) { // (debugging aid: waits for the device)
+        static const bool trace_init = getenv("BZH_TRACE_ROUNDS") != nullptr;
+        if (trace_init) { // (debugging aid: waits for the device)
             uint32_t c[MS_CNT_WORDS];
             if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(c, bt.ms_cnt, sizeof c, hipMemcpyDeviceToHost) == hipSuccess)
                 fprintf(stderr, "[bzhip] initial sort: %u blocks bucket-first, %u blocks 8-pass; %u units; %.1f %% of the suffixes in oversized 2-byte buckets; oversized buckets per level %u %u %u %u %u (tiles %u %u %u %u %u)\n",

@@ -39,11 +39,18 @@ extern "C" {
     fn bzh_stream_consumed(ctx: *const BzhCtx) -> usize;
 }
 
-struct Ctx(*mut BzhCtx);
+// A context and the two host buffers an encode works with.  They stay together in the pool: the output buffer is sized by
+// bzh_stream_bound (a worst case of a few hundred megabytes for a 100 MB input) and `resize` zero-fills what it adds -- once
+// per pooled context, not once per call (per call it cost more than the encode: tests/abi_facade.c measures both).
+struct Ctx {
+    handle: *mut BzhCtx,
+    out: Vec<u8>,
+    stage: Vec<u8>,
+}
 
 impl Drop for Ctx {
     fn drop(&mut self) {
-        unsafe { bzh_destroy(self.0) }
+        unsafe { bzh_destroy(self.handle) }
     }
 }
 
@@ -56,6 +63,7 @@ unsafe impl Send for Ctx {}
 // nor `bzh_create` -- per call.  `encode` checks a context OUT of the pool (two threads never share one), and back
 // IN when its stream ended cleanly; a context whose stream failed is dropped.  At most POOL_KEEP idle contexts a key.
 const POOL_KEEP: usize = 2;
+const STAGE: usize = 4 << 20; // small fill_buf slices are coalesced into feeds of this size
 static POOL: OnceLock<Mutex<HashMap<(c_int, usize), Vec<Ctx>>>> = OnceLock::new();
 
 fn checkout(device: c_int, level: usize) -> io::Result<Ctx> {
@@ -68,7 +76,7 @@ fn checkout(device: c_int, level: usize) -> io::Result<Ctx> {
     if status != 0 {
         return Err(to_io_error(std::ptr::null(), status));
     }
-    Ok(Ctx(handle))
+    Ok(Ctx { handle, out: Vec::new(), stage: Vec::with_capacity(STAGE) })
 }
 
 fn checkin(device: c_int, level: usize, ctx: Ctx) {
@@ -105,8 +113,8 @@ where
     assert!(1 <= level && level <= 9);
 
     let device: c_int = std::env::var("BZHIP_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
-    let ctx = checkout(device, level)?; // (an error below drops it: only a context whose stream ended cleanly goes back)
-    let handle = ctx.0; // (a copy of the raw pointer: the closure below must not hold a borrow of `ctx` when it is checked in)
+    let mut ctx = checkout(device, level)?; // (an error below drops it: only a context whose stream ended cleanly goes back)
+    let handle = ctx.handle; // (a copy of the raw pointer: the closure below borrows the context's buffers only)
     let status = unsafe { bzh_stream_begin(handle) };
     if status != 0 {
         return Err(to_io_error(handle, status));
@@ -117,9 +125,9 @@ where
     // so small slices are coalesced into a staging buffer of STAGE bytes and fed from there; slices of STAGE
     // bytes or more go straight through.  The library buffers what it must and returns stream bytes as soon
     // as they are final.
-    const STAGE: usize = 4 << 20;
-    let mut stage: Vec<u8> = Vec::with_capacity(STAGE);
-    let mut out: Vec<u8> = Vec::new();
+    let out = &mut ctx.out; // (the pooled context's buffers: disjoint fields, borrowed until the loop below ends)
+    let stage = &mut ctx.stage;
+    stage.clear();
     let mut feed = |chunk: &[u8], eof: bool, writer: &mut io::BufWriter<W>| -> io::Result<()> {
         let cap = unsafe { bzh_stream_bound(handle, chunk.len()) };
         if out.len() < cap {
@@ -138,7 +146,7 @@ where
         let len = {
             let buf = reader.fill_buf()?;
             if buf.is_empty() {
-                feed(&stage, true, &mut writer)?; // end of input: whatever is staged, with the eof mark
+                feed(&stage[..], true, &mut writer)?; // end of input: whatever is staged, with the eof mark
                 break;
             }
             if stage.is_empty() && buf.len() >= STAGE {
@@ -146,7 +154,7 @@ where
             } else {
                 stage.extend_from_slice(buf);
                 if stage.len() >= STAGE {
-                    feed(&stage, false, &mut writer)?;
+                    feed(&stage[..], false, &mut writer)?;
                     stage.clear();
                 }
             }

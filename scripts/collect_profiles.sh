@@ -54,7 +54,11 @@ python3 -c "
 import sys; sys.path.insert(0, '.')
 from banzai_amd import corpus
 corpus.workload(100_000_000)[0].tofile('/tmp/facade_in.bin')"
-/tmp/abi_facade 9 16777216 /tmp/facade_in.bin /dev/null 5 > "$OUT/${TAG}_facade_calls.txt" 2>&1
+{ echo "# tests/abi_facade.c = the calling pattern of rust/src/lib.rs (context pool, pooled buffers); 100 MB of the bench workload, output to /dev/null"
+  echo "# in-memory reader (fill_buf = everything that is left: what value_stream_api feeds from), 6 calls in one process:"
+  /tmp/abi_facade 9 0 /tmp/facade_in.bin /dev/null 6
+  echo "# encode_file's reader (16 MiB BufReader slices from the page cache), 6 calls:"
+  /tmp/abi_facade 9 16777216 /tmp/facade_in.bin /dev/null 6; } > "$OUT/${TAG}_facade_calls.txt" 2>&1
 rm -f /tmp/facade_in.bin
 python3 bench.py --gpus 3 --single-process --devices 0,0,0 --bytes 30000000 --steps 5 > "$OUT/${TAG}_single_process_3x30MB.json" 2>/dev/null
 rm -f "$OUT"/pmc_*.log "$OUT"/*.err

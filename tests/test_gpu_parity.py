@@ -902,6 +902,17 @@ def test_rust_facade_twin(oracle, native, tmp_path):
         assert r.returncode == 0, r.stderr
         assert r.stdout.strip() == f"consumed {len(data)}"
         assert fout.read_bytes() == oracle.encode(data, level), (level, slice_bytes, len(data))
+    # the context pool: three calls in one process (the second and third find the context, its output vector and its stage in
+    # the pool), through the in-memory reader (slice 0: fill_buf hands out all that is left, as Rust's &[u8] does) and through
+    # 8 KiB slices; every call writes the same bytes
+    for slice_bytes in (0, 8192):
+        fin, fout = tmp_path / "in.bin", tmp_path / "out.bz2"
+        fin.write_bytes(text)
+        r = subprocess.run([str(exe), "9", str(slice_bytes), str(fin), str(fout), "3"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        lines = r.stdout.strip().splitlines()
+        assert len(lines) == 4 and lines[-1] == f"consumed {len(text)}" and all(ln.startswith("call ") for ln in lines[:3])
+        assert fout.read_bytes() == oracle.encode(text, 9)
 
 
 def test_full_size_headline_bit_exact_vs_oracle(oracle, native):
