@@ -846,9 +846,13 @@ static int prepare_batch(bzh_ctx *lane, RangeJob &j, bool wait_total = true)
 
 // Encodes plan blocks [b0, b1) into d_out starting at bit `bit_base`; words of d_out from
 // bit_base/32 on are zeroed here as needed (words before that are the caller's).
+// (`framed`: in/out -- the caller wants the whole stream's header and footer around these blocks; set back to false unless
+// this call wrote them on the device: one batch, one lane, all blocks of the plan from bit 32 on)
 static int encode_range(bzh_ctx *ctx, size_t b0, size_t b1, uint8_t *d_out, size_t cap, uint64_t bit_base,
-                        uint64_t *nbits, const uint32_t *seed_word = nullptr)
+                        uint64_t *nbits, const uint32_t *seed_word = nullptr, bool *framed = nullptr)
 {
+    const bool want_frame = framed && *framed;
+    if (framed) *framed = false;
     if (((uintptr_t)d_out & 3u) != 0) {
         bzh_set_error(ctx, "output buffer must be 4-byte aligned");
         return BZH_E_ARG;
@@ -953,9 +957,14 @@ static int encode_range(bzh_ctx *ctx, size_t b0, size_t b1, uint8_t *d_out, size
         if (status == BZH_OK && one_batch) {
             hipStream_t st = lane->stream;
             uint64_t *rec = reinterpret_cast<uint64_t *>(lane->h_pinned); // (the first 64 words of the pinned block are free)
-            status = huff_pack_gate(lane, job.B, d_out, bit_base, cap_words, seed_word ? *seed_word : 0u, seed_word != nullptr, rec);
+            const bool frame = want_frame && bit_base == 32 && b0 == 0 && !seed_word; // (block CRCs of the batch = of the stream)
+            status = huff_pack_gate(lane, job.B, d_out, bit_base, cap_words, seed_word ? *seed_word : 0u, seed_word != nullptr, rec, frame ? 80u : 0u);
             if (status == BZH_OK) {
                 status = huff_pack(lane, job.B, job.mmax, d_out, bit_base, true);
+                if (status == BZH_OK && frame) {
+                    status = huff_frame_stream(lane, job.B, d_out);
+                    if (status == BZH_OK) *framed = true;
+                }
                 if (status != BZH_OK) (void)bzh_stream_wait(st); // (pack_gate is queued: nothing of this call may still run when the error is reported)
             }
             hipError_t he = hipSuccess;
@@ -1261,14 +1270,28 @@ extern "C" int bzh_encode_device(bzh_ctx *ctx, const void *d_in, size_t n, void 
     HIP_TRY(ctx, hipMemsetAsync(d_out, 0, 4, st));
     uint64_t body = 0;
     const size_t nb = ctx->plan_blocks.size();
+    bool framed = true; // (a stream of one batch gets its header and footer on the device, behind the pack: no host round trip)
     if (nb) {
-        BZH_TRY(encode_range(ctx, 0, nb, (uint8_t *)d_out, cap, 32, &body));
+        BZH_TRY(encode_range(ctx, 0, nb, (uint8_t *)d_out, cap, 32, &body, nullptr, &framed));
     } else {
+        framed = false;
         HIP_TRY(ctx, hipMemsetAsync(d_out, 0, 16, st));
     }
     const uint64_t total_bits = 32 + body + 80;
     const size_t bytes = (size_t)((total_bits + 7) / 8);
     *out_len = bytes;
+    if (framed) { // (everything is written and waited for; the CRCs are collected for bzh_plan_blocks' sake)
+        BZH_TRY(rle1_plan_crc_join(ctx));
+        if (ctx->profiling) {
+            t2 = bzh_event(ctx);
+            hipEventRecord(t2, st);
+            HIP_TRY(ctx, bzh_stream_wait(st));
+            ctx->stats.ms_plan = span_ms(t0, t1);
+            ctx->stats.ms_total = span_ms(t0, t2);
+        }
+        if (consumed) *consumed = n;
+        return BZH_OK;
+    }
     // the footer may reach one word past what encode_range zeroed
     const uint64_t zero_from = (32 + body + 31) / 32 + (nb ? 1 : 0), zero_to = (total_bits + 31) / 32 + 1;
     if (zero_to * 4 > cap) return BZH_E_CAP;

@@ -1634,12 +1634,14 @@ struct TailArgs {
     const uint32_t *hb;  // [B] depth h of each block
     uint32_t S, T;
     Lst lst;
+    const uint32_t *nplain; // the host launched no plain form this round: *nplain (blocks listed for it) must be 0
 };
 
 // list record: [rank:20 @40][0:20][suffix:20 @0]
 template <bool QUAD>
 __global__ void __launch_bounds__(TR_THREADS) tail_round(TailArgs a)
 {
+    if (QUAD && a.nplain && blockIdx.x == 0 && threadIdx.x == 0 && *a.nplain != 0u) atomicOr(a.err, 4u); // (loud, not wrong bytes)
     uint32_t b, tile;
     if (!wg_map(a.T, a.lst, b, tile)) return;
     const uint32_t len = a.len[b];
@@ -2358,7 +2360,9 @@ __global__ void __launch_bounds__(1024) round_begin(Batch bt, uint32_t B, uint32
     // a block with small groups only may look three h-blocks ahead (depth 4h, three gathers per suffix):
     // worth it once few suffixes are left -- in the block, or in the whole batch -- when rounds are latency-bound
     const bool few = (uint64_t)gT * QUAD_DIV < n || (uint64_t)sum[0] * QUAD_DIV < sum[3];
-    const uint32_t quad = (valid && gA == 0u && gTl != 0u && few && h < (1u << 28)) ? 1u : 0u;
+    // (h == H_DONE -- identical rotations, keyed on the index -- takes the depth x4 kernel as well: it keys them the same way,
+    // and once every block with small groups is on it the host stops launching the plain form at all)
+    const uint32_t quad = (valid && gA == 0u && gTl != 0u && few && (h < (1u << 28) || h == H_DONE)) ? 1u : 0u;
     if (valid) bt.gateT[b] = gTl | (quad ? QUAD_BIT : 0u);
     // order-preserving lists: position = listed blocks in lower lanes + in earlier wavefronts
     // (list 3 only counts: blocks that HOLD small groups, sitting out or not -- the host bounds the next round with it)
@@ -3079,14 +3083,23 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal, bool is_re
         }
     };
     // -- small groups: one kernel per form (depth x2 / depth x4); survivors move to the other list buffer
+    // (all_quad: the last summary read shows no block in SWEEP mode, none with a big list and every block that holds small
+    // groups on the depth x4 form -- all of which only ever stays so --: the plain form has no block to work on and is not
+    // launched; the depth x4 kernel checks the list it would have had)
+    bool all_quad = false;
     auto run_T = [&]() {
         const uint32_t tt = (maxT + TR_T - 1) / TR_T;
         if (!nT || !tt) return;
         KSpan ks(ctx, K_TAIL_ROUND, 0, nQ ? 2 : 1);
         ta.T = tt | (few_blocks(nT) ? WG_SPREAD : 0u);
         ta.tag = a.tag;
-        ta.lst = Lst{actP, bt.nlist + L_P, B};
-        tail_round<false><<<dim3(xcd_grid(ta.T, nT)), TR_THREADS, 0, st>>>(ta);
+        ta.nplain = nullptr;
+        if (!(all_quad && nQ)) {
+            ta.lst = Lst{actP, bt.nlist + L_P, B};
+            tail_round<false><<<dim3(xcd_grid(ta.T, nT)), TR_THREADS, 0, st>>>(ta);
+        } else {
+            ta.nplain = bt.nlist + L_P;
+        }
         if (nQ) {
             ta.lst = Lst{bt.actQ, bt.nlist + L_Q, B};
             tail_round<true><<<dim3(xcd_grid(ta.T, nQ)), TR_THREADS, 0, st>>>(ta);
@@ -3162,6 +3175,7 @@ int bwt_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal, bool is_re
             nT = std::min(B, pT + pA + cS);
             nQ = nT;
             maxT = std::min(nmax, mT + std::max(mA, cS ? mS : 0u));
+            all_quad = pS == 0u && pA == 0u && cS == 0u && pT != 0u && s[4] == pT;
         }
         if (round == 0) {
             // Nothing is known yet, and text-like batches have no block in SWEEP mode: the big-list and small-group

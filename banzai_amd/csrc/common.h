@@ -510,7 +510,8 @@ int huff_pack(bzh_ctx *ctx, uint32_t B, uint32_t mmax, uint8_t *d_out, uint64_t 
 // (one batch, no host in between: zeroes the output words the batch's bits will occupy -- the first one may carry bits owed to
 // it --, checks the capacity on the device and opens or shuts the gate of the pack kernels; hostrec[0] = bits, [1] = fits)
 int huff_pack_gate(bzh_ctx *ctx, uint32_t B, uint8_t *d_out, uint64_t bit_base, uint64_t cap_words, uint32_t seed, bool has_seed,
-                   uint64_t *hostrec);
+                   uint64_t *hostrec, uint32_t tail_bits = 0);
+int huff_frame_stream(bzh_ctx *ctx, uint32_t B, uint8_t *d_out); // huffman.hip: stream header + footer of a one-batch stream, on the device
 int rle1_plan(bzh_ctx *ctx, const uint8_t *d_in, size_t n, bool with_crc = true, bool crc_async = false); // rle1.hip: tables + split from 0
 int rle1_plan_tables(bzh_ctx *ctx, const uint8_t *d_in, size_t n);                 // rle1.hip
 int rle1_plan_split(bzh_ctx *ctx, size_t start, bool with_crc, size_t stop, bool crc_async = false); // rle1.hip

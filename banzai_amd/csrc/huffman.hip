@@ -942,10 +942,12 @@ int huff_prepare(bzh_ctx *ctx, uint32_t B, uint32_t mmax)
 // Writes blocks 0..B-1 at bit_base + bitoff[b] of d_out (zero-initialised, 4-byte aligned).
 // What encode_range does on the host between two batches -- read the batch's bit total, check the capacity, zero the words
 // the bits will be ORed into, seed the first word -- for a call of one batch, on the device: T = bitoff[B].
+// (`tail_bits`: bits the caller writes behind the batch's -- the stream footer, 80, when the whole stream is framed on the
+// device: they are zeroed and counted against the capacity here as well)
 __global__ void __launch_bounds__(256) pack_gate(uint32_t *out, uint64_t bit_base, const uint64_t *T, uint64_t cap_words, uint32_t seed,
-                                                 uint32_t has_seed, uint32_t *gate, uint64_t *hostrec)
+                                                 uint32_t has_seed, uint32_t *gate, uint64_t *hostrec, uint32_t tail_bits)
 {
-    const uint64_t t = *T, w0 = bit_base / 32, need = (bit_base + t + 31) / 32 + 1;
+    const uint64_t t = *T, w0 = bit_base / 32, need = (bit_base + t + tail_bits + 31) / 32 + 1;
     const bool ok = need <= cap_words;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *gate = ok ? 1u : 0u;
@@ -958,11 +960,40 @@ __global__ void __launch_bounds__(256) pack_gate(uint32_t *out, uint64_t bit_bas
 }
 
 int huff_pack_gate(bzh_ctx *ctx, uint32_t B, uint8_t *d_out, uint64_t bit_base, uint64_t cap_words, uint32_t seed, bool has_seed,
-                   uint64_t *hostrec)
+                   uint64_t *hostrec, uint32_t tail_bits)
 {
     Batch &bt = ctx->bt;
     pack_gate<<<dim3(2048), 256, 0, ctx->stream>>>(reinterpret_cast<uint32_t *>(d_out), bit_base, bt.bitoff + B, cap_words, seed, has_seed ? 1u : 0u,
-                                                   bt.packgate, hostrec);
+                                                   bt.packgate, hostrec, tail_bits);
+    HIP_TRY(ctx, hipGetLastError());
+    return BZH_OK;
+}
+
+// The stream's frame, written on the device behind the pack of a one-batch stream: "BZh" + level in word 0 (lib/lib.rs:18-22),
+// footer magic + stream CRC behind the body (lib/lib.rs:66-70) -- the CRC folded over the batch's block CRCs in block order
+// (lib/lib.rs:107-108: crc = block ^ rotl(crc, 1)) where crc_finish left them.  The host used to do this between two waits
+// (read the bit total, zero the footer's words, fold, launch): 50 us with the device idle at the end of every step.
+__global__ void frame_stream(uint32_t *out, int level, const uint64_t *T, const BlockDesc *desc, uint32_t B, const uint32_t *gate)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0 || *gate == 0u) return;
+    uint32_t crc = 0;
+    for (uint32_t b = 0; b < B; b++) crc = desc[b].crc ^ ((crc << 1) | (crc >> 31));
+    atomicOr(out, __builtin_bswap32(0x425A6800u | (uint32_t)('0' + level)));
+    const uint32_t words[3] = {0x17724538u, 0x50900000u | (crc >> 16), crc << 16}; // 80 bits
+    const uint64_t pos = 32 + *T;
+    const uint32_t sh = (uint32_t)(pos & 31u);
+    const uint64_t w0 = pos >> 5;
+    for (int k = 0; k < 3; k++) {
+        const uint32_t hi = words[k] >> sh, lo = sh ? words[k] << (32 - sh) : 0u;
+        if (hi) atomicOr(out + w0 + k, __builtin_bswap32(hi));
+        if (lo) atomicOr(out + w0 + k + 1, __builtin_bswap32(lo));
+    }
+}
+
+int huff_frame_stream(bzh_ctx *ctx, uint32_t B, uint8_t *d_out)
+{
+    Batch &bt = ctx->bt;
+    frame_stream<<<dim3(1), 64, 0, ctx->stream>>>(reinterpret_cast<uint32_t *>(d_out), ctx->level, bt.bitoff + B, bt.pdesc, B, bt.packgate);
     HIP_TRY(ctx, hipGetLastError());
     return BZH_OK;
 }

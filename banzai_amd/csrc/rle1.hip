@@ -179,6 +179,36 @@ __device__ __forceinline__ uint32_t block_incl_umax(uint32_t v, uint32_t *lds) /
     return v;
 }
 
+// 16 consecutive table words of a thread as four 16-byte accesses (the tables are 256-byte aligned and a thread's first index
+// is a multiple of 16): a scalar loop made every wavefront load touch 64 different lines for 4 bytes each
+__device__ __forceinline__ void load16(const uint32_t *p, uint32_t e0, uint32_t NT, uint32_t fill, uint32_t (&v)[PC_PER])
+{
+    if (e0 + PC_PER <= NT) {
+#pragma unroll
+        for (int q = 0; q < PC_PER / 4; q++) {
+            const uint4 w = *reinterpret_cast<const uint4 *>(p + e0 + 4 * q);
+            v[4 * q] = w.x;
+            v[4 * q + 1] = w.y;
+            v[4 * q + 2] = w.z;
+            v[4 * q + 3] = w.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < PC_PER; k++) v[k] = e0 + k < NT ? p[e0 + k] : fill;
+    }
+}
+__device__ __forceinline__ void store16(uint32_t *p, uint32_t e0, uint32_t NT, const uint32_t (&v)[PC_PER])
+{
+    if (e0 + PC_PER <= NT) {
+#pragma unroll
+        for (int q = 0; q < PC_PER / 4; q++) *reinterpret_cast<uint4 *>(p + e0 + 4 * q) = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < PC_PER; k++)
+            if (e0 + k < NT) p[e0 + k] = v[k];
+    }
+}
+
 __global__ void __launch_bounds__(1024) plan_carries(PlanArrays pa)
 {
     __shared__ uint32_t lm[16];
@@ -187,11 +217,11 @@ __global__ void __launch_bounds__(1024) plan_carries(PlanArrays pa)
     uint32_t carry = 0;
     for (uint32_t base = 0; base < NT; base += PC_CHUNK) {
         const uint32_t e0 = base + t * PC_PER;
-        uint32_t v[PC_PER], run = 0;
+        uint32_t v[PC_PER], o[PC_PER], run = 0;
+        load16(pa.lrs, e0, NT, NONE32, v);
 #pragma unroll
         for (int k = 0; k < PC_PER; k++) {
-            const uint32_t raw = e0 + k < NT ? pa.lrs[e0 + k] : NONE32;
-            v[k] = raw == NONE32 ? 0u : raw + 1u;
+            v[k] = v[k] == NONE32 ? 0u : v[k] + 1u;
             run = max(run, v[k]);
         }
         tailv[t] = block_incl_umax(run, lm);
@@ -199,9 +229,10 @@ __global__ void __launch_bounds__(1024) plan_carries(PlanArrays pa)
         uint32_t ex = max(carry, t ? tailv[t - 1] : 0u);
 #pragma unroll
         for (int k = 0; k < PC_PER; k++) {
-            if (e0 + k < NT) pa.lrs[e0 + k] = ex ? ex - 1u : NONE32; // exclusive
+            o[k] = ex ? ex - 1u : NONE32; // exclusive
             ex = max(ex, v[k]);
         }
+        store16(pa.lrs, e0, NT, o);
         carry = max(carry, tailv[1023]);
         __syncthreads();
     }
@@ -312,11 +343,9 @@ __global__ void __launch_bounds__(1024) plan_tc(PlanArrays pa)
     for (uint32_t base = 0; base < NT; base += PC_CHUNK) {
         const uint32_t e0 = base + t * PC_PER;
         uint32_t v[PC_PER], sum = 0;
+        load16(pa.csum, e0, NT, 0u, v);
 #pragma unroll
-        for (int k = 0; k < PC_PER; k++) {
-            v[k] = e0 + k < NT ? pa.csum[e0 + k] : 0u;
-            sum += v[k];
-        }
+        for (int k = 0; k < PC_PER; k++) sum += v[k];
         uint32_t tot;
         uint32_t ex = block_excl_add(sum, ls, &tot);
 #pragma unroll
