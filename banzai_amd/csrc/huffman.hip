@@ -973,11 +973,15 @@ int huff_pack_gate(bzh_ctx *ctx, uint32_t B, uint8_t *d_out, uint64_t bit_base, 
 // footer magic + stream CRC behind the body (lib/lib.rs:66-70) -- the CRC folded over the batch's block CRCs in block order
 // (lib/lib.rs:107-108: crc = block ^ rotl(crc, 1)) where crc_finish left them.  The host used to do this between two waits
 // (read the bit total, zero the footer's words, fold, launch): 50 us with the device idle at the end of every step.
-__global__ void frame_stream(uint32_t *out, int level, const uint64_t *T, const BlockDesc *desc, uint32_t B, const uint32_t *gate)
+__global__ void __launch_bounds__(256) frame_stream(uint32_t *out, int level, const uint64_t *T, const BlockDesc *desc, uint32_t B, const uint32_t *gate)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0 || *gate == 0u) return;
+    __shared__ uint32_t crcs[1024]; // (a batch has at most 1,024 blocks: bzh_create) -- loaded by all threads, folded by one from LDS
+    if (*gate == 0u) return;
+    for (uint32_t b = threadIdx.x; b < B && b < 1024u; b += 256) crcs[b] = desc[b].crc;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     uint32_t crc = 0;
-    for (uint32_t b = 0; b < B; b++) crc = desc[b].crc ^ ((crc << 1) | (crc >> 31));
+    for (uint32_t b = 0; b < B; b++) crc = (b < 1024u ? crcs[b] : desc[b].crc) ^ ((crc << 1) | (crc >> 31));
     atomicOr(out, __builtin_bswap32(0x425A6800u | (uint32_t)('0' + level)));
     const uint32_t words[3] = {0x17724538u, 0x50900000u | (crc >> 16), crc << 16}; // 80 bits
     const uint64_t pos = 32 + *T;
@@ -993,7 +997,7 @@ __global__ void frame_stream(uint32_t *out, int level, const uint64_t *T, const 
 int huff_frame_stream(bzh_ctx *ctx, uint32_t B, uint8_t *d_out)
 {
     Batch &bt = ctx->bt;
-    frame_stream<<<dim3(1), 64, 0, ctx->stream>>>(reinterpret_cast<uint32_t *>(d_out), ctx->level, bt.bitoff + B, bt.pdesc, B, bt.packgate);
+    frame_stream<<<dim3(1), 256, 0, ctx->stream>>>(reinterpret_cast<uint32_t *>(d_out), ctx->level, bt.bitoff + B, bt.pdesc, B, bt.packgate);
     HIP_TRY(ctx, hipGetLastError());
     return BZH_OK;
 }
