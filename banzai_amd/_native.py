@@ -92,6 +92,7 @@ SIGNATURES = {
     "bzh_multi_fetch": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_size_t]),
     "bzh_multi_output_device": (ctypes.c_void_p, [ctypes.c_void_p]),
     "bzh_multi_times": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_size_t]),
+    "bzh_multi_debug_slab": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
     "bzh_rle1_split": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_size_t, ctypes.POINTER(Block), ctypes.c_size_t,
                                       szp, u8p, ctypes.c_size_t]),
     "bzh_crc32": (ctypes.c_int, [ctypes.c_void_p, u8p, ctypes.c_size_t, u32p]),
@@ -502,6 +503,9 @@ class MultiContext:
         out = np.empty(max(1, n), dtype=np.uint8)
         self.check(lib().bzh_multi_fetch(self._h, ptr(out), out.size))
         return out[:n].tobytes()
+
+    def debug_slab(self, nbytes):
+        self.check(lib().bzh_multi_debug_slab(self._h, nbytes))
 
     def times(self):
         w = len(self.devices)

@@ -56,6 +56,7 @@ struct bzh_multi {
     size_t n = 0;             // bytes of the loaded input
     bool loaded = false;
     std::vector<size_t> bounds;
+    size_t slab_override = 0; // test hook (bzh_multi_debug_slab): the slab size of the next runs instead of the heuristic
     char err[768] = {0};
     // the chain: start[r] = where worker r's first block begins (-1: a worker before it failed), ready[r]
     std::mutex mu;
@@ -379,13 +380,19 @@ extern "C" int bzh_multi_run(bzh_multi *m, size_t *out_len)
         }
         const int W = (int)m->w.size();
         // slabs (on every worker's device) and their landing buffers (on device 0), sized before the workers start
-        const size_t slab = worst_case_slab(m->bounds, m->level);
+        const size_t slab = m->slab_override ? (m->slab_override + 3) & ~(size_t)3 : worst_case_slab(m->bounds, m->level);
         for (int r = 0; r < W; r++) {
             Worker &k = m->w[r];
+            if (m->slab_override && k.d_part) { // (the hook wants exactly this size: a buffer that only grows would hide it)
+                if (hipSetDevice(k.device) == hipSuccess) hipFree(k.d_part);
+                k.d_part = nullptr;
+                k.part_cap = 0;
+            }
             if (hipSetDevice(k.device) != hipSuccess || ensure_dev(k.d_part, k.part_cap, slab) != BZH_OK) {
                 set_err(m, "hipMalloc for a worker's slab failed");
                 return BZH_E_NOMEM;
             }
+            if (m->slab_override) k.part_cap = slab; // (what the worker offers the encoder)
         }
         if (hipSetDevice(m->w[0].device) != hipSuccess) return BZH_E_HIP;
         m->w[0].d_seg = m->w[0].d_part;
@@ -447,6 +454,15 @@ extern "C" int bzh_multi_fetch(bzh_multi *m, uint8_t *out, size_t cap)
 }
 
 extern "C" const void *bzh_multi_output_device(const bzh_multi *m) { return m ? m->d_out : nullptr; }
+
+// Test hook: the slab a worker encodes into is `bytes` instead of the heuristic's size (0: the heuristic again) -- a slab that is
+// too small makes the worker's encode return BZH_E_CAP, which it answers ONCE with a slab of twice the size.
+extern "C" int bzh_multi_debug_slab(bzh_multi *m, size_t bytes)
+{
+    if (!m) return BZH_E_ARG;
+    m->slab_override = bytes;
+    return BZH_OK;
+}
 
 extern "C" int bzh_multi_encode(bzh_multi *m, const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len, size_t *consumed)
 {

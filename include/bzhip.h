@@ -217,6 +217,9 @@ BZH_API int bzh_multi_fetch(bzh_multi *m, uint8_t *out, size_t cap);
 BZH_API const void *bzh_multi_output_device(const bzh_multi *m); /* the assembled stream on devices[0] (device pointer) */
 /* Wall clocks of the last call per worker, 5 doubles each (ms): load, wait for the chain, tables + split, encode, copy. */
 BZH_API int bzh_multi_times(const bzh_multi *m, double *out, size_t max_workers);
+/* Test hook: the next runs give every worker a slab of `bytes` instead of the heuristic's (0 = the heuristic): a slab that is
+ * too small is answered once with one of twice the size, a second overflow fails the call with BZH_E_CAP. */
+BZH_API int bzh_multi_debug_slab(bzh_multi *m, size_t bytes);
 
 /* ---- stage seams (host pointers; computed on the GPU; used by the parity tests) ------------ */
 

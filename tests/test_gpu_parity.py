@@ -1149,6 +1149,20 @@ def test_multi_device_public_api_and_errors(oracle, native):
         native.MultiContext([0, 63], 9)
     with pytest.raises(native.BzhError):
         native.MultiContext([], 9)
+    # a slab that turns out too small (the slab size is a heuristic): the worker repeats its encode once with twice the room;
+    # a slab that is still too small then fails the call with BZH_E_CAP on every worker's behalf, and the handle stays usable
+    from banzai_amd import corpus
+    text = corpus.enwik_synthetic(24_000_000, seed=91).tobytes()
+    want = oracle.encode(text, 9)
+    with native.MultiContext([0, 0, 0], 9) as m:
+        m.debug_slab(1_600_000)  # (a worker's 8 MB of text need about 2.2 MB)
+        assert m.encode(text) == want
+        m.debug_slab(400_000)
+        with pytest.raises(native.BzhError) as ei:
+            m.encode(text)
+        assert ei.value.status == -4
+        m.debug_slab(0)
+        assert m.encode(text) == want
 
 
 def test_near_periodic_from_the_start(oracle, native):
