@@ -91,12 +91,21 @@ std::vector<size_t> offsets(size_t n, int world) // range boundaries B_0..B_worl
     return out;
 }
 
-size_t worst_case_slab(const std::vector<size_t> &b, int level) // (sharded.worst_case_slab: a heuristic, a slab that is too small is caught)
+// Slab for a worker's bit string -- a BOUND, not an estimate: RLE1 expands a range by at most 5/4 (lib/rle.rs:210-234: five
+// bytes for four), MTF + RLE2 leave at most one symbol per RLE1 byte + EOB (lib/mtf.rs:36), no code is longer than 17 bits
+// (build_table_from_freqs rescales until that holds, lib/huffman.rs:293-296), a selector costs at most 6 bits per 50 symbols
+// (one in the reference's mode), and a block's header, symbol map and coding tables fit 4,400 bytes (HDR_BYTES + the fixed
+// mode's six tables are below it per table).  2.2 bytes per RLE1 byte covers 17 + 6/50 bits.  (Rounds 2-5 sized the slab at
+// 5/4 of the range + 4 KiB a block -- what text needs five times over, but not a bound; the retry with a doubled slab stays
+// behind it and is exercised through bzh_multi_debug_slab.)
+size_t worst_case_slab(const std::vector<size_t> &b, int level)
 {
     size_t rng = 0;
     for (size_t r = 0; r + 1 < b.size(); r++) rng = std::max(rng, b[r + 1] - b[r]);
-    const size_t blocks = rng / ((size_t)(100000 * level - 1) * 4 / 5) + 2;
-    return (rng + rng / 4 + blocks * 4096 + 65536 + 3) & ~(size_t)3;
+    const size_t M = (size_t)(100000 * level - 1);
+    const size_t blocks = rng / (M * 4 / 5) + 2;
+    const size_t rle = rng + rng / 4 + blocks * 8; // RLE1 bytes of the range's blocks (the last block may start in the range and end behind it: + M)
+    return ((rle + M) * 22 / 10 + blocks * 4400 + 65536 + 3) & ~(size_t)3;
 }
 
 int ensure_dev(uint8_t *&p, size_t &cap, size_t need)
@@ -398,7 +407,7 @@ extern "C" int bzh_multi_run(bzh_multi *m, size_t *out_len)
         m->w[0].d_seg = m->w[0].d_part;
         m->w[0].seg_cap = m->w[0].part_cap;
         for (int r = 1; r < W; r++)
-            if (ensure_dev(m->w[r].d_seg, m->w[r].seg_cap, 2 * slab) != BZH_OK) { // (room for a slab that had to be doubled)
+            if (ensure_dev(m->w[r].d_seg, m->w[r].seg_cap, m->slab_override ? 2 * slab : slab) != BZH_OK) { // (the test hook's slab may be doubled)
                 set_err(m, "hipMalloc for a landing buffer on device 0 failed");
                 return BZH_E_NOMEM;
             }

@@ -184,7 +184,7 @@ def encode_sharded(engine, dist=None, rank=0, world=1, side=None):
                 own = engine.crcs(b0, b1)
                 break
             except Exception as e:  # noqa: BLE001
-                # a slab that turned out too small (worst_case_slab is a heuristic): once more with twice the room
+                # a slab that turned out too small (cannot happen with worst_case_slab's bound; a caller may pass its own): once more with twice the room
                 if attempt == 0 and is_cap_error(e) and hasattr(engine, "grow"):
                     engine.grow()
                     t["retries"] = 1
@@ -255,14 +255,18 @@ def min_lookahead(level):
 
 
 def worst_case_slab(n, world, level=9):
-    """Slab size for a rank's bit string: 5/4 of the range (RLE1 expands by at most 5/4; the Huffman stage stays near
-    or below 8 bits per symbol on anything but adversarial frequency tables) plus 4 KiB of headers and tables per
-    block.  Not a proven bound: a slab that is too small is caught, not overrun (BZH_E_CAP -> ShardError on every
-    rank)."""
+    """Slab size for a rank's bit string -- a bound, not an estimate (round 6; the same arithmetic as csrc/multi.hip): RLE1
+    expands a range by at most 5/4 (lib/rle.rs:210-234), MTF + RLE2 leave at most one symbol per RLE1 byte + EOB
+    (lib/mtf.rs:36), no code is longer than 17 bits (lib/huffman.rs:293-296), a selector costs at most 6 bits per 50 symbols,
+    and a block's header, symbol map and coding tables fit 4,400 bytes; a rank's last block may start in its range and end up
+    to M RLE1 bytes behind it.  2.2 bytes per RLE1 byte covers 17 + 6/50 bits.  The retry with a doubled slab (BZH_E_CAP ->
+    engine.grow) stays behind it."""
     b = offsets(n, world)
     rng = max(b[r + 1] - b[r] for r in range(world))
-    blocks = rng // ((100000 * level - 1) * 4 // 5) + 2
-    return (rng + rng // 4 + blocks * 4096 + 65536 + 3) & ~3
+    M = 100000 * level - 1
+    blocks = rng // (M * 4 // 5) + 2
+    rle = rng + rng // 4 + blocks * 8
+    return ((rle + M) * 22 // 10 + blocks * 4400 + 65536 + 3) & ~3
 
 
 class DeviceEngine:
