@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) mtf_tile_last(Batch bt, int32_t *tlast, u
 #pragma unroll 1
     for (uint32_t sub = 0; sub < TL; sub += 2048) {
     const uint32_t p0 = tile * TL + sub + threadIdx.x * 8;
-    if (p0 < n) {
+    if (sub + threadIdx.x * 8 < TL && p0 < n) { // (a tile may be shorter than one sweep of the workgroup: 512 bytes in tiny batches)
         uint2 w = *reinterpret_cast<const uint2 *>(s + p0);
         // only the last byte of a run inside my 8 bytes can be its symbol's last occurrence among them (after a
         // BWT most bytes repeat their neighbour, and equal symbols from one wavefront queue on one LDS word)
@@ -685,6 +685,9 @@ int mtf_run(bzh_ctx *ctx, uint32_t B, uint32_t nmax, uint64_t ntotal)
     // name: a fifth of the walk of a 2,048-byte tile of text).  Tiles of 4,096 bytes halve that share and still leave a large
     // batch three rounds of wavefronts (100 MB: 8.40 -> 8.34 ms); a small batch needs the wavefronts more (28 MB: 3.39 ->
     // 3.49 ms with 4,096) and keeps 2,048.  8,192: no gain anywhere.
+    // (Tiles of 512 bytes for batches of one to four blocks -- more wavefronts for a batch that cannot fill the device -- measured
+    // SLOWER: config 2 1.062 -> 1.099 ms, one text block 1.258 -> 1.304 ms: the list a tile's walk starts from costs more than
+    // the extra wavefronts return.)
     const uint32_t TL = B >= 64u ? 2u * MTF_TILE : MTF_TILE;
     const uint32_t MT = (bt.S + TL - 1) / TL;
     int32_t *tlast = reinterpret_cast<int32_t *>(bt.listA);  // B*MT*256*4 <= B*S*8
