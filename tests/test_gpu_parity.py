@@ -468,6 +468,30 @@ def test_output_capacity_error(native):
         assert e.value.status == -4
 
 
+def test_output_capacity_boundary_of_a_framed_stream(oracle, native):
+    """a one-batch stream gets its header and footer on the device (frame_stream), the capacity check included (pack_gate counts
+    the footer's 80 bits): with exactly the room include/bzhip.h asks for -- the stream rounded up to 4 bytes, plus 4 -- the call
+    succeeds and nothing is written behind it; with 8 bytes less it fails with BZH_E_CAP and the context stays usable"""
+    import torch
+    dev = torch.device("cuda", 0)
+    for data in (cases.repeats(700_000, 8), cases.gen(1_000_000, "random", 8)[:300_001], b"q"):
+        want = oracle.encode(data, 9)
+        n = len(data)
+        d_in = torch.zeros(n + 16, dtype=torch.uint8, device=dev)
+        d_in[:n] = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+        need = (len(want) + 3) // 4 * 4 + 4
+        d_out = torch.full((need + 64,), 0xA5, dtype=torch.uint8, device=dev)
+        with native.Context(0, 9, 4) as ctx:
+            ln = ctx.encode_device(d_in.data_ptr(), n, d_out.data_ptr(), need)
+            got = d_out.cpu().numpy()
+            assert got[:ln].tobytes() == want and bool((got[need:] == 0xA5).all())
+            if need > 16:
+                with pytest.raises(native.BzhError) as e:
+                    ctx.encode_device(d_in.data_ptr(), n, d_out.data_ptr(), need - 8)
+                assert e.value.status == -4
+            assert ctx.encode(data) == want
+
+
 def test_full_size_properties_config3(native, oracle):
     """BASELINE.json configs[2] at full size (100,000,000 bytes): properties that do not need the
     encoding oracle -- libbz2 and the in-repo decoder reproduce the input (pins every CRC, table and block cut), the block table
