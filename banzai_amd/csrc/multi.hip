@@ -151,8 +151,10 @@ void run_one(bzh_multi *m, int r)
     Worker &k = m->w[r];
     const int W = (int)m->w.size();
     long long next = -1; // what worker r + 1 is told (-1: failed)
+    bool published = false;
     auto publish = [&]() {
-        if (r + 1 >= W) return;
+        if (published || r + 1 >= W) return;
+        published = true;
         {
             std::lock_guard<std::mutex> g(m->mu);
             m->start[r + 1] = next;
@@ -369,7 +371,14 @@ extern "C" int bzh_multi_load(bzh_multi *m, const uint8_t *in, size_t n)
         const int W = (int)m->w.size();
         m->bounds = offsets(n, W);
         std::vector<std::thread> th;
-        for (int r = 0; r < W; r++) th.emplace_back(load_one, m, r, in);
+        for (int r = 0; r < W; r++)
+            th.emplace_back([m, r, in]() {
+                try {
+                    load_one(m, r, in);
+                } catch (...) { // (nothing may unwind out of a thread: the failure is a status like any other)
+                    fail(m->w[r], BZH_E_NOMEM, "exception in the worker (out of host memory?)");
+                }
+            });
         for (auto &t : th) t.join();
         const int st = first_error(m, "load");
         m->loaded = st == BZH_OK;
@@ -415,7 +424,24 @@ extern "C" int bzh_multi_run(bzh_multi *m, size_t *out_len)
         m->ready.assign(W, 0);
         m->ready[0] = 1;
         std::vector<std::thread> th;
-        for (int r = 0; r < W; r++) th.emplace_back(run_one, m, r);
+        for (int r = 0; r < W; r++)
+            th.emplace_back([m, r, W]() {
+                try {
+                    run_one(m, r);
+                } catch (...) {
+                    fail(m->w[r], BZH_E_NOMEM, "exception in the worker (out of host memory?)");
+                    if (r + 1 < W) { // (the worker behind must not wait for ever: whatever was or was not published, it hears -1 now)
+                        {
+                            std::lock_guard<std::mutex> g(m->mu);
+                            if (!m->ready[r + 1]) {
+                                m->start[r + 1] = -1;
+                                m->ready[r + 1] = 1;
+                            }
+                        }
+                        m->cv.notify_all();
+                    }
+                }
+            });
         for (auto &t : th) t.join();
         int st = first_error(m, "encode");
         if (st != BZH_OK) return st;
